@@ -1,0 +1,404 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ from the *imported* reference.
+
+Runs ONLY in the build container (needs /root/reference); the outputs (.npz / .json, data only)
+are committed, this script is committed, the reference's source is never copied.
+
+Shims: an empty in-memory `apex`/`apex.amp`; `device='cpu'` in both reference
+modules; `yaml.load` given SafeLoader (PyYAML >= 6).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, meta.json
+
+Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
+G4 vote helpers, G5 load_network_spec, G6 one train_dcll step, G7 dense layer steps,
+G8 image2spiketrain (seeded).
+"""
+import json
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+import yaml
+
+REF = os.environ.get("DCLL_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    apex = types.ModuleType("apex")
+    apex.amp = types.ModuleType("apex.amp")
+    sys.modules["apex"] = apex
+    sys.modules["apex.amp"] = apex.amp
+    _load = yaml.load
+    yaml.load = lambda stream, Loader=None: _load(stream, Loader=yaml.SafeLoader)
+    sys.path.insert(0, REF)
+    import dcll.pytorch_libdcll as lib
+    import networks as nets
+    import data.utils as du
+    lib.device = "cpu"
+    nets.device = "cpu"
+    return lib, nets, du
+
+
+def seed(s=1):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def state_dict_np(module, prefix="sd/"):
+    return {prefix + k: npy(v) for k, v in module.state_dict().items()}
+
+
+def pack_bits(x):
+    """(…, N) {0,1} float -> uint8 little-endian bit packing along the last axis."""
+    return np.packbits(x.astype(np.uint8), axis=-1, bitorder="little")
+
+
+# ---------------------------------------------------------------------------------------------
+def g1_layer_steps(lib):
+    """Single Conv2dDCLLlayer, 3 consecutive steps from zero state (state in(t) = state out(t-1)); several variants."""
+    cases = {
+        # name: (Cin, Cout, k, pad, pool, im_dims, wrp, random_tau, output_layer, B)
+        "radio_l0": (1, 32, 7, 3, 1, (16, 16), 1.0, True, False, 3),
+        "radio_l1": (32, 32, 7, 3, 1, (16, 16), 1.0, True, False, 1),
+        "radio_l2_out": (32, 32, 7, 3, 1, (16, 16), 1.0, True, True, 1),
+        "radio_norp": (32, 32, 7, 3, 1, (16, 16), 0.0, True, False, 1),
+        "scalar_tau": (4, 8, 5, 2, 1, (12, 10), 1.0, False, False, 3),
+        "mnist_l0": (1, 16, 7, 2, 2, (28, 28), 0.0, False, False, 2),
+        "mnist_l2": (24, 32, 7, 2, 2, (11, 11), 0.0, True, True, 2),
+        "ref_tuple": (2, 64, (1, 3), (0, 1), (1, 2), (1, 128), 1.0, True, False, 2),
+        "pool3": (3, 5, 3, 1, 3, (9, 9), 0.5, False, False, 2),
+    }
+    out = {}
+    meta = {}
+    for name, (cin, cout, k, pad, pool, im, wrp, rtau, outl, B) in cases.items():
+        seed(7)
+        layer = lib.Conv2dDCLLlayer(cin, cout, kernel_size=k, padding=pad, pooling=pool, im_dims=im,
+                                    target_size=24, alpha=.92, alphas=.85, alpharp=.65, wrp=wrp,
+                                    act=torch.nn.Sigmoid(), lc_ampl=.5, random_tau=rtau, spiking=True,
+                                    lc_dropout=False, output_layer=outl).init_hiddens(B)
+        # make the conv drive strong enough that both spike values occur after step 0
+        with torch.no_grad():
+            layer.i2h.weight.mul_(30.0)
+            layer.i2h.bias.mul_(0.05)
+        pre = "g1/%s/" % name
+        out.update(state_dict_np(layer, pre + "sd/"))
+        for t in range(3):
+            x = (torch.rand(B, cin, *im) < 0.15).float()
+            o, p, pv, v = layer.forward(x)
+            st_out = [npy(s) for s in layer.i2h.state]
+            out[pre + "x%d" % t] = npy(x)
+            for i, nm in enumerate(layer.i2h.state._fields):
+                out[pre + "out_%s%d" % (nm, t)] = st_out[i]
+            out[pre + "o%d" % t] = npy(o)
+            out[pre + "p%d" % t] = npy(p)
+            out[pre + "pv%d" % t] = npy(pv)
+            out[pre + "v%d" % t] = npy(v)
+        meta[name] = dict(cin=cin, cout=cout, k=k, pad=pad, pool=pool, im=im, wrp=wrp, random_tau=rtau,
+                          output_layer=outl, B=B, alpharp=.65)
+    np.savez_compressed(os.path.join(OUT, "g1_layer_steps.npz"), **out)
+    return meta
+
+
+def make_args(**kw):
+    a = dict(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    a.update(kw)
+    return Namespace(**a)
+
+
+def synth_iq(B, L=128, s=1):
+    g = torch.Generator().manual_seed(s)
+    return 0.4 * torch.randn(B, 2, 1, L, generator=g)
+
+
+def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.0):
+    convs = nets.load_network_spec(os.path.join(REF, "networks", yaml_name))
+    seed(1)
+    net = nets.ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                           opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    if weight_gain != 1.0:
+        with torch.no_grad():
+            for s in net.dcll_slices:
+                s.dclllayer.i2h.weight.mul_(weight_gain)
+    x = synth_iq(B, 128, 1)
+    labels = torch.randint(0, 24, (B,), generator=torch.Generator().manual_seed(2))
+    y1h = du.to_one_hot(labels, 24)
+    np.random.seed(3)
+    spikes, targets = du.iq2spiketrain(x, y1h, out_w=R, out_h=R, max_duration=T)
+    xin = torch.Tensor(spikes)
+    out = {}
+    for i, s in enumerate(net.dcll_slices):
+        out.update(state_dict_np(s.dclllayer, "sd/%d/" % i))
+    out["iq"] = npy(x)
+    out["labels"] = labels.numpy()
+    cells = np.zeros((T, B), dtype=np.int32)
+    for t in range(T):
+        for b in range(B):
+            cells[t, b] = int(np.flatnonzero(spikes[t, b, 0].reshape(-1))[0])
+    out["cells"] = cells
+    nl = len(net.dcll_slices)
+    spk = [[] for _ in range(nl)]
+    pl = [[] for _ in range(nl)]
+    minabs = np.zeros((nl, T), dtype=np.float32)
+    ol = []
+    traces = {}
+    net.reset()
+    net.eval()
+    for t in range(T):
+        cur = xin[t]
+        for i, s in enumerate(net.dcll_slices):
+            if full_traces:
+                for j, nm in enumerate(s.dclllayer.i2h.state._fields):
+                    traces.setdefault("tr/%d/in_%s" % (i, nm), []).append(npy(s.dclllayer.i2h.state[j]))
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            pooled_s = s.dclllayer.pool((v > 0).float())
+            spk[i].append(pack_bits(npy(pooled_s).reshape(B, -1)))
+            pl[i].append(npy(p))
+            minabs[i, t] = float(v.detach().abs().min())
+            if full_traces:
+                traces.setdefault("tr/%d/v" % i, []).append(npy(v))
+                traces.setdefault("tr/%d/pv" % i, []).append(npy(pv))
+            if s.dclllayer.output_layer:
+                ol.append(npy(o))
+            cur = o
+    t1h = torch.Tensor(targets)
+    accs = net.accuracy(t1h)
+    conf = net.confusion_matrix(t1h)
+    for i in range(nl):
+        out["spikes/%d" % i] = np.stack(spk[i])          # (T,B,ceil(CHW/8)) uint8, C-major flatten
+        out["p/%d" % i] = np.stack(pl[i])                 # (T,B,24)
+        out["clout/%d" % i] = np.array(net.dcll_slices[i].clout)  # (T,B)
+        pred, lab = lib.get_predictions_by_vote(net.dcll_slices[i].clout, t1h)
+        out["vote/%d" % i] = pred.astype(np.int64)
+    out["o_last"] = np.stack(ol)
+    out["minabs_v"] = minabs
+    out["acc"] = np.array(accs, dtype=np.float64)
+    out["confusion"] = conf
+    for k, vlist in traces.items():
+        out[k] = np.stack(vlist)
+    # final neuron state (for the state-carry-over quirk Q3)
+    for i, s in enumerate(net.dcll_slices):
+        for j, nm in enumerate(s.dclllayer.i2h.state._fields):
+            out["final/%d/%s" % (i, nm)] = npy(s.dclllayer.i2h.state[j])
+    return out
+
+
+def g2_rollouts(lib, nets, du):
+    full = rollout(lib, nets, du, "radio_ml_conv.yaml", R=16, T=128, B=2, args=make_args(), full_traces=False)
+    np.savez_compressed(os.path.join(OUT, "g2_radio_r16_t128_b2.npz"), **full)
+    small = rollout(lib, nets, du, "radio_ml_conv.yaml", R=8, T=32, B=3, args=make_args(netscale=0.25),
+                    full_traces=True)
+    np.savez_compressed(os.path.join(OUT, "g2_radio_r8_t32_b3_traces.npz"), **small)
+    norp = rollout(lib, nets, du, "radio_ml_conv.yaml", R=8, T=24, B=2,
+                   args=make_args(netscale=0.25, arp=0.0, random_tau=False), full_traces=True)
+    np.savez_compressed(os.path.join(OUT, "g2_radio_r8_t24_b2_norp_traces.npz"), **norp)
+    return {"full": dict(R=16, T=128, B=2), "small": dict(R=8, T=32, B=3, netscale=0.25),
+            "norp": dict(R=8, T=24, B=2, netscale=0.25, arp=0.0, random_tau=False)}
+
+
+def g2_mnist(lib, nets, du):
+    """BASELINE config 1 plumbing: mnist_conv.yaml, synthetic 28x28, T=50, B=4, arp=0."""
+    convs = nets.load_network_spec(os.path.join(REF, "networks", "mnist_conv.yaml"))
+    seed(1)
+    B, T = 4, 50
+    args = make_args(arp=0.0)
+    net = nets.ConvNetwork(args, (1, 28, 28), B, convs, 10, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                           opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    img = torch.rand(B, 28, 28, generator=torch.Generator().manual_seed(5))
+    labels = torch.randint(0, 10, (B,), generator=torch.Generator().manual_seed(6))
+    np.random.seed(4)
+    spikes, targets = du.image2spiketrain(img.numpy(), du.to_one_hot(labels, 10).numpy(), (1, 28, 28),
+                                          gain=100, min_duration=T - 1, max_duration=T)
+    xin = torch.Tensor(spikes)
+    out = {"img": img.numpy(), "labels": labels.numpy(), "x": pack_bits(spikes.reshape(T, B, -1))}
+    for i, s in enumerate(net.dcll_slices):
+        out.update(state_dict_np(s.dclllayer, "sd/%d/" % i))
+    nl = len(net.dcll_slices)
+    spk = [[] for _ in range(nl)]
+    pl = [[] for _ in range(nl)]
+    ol = []
+    net.reset()
+    for t in range(T):
+        cur = xin[t]
+        for i, s in enumerate(net.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            spk[i].append(pack_bits(npy(s.dclllayer.pool((v > 0).float())).reshape(B, -1)))
+            pl[i].append(npy(p))
+            if s.dclllayer.output_layer:
+                ol.append(npy(o))
+            cur = o
+    for i in range(nl):
+        out["spikes/%d" % i] = np.stack(spk[i])
+        out["p/%d" % i] = np.stack(pl[i])
+        out["clout/%d" % i] = np.array(net.dcll_slices[i].clout)
+    out["o_last"] = np.stack(ol)
+    out["acc"] = np.array(net.accuracy(torch.Tensor(targets)))
+    np.savez_compressed(os.path.join(OUT, "g2_mnist_t50_b4.npz"), **out)
+    return dict(B=B, T=T)
+
+
+def g3_iq(du):
+    out = {}
+    seed(1)
+    # boundary / out-of-range / exact values
+    special = np.array([-2.0, -1.0, -0.999999, -0.5, -1e-3, -0.0, 0.0, 1e-7, 1e-3, 0.25, 0.5, 0.7071, 0.999999,
+                        1.0, 1.5, 3.0], dtype=np.float32)
+    for R in (16, 28, 128):
+        B, L = 8, 64
+        x = 0.5 * torch.randn(B, 2, 1, L)
+        x[0, 0, 0, :16] = torch.from_numpy(special)
+        x[0, 1, 0, :16] = torch.from_numpy(special[::-1].copy())
+        # values sitting near cell boundaries of the gamma curve
+        cells = np.arange(1, R, dtype=np.float64) / (R - 1)
+        bnd = np.sign(2 * cells - 1) * np.abs(2 * cells - 1) ** 1.2
+        n = min(L, len(bnd))
+        x[1, 0, 0, :n] = torch.from_numpy(bnd[:n].astype(np.float32))
+        x[1, 1, 0, :n] = torch.from_numpy(np.nextafter(bnd[:n].astype(np.float32), np.float32(-2)))
+        y = du.to_one_hot(torch.arange(B) % 24, 24)
+        for T in (L, L // 2):
+            np.random.seed(11)
+            st, tg = du.iq2spiketrain(x, y, out_w=R, out_h=R, max_duration=T)
+            np.random.seed(11)
+            t0 = np.random.randint(0, L - T + 1)
+            assert st.sum() == T * B
+            idx = st.reshape(T, B, -1).argmax(-1)
+            out["R%d_T%d/x" % (R, T)] = npy(x)
+            out["R%d_T%d/cell" % (R, T)] = idx.astype(np.int32)      # q*R + i
+            out["R%d_T%d/t0" % (R, T)] = np.array(t0)
+            out["R%d_T%d/target" % (R, T)] = np.asarray(tg, dtype=np.float32)
+    # non-square plane, non-default bounds, no gamma
+    x = 0.7 * torch.randn(5, 2, 1, 32)
+    y = du.to_one_hot(torch.arange(5) % 24, 24)
+    np.random.seed(12)
+    st, _ = du.iq2spiketrain(x, y, out_w=20, out_h=12, min_I=-2, max_I=1.5, min_Q=-0.5, max_Q=0.75,
+                             max_duration=32, do_gamma=False)
+    out["rect/x"] = npy(x)
+    out["rect/cell"] = st.reshape(32, 5, -1).argmax(-1).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "g3_iq2spiketrain.npz"), **out)
+
+
+def g4_votes(lib):
+    rng = np.random.RandomState(5)
+    T, B, C = 9, 64, 5
+    clout = [rng.randint(0, C, size=B) for _ in range(T)]
+    # force ties: sample 0 alternates, sample 1 has a late majority tie
+    for t in range(T):
+        clout[t][0] = [3, 1, 3, 1, 2, 2, 4, 4, 0][t]
+        clout[t][1] = [2, 2, 0, 0, 1, 1, 3, 3, 4][t]
+    lab = rng.randint(0, C, size=B)
+    y = torch.zeros(T, B, C)
+    y[:, np.arange(B), lab] = 1
+    pred, labv = lib.get_predictions_by_vote(clout, y)
+    acc = lib.accuracy_by_vote(clout, y)
+    np.savez_compressed(os.path.join(OUT, "g4_votes.npz"), clout=np.array(clout), labels=lab,
+                        pred=pred.astype(np.int64), labv=labv.astype(np.int64), acc=np.array(acc))
+
+
+def g5_specs(nets):
+    res = {}
+    for n in ("radio_ml_conv.yaml", "mnist_conv.yaml", "radio_ml_conv_ref.yaml"):
+        res[n] = nets.load_network_spec(os.path.join(REF, "networks", n))
+    return res
+
+
+def g6_train_step(lib, nets, du):
+    """Three post-burn-in train_dcll steps on the reduced radio net (for SURVEY 8(f)-2)."""
+    convs = nets.load_network_spec(os.path.join(REF, "networks", "radio_ml_conv.yaml"))
+    seed(1)
+    B, R, T = 3, 8, 6
+    args = make_args(netscale=0.25)
+    opt_param = {"betas": [0.0, .95], "weight_decay": 10.0}
+    net = nets.ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                           opt=torch.optim.Adam, opt_param=opt_param, learning_rates=[1e-6], burnin=3)
+    net.reset(True)
+    x = synth_iq(B, 128, 4)
+    labels = torch.randint(0, 24, (B,), generator=torch.Generator().manual_seed(2))
+    np.random.seed(3)
+    spikes, targets = du.iq2spiketrain(x, du.to_one_hot(labels, 24), out_w=R, out_h=R, max_duration=T)
+    xin, tg = torch.Tensor(spikes), torch.Tensor(targets)
+    out = {"x": spikes.astype(np.float32), "targets": np.asarray(targets, dtype=np.float32)}
+    for i, s in enumerate(net.dcll_slices):
+        out.update(state_dict_np(s.dclllayer, "sd0/%d/" % i))
+    net.reset()
+    net.train()
+    for t in range(T):
+        net.learn(xin[t], tg[t])
+        for i, s in enumerate(net.dcll_slices):
+            if s.iter >= s.burnin:
+                out["grad/%d/%d/w" % (t, i)] = npy(s.dclllayer.i2h.weight.grad)
+                out["grad/%d/%d/b" % (t, i)] = npy(s.dclllayer.i2h.bias.grad)
+    for i, s in enumerate(net.dcll_slices):
+        out.update(state_dict_np(s.dclllayer, "sd1/%d/" % i))
+    np.savez_compressed(os.path.join(OUT, "g6_train_steps.npz"), **out)
+
+
+def g7_dense(lib):
+    out = {}
+    for name, wrp, rtau in (("rrp", 1.0, False), ("plain", 0.0, False), ("plain_rtau", 0.0, True)):
+        seed(9)
+        layer = lib.DenseDCLLlayer(40, 24, target_size=10, alpha=.9, alphas=.85, alpharp=.65, wrp=wrp,
+                                   random_tau=rtau).init_hiddens(5)
+        with torch.no_grad():
+            layer.i2h.weight.mul_(200.0)
+            layer.i2h.bias.mul_(0.02)
+        pre = "g7/%s/" % name
+        out.update(state_dict_np(layer, pre + "sd/"))
+        for t in range(3):
+            x = (torch.rand(5, 40) < 0.2).float()
+            o, p, pv, v = layer.forward(x)
+            out[pre + "x%d" % t] = npy(x)
+            out[pre + "o%d" % t] = npy(o)
+            out[pre + "p%d" % t] = npy(p)
+            out[pre + "pv%d" % t] = npy(pv)
+            out[pre + "v%d" % t] = npy(v)
+            for i, nm in enumerate(layer.i2h.state._fields):
+                out[pre + "out_%s%d" % (nm, t)] = npy(layer.i2h.state[i])
+    np.savez_compressed(os.path.join(OUT, "g7_dense.npz"), **out)
+
+
+def g8_image(du):
+    rng = np.random.RandomState(3)
+    x = rng.rand(3, 6, 6).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[[1, 4, 7]]
+    np.random.seed(21)
+    a, tg = du.image2spiketrain(x, y, (1, 6, 6), gain=100, min_duration=19, max_duration=20)
+    np.savez_compressed(os.path.join(OUT, "g8_image2spiketrain.npz"), x=x, y=y,
+                        spikes=pack_bits(a.reshape(20, 3, -1)), target=np.asarray(tg))
+
+
+def main():
+    lib, nets, du = import_reference()
+    torch.set_num_threads(1)        # pin the oneDNN reduction schedule used for the fixtures
+    meta = {
+        "torch": torch.__version__,
+        "numpy": np.__version__,
+        "torch_num_threads": torch.get_num_threads(),
+        "torch_config": torch.__config__.show(),
+        "g1": g1_layer_steps(lib),
+        "g2": g2_rollouts(lib, nets, du),
+        "g2_mnist": g2_mnist(lib, nets, du),
+        "g5": {k: [{kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in d.items()} for d in v]
+               for k, v in g5_specs(nets).items()},
+    }
+    g3_iq(du)
+    g4_votes(lib)
+    g6_train_step(lib, nets, du)
+    g7_dense(lib)
+    g8_image(du)
+    with open(os.path.join(OUT, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, default=lambda o: list(o))
+    for fn in sorted(os.listdir(OUT)):
+        print("%-40s %8d" % (fn, os.path.getsize(os.path.join(OUT, fn))))
+
+
+if __name__ == "__main__":
+    main()
