@@ -1,0 +1,157 @@
+/*
+ * dcll_hip.h — C ABI of libdcll_hip.so: the MI355X (gfx950) replacement for the per-timestep DCLL layer
+ * forward of ohjay/snn-modulation-classification.
+ *
+ * The reference exposes a Python object protocol, not an FFI; the seam this ABI replaces is
+ *     o, p, pv, pvmem = self.dclllayer.forward(input)          dcll/pytorch_libdcll.py:657
+ * i.e. Conv2dDCLLlayer.forward (:599-608) -> ContinuousConv2D.forward (:407-426) /
+ * ContinuousRelativeRefractoryConv2D.forward (:485-509), and DenseDCLLlayer.forward (:250-255) ->
+ * CLLDenseModule.forward (:131-148) / CLLDenseRRPModule.forward (:171-195), plus the per-step vote collection of
+ * DCLLClassification.forward (:722-729) and the T-loop of test_radio_ml.py:144-145.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch types. All pointers are DEVICE pointers (HBM) unless marked host.
+ *   - every buffer is allocated and owned by the caller (PyTorch-ROCm tensors); the library never allocates
+ *     persistent device memory and never frees anything.
+ *   - tensors are contiguous fp32, NCHW, unless a packed layout is documented at the parameter.
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream) and never
+ *     synchronise internally; thread-safe for distinct (stream, state) pairs.
+ *   - return value: DCLL_OK (0) or a negative DCLL_ERR_* code; never throws across the ABI.
+ *     dcll_last_error() returns a thread-local, human-readable message for the last failing call.
+ *   - arithmetic contract (bit-level, see DESIGN.md "Pinned arithmetic"):
+ *       eps0' = x*tau_s + alphas*eps0         three separately rounded fp32 ops (no FMA contraction)
+ *       eps1' = alpha*eps1 + eps0'*tau_m      idem
+ *       pvmem[co,y,x] = fmaf-chain starting from bias[co], over k = (ci-pair cp, ky, kx, ci = 2cp+h), in that
+ *                       nesting order, zero padding contributing fmaf(0, w, acc); one rounding per product
+ *       arp' = alpharp*arp ; v = pvmem + arp' ; s = v > 0 ; arp'' = arp' - s*wrp     (refractory variant)
+ *       pv = 1/(1+exp(-v)) (not bit-pinned) ; readouts p,o fp32 (not bit-pinned; |err| <= 1e-4)
+ */
+#ifndef DCLL_HIP_H
+#define DCLL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCLL_ABI_VERSION 1
+
+enum {
+    DCLL_OK = 0,
+    DCLL_ERR_INVALID = -1,      /* bad descriptor / null pointer / size mismatch            */
+    DCLL_ERR_UNSUPPORTED = -2,  /* legal in the reference but not implemented by this build */
+    DCLL_ERR_LAUNCH = -3        /* HIP runtime reported an error (message has the string)   */
+};
+
+/* Geometry + constants of one Conv2dDCLLlayer (ctor: dcll/pytorch_libdcll.py:513-581). */
+typedef struct dcll_conv_desc {
+    int32_t c_in, c_out;        /* i2h.weight is (c_out, c_in, kh, kw)                                   */
+    int32_t h, w;               /* input plane = im_dims                                                 */
+    int32_t kh, kw;             /* kernel_size                                                           */
+    int32_t pad_h, pad_w;       /* padding                                                               */
+    int32_t stride, dilation, groups; /* must be 1,1,1 (what ConvNetwork builds, networks/__init__.py:132-145) */
+    int32_t pool_h, pool_w;     /* MaxPool2d(kernel=stride=pool, padding=(pool-1)/2)   :542-549          */
+    int32_t target;             /* target_size: rows of i2o.weight (and output_.weight)                  */
+    int32_t output_layer;       /* !=0: also o = output_(flatten(pv))  :605-606                          */
+    int32_t tau_is_tensor;      /* 0: alpha,tau_m,alphas,tau_s hold 1 float; 1: (c_in,h,w) floats :391-405 */
+    int32_t refractory;         /* !=0: wrp > 0 variant (:485-509), arp state used                       */
+    float alpharp;              /* :497                                                                  */
+    float wrp;                  /* :503                                                                  */
+} dcll_conv_desc;
+
+/* Geometry + constants of one DenseDCLLlayer (ctor: dcll/pytorch_libdcll.py:199-242). */
+typedef struct dcll_dense_desc {
+    int32_t in_features, out_features;  /* i2h.weight is (out, in)                                       */
+    int32_t target;                     /* i2o is Linear(out, target)                                    */
+    int32_t tau_is_tensor;              /* 0: 1 float each; 1: (in_features) floats :119-129             */
+    int32_t refractory;
+    float alpharp, wrp;
+} dcll_dense_desc;
+
+int dcll_version(void);                 /* DCLL_ABI_VERSION of the loaded library                        */
+const char *dcll_last_error(void);      /* thread-local message of the last failing call ("" if none)    */
+
+/* Output spatial sizes of the conv and of the pooled map (get_output_shape :368-375, :593-597). */
+int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *conv_h, int32_t *conv_w, int32_t *pool_h, int32_t *pool_w);
+
+/*
+ * One timestep of Conv2dDCLLlayer.forward — exact drop-in for dcll/pytorch_libdcll.py:599-608.
+ *   x        (B,c_in,h,w)   input spikes (any fp32 values are accepted, the reference does not check)
+ *   W,b      i2h.weight (c_out,c_in,kh,kw), i2h.bias (c_out)
+ *   alpha,tau_m,alphas,tau_s   i2h.alpha, i2h.tau_m__dt, i2h.alphas, i2h.tau_s__dt
+ *   eps0,eps1 (B,c_in,h,w)  neuron state, updated IN PLACE          arp (B,c_out,ch,cw) idem (may be NULL if !refractory)
+ *   i2o_W (target, c_out*ph*pw), i2o_b (target)        out_W,out_b: output_ layer, NULL unless output_layer
+ *   out_s  (B,c_out,ph,pw) pooled spikes          out_p (B,target) local readout      out_o (B,target) or NULL
+ *   out_pv (B,c_out,ph,pw) pooled sigmoid         out_v (B,c_out,ch,cw) = pvmem (+arp) before pooling, may be NULL
+ */
+int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
+                       const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
+                       float *eps0, float *eps1, float *arp,
+                       const float *i2o_W, const float *i2o_b, const float *out_W, const float *out_b,
+                       float *out_s, float *out_p, float *out_o, float *out_pv, float *out_v,
+                       int32_t B, void *stream);
+
+/* One timestep of DenseDCLLlayer.forward — drop-in for dcll/pytorch_libdcll.py:250-255 (dropout = identity). */
+int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W, const float *b,
+                        const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
+                        float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
+                        float *out_s, float *out_p, float *out_pv, float *out_v, int32_t B, void *stream);
+
+/*
+ * Whole-sequence fast path behind ConvNetwork.test (networks/__init__.py:182-185) for one layer: all T timesteps
+ * of dcll/pytorch_libdcll.py:485-509 / :407-426 in ONE launch with the neuron state held on-chip.
+ * Supported geometry (else DCLL_ERR_UNSUPPORTED): c_in==32, c_out==32, 7x7, pad 3, 16x16, pool 1, time constants
+ * constant over (h,w) per input channel (what randomize_tau produces, :391-405).
+ *   spk_in   (T,B,c_in,h*w/32) uint32   packed input spikes: bit (y*w+x)%32 of word (y*w+x)/32
+ *   tau4     (4,c_in) fp32              rows: alpha, tau_m, alphas, tau_s per input channel
+ *   eps0,eps1,arp                       neuron state in/out as in dcll_conv_lif_step (read at t=0, written after t=T-1)
+ *   spk_out  (T,B,c_out,h*w/32) uint32  packed output spikes (same layout, feeds the next layer); may be NULL
+ *   pv_out   (T,B,c_out,h,w) fp32       sigmoid(v) for the readout GEMM; may be NULL
+ *   v_out    (T,B,c_out,h,w) fp32       debugging / parity only; may be NULL
+ */
+int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+                           const float *tau4, float *eps0, float *eps1, float *arp,
+                           uint32_t *spk_out, float *pv_out, float *v_out, int32_t T, int32_t B, void *stream);
+
+/*
+ * First-layer sequence kernel (c_in==1): the input is exactly one spike per sample per step (iq2spiketrain,
+ * data/utils.py:43-87), given as its cell index q*w+i.  Geometry: c_in==1, c_out<=32, 7x7, pad 3, 16x16, pool 1.
+ *   cells (T,B) int32 ; tau4 (4,1) ; other arguments as dcll_conv_lif_sequence.
+ */
+int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *W, const float *b,
+                                 const float *tau4, float *eps0, float *eps1, float *arp,
+                                 uint32_t *spk_out, float *pv_out, float *v_out, int32_t T, int32_t B, void *stream);
+
+/*
+ * Local readout for many rows at once: out[r, n] = sum_k pv[r,k]*Wt[n,k] + bias[n]   (i2o / output_, :602-606),
+ * fp32 MFMA.  rows = T*B, K = c_out*ph*pw, N = target (<= 32).
+ */
+int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out,
+                 int64_t rows, int32_t K, int32_t N, void *stream);
+
+/*
+ * Per-step argmax + vote (DCLLClassification.forward :724-728, get_predictions_by_vote :44-56):
+ *   logits (T,B,N) -> clout (T,B) int32 (first maximum wins, like torch.argmax) and, if vote != NULL,
+ *   vote (B) int32 = mode over t in [t_begin,T) of clout, ties broken by first occurrence in time.
+ */
+int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t T, int32_t B, int32_t N,
+                     int32_t t_begin, void *stream);
+
+/*
+ * iq2spiketrain on device (data/utils.py:60-82) as a threshold search: cell = #{j : x >= thr[j]} for the
+ * monotone map x -> int(clamp(gamma(x),0,1)*(R-1)); thr_i (w-1) and thr_q (h-1) are produced on the host from
+ * the host encoder so that the result is bit-identical to it.
+ *   iq (B,2,L) fp32 ; cells (T,B) int32 = q*w + i for samples t0..t0+T-1
+ */
+int dcll_iq_encode(const float *iq, const float *thr_i, const float *thr_q, int32_t *cells,
+                   int32_t B, int32_t L, int32_t t0, int32_t T, int32_t w, int32_t h, void *stream);
+
+/* Unpack (T*B, C, HW/32) packed spikes to fp32 (T*B, C, HW) and back — glue for the tensor-level API. */
+int dcll_unpack_spikes(const uint32_t *packed, float *dense, int64_t nwords, void *stream);
+int dcll_pack_spikes(const float *dense, uint32_t *packed, int64_t nwords, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCLL_HIP_H */

@@ -1,0 +1,209 @@
+"""oracle/dcll_oracle.c (pinned fmaf-chain order; the bit-level checker of the HIP kernels) against the golden
+vectors generated from the imported reference.  Protocol:
+  traces eps0/eps1            bit-exact
+  spikes / arp                teacher-forced; a mismatch is allowed only where |v_ref| <= 8*eps_f32*sum|w*eps1|
+  v                           |dv| <= same band
+  pv, logits p / o            |d| <= 1e-4 (stated tolerance of BASELINE.json north_star)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import c_oracle as C
+from conftest import unpack_bits
+
+EPS = float(np.finfo(np.float32).eps)
+LOGIT_TOL = 1e-4
+
+
+def band(eps1, W, b, pad):
+    """8*eps*sum|w*eps1| per conv output — how far two fp32 summation orders can legitimately be apart."""
+    s = F.conv2d(torch.from_numpy(np.abs(eps1)), torch.from_numpy(np.abs(W)), torch.from_numpy(np.abs(b)), 1, pad)
+    return 8 * EPS * s.numpy()
+
+
+G1_CASES = ["radio_l0", "radio_l1", "radio_l2_out", "radio_norp", "scalar_tau", "mnist_l0", "mnist_l2",
+            "ref_tuple", "pool3"]
+
+
+@pytest.mark.parametrize("case", G1_CASES)
+def test_g1_layer_steps(golden, golden_meta, case):
+    g = golden("g1_layer_steps.npz")
+    m = golden_meta["g1"][case]
+    sd = g.sub("g1/%s/sd/" % case)
+    layer = C.OracleConvLayer(sd, m["im"], m["pad"], m["pool"], m["wrp"], m["alpharp"], m["output_layer"])
+    pad = tuple(m["pad"]) if isinstance(m["pad"], list) else (m["pad"], m["pad"])
+    B = m["B"]
+    layer.init_state(B)
+    flips = total = 0
+    for step in range(3):
+        x = g["g1/%s/x%d" % (case, step)]
+        if step > 0:   # teacher forcing: start every step from the reference's state
+            layer.state[0][...] = g["g1/%s/out_eps0%d" % (case, step - 1)]
+            layer.state[1][...] = g["g1/%s/out_eps1%d" % (case, step - 1)]
+            if m["wrp"] > 0:
+                layer.state[2][...] = g["g1/%s/out_arp%d" % (case, step - 1)]
+        o, p, pv, v, s = layer.forward(x)
+        e = lambda n: g["g1/%s/%s%d" % (case, n, step)]
+        assert np.array_equal(layer.state[0], e("out_eps0")), "eps0 must be bit-exact"
+        assert np.array_equal(layer.state[1], e("out_eps1")), "eps1 must be bit-exact"
+        bnd = band(e("out_eps1"), sd["i2h.weight"], sd["i2h.bias"], pad)
+        bnd = bnd + EPS * np.abs(e("v"))      # + the final rounding of pvmem + arp
+        assert np.all(np.abs(v - e("v")) <= bnd), (case, step, np.abs(v - e("v")).max())
+        s_ref = (e("v") > 0).astype(np.float32)
+        s_mine = (v > 0).astype(np.float32)
+        mism = s_ref != s_mine
+        assert np.all(np.abs(e("v"))[mism] <= bnd[mism]), "spike flip outside the rounding band"
+        flips += int(mism.sum()); total += mism.size
+        if not mism.any():
+            assert np.array_equal(s, e("o") if not m["output_layer"] else s)
+            np.testing.assert_allclose(pv, e("pv"), atol=LOGIT_TOL, rtol=0)
+            np.testing.assert_allclose(p, e("p"), atol=LOGIT_TOL, rtol=0)
+            if m["output_layer"]:
+                np.testing.assert_allclose(o, e("o"), atol=LOGIT_TOL, rtol=0)
+            else:
+                assert np.array_equal(o, e("o")), "pooled spikes"
+            if m["wrp"] > 0:
+                np.testing.assert_allclose(layer.state[2], e("out_arp"), atol=1e-6, rtol=0)
+    print("%s: %d/%d spike flips inside band" % (case, flips, total))
+
+
+@pytest.mark.parametrize("name,R_,wrp", [("g2_radio_r8_t32_b3_traces.npz", 8, 1.0),
+                                          ("g2_radio_r8_t24_b2_norp_traces.npz", 8, 0.0)])
+def test_g2_teacher_forced_per_step(golden, name, R_, wrp):
+    """Reduced net with full reference traces: inject the reference state before every step of every layer."""
+    g = golden(name)
+    convs = [dict(padding=3, pooling=1)] * 3
+    sds = [g.sub("sd/%d/" % i) for i in range(3)]
+    net = C.OracleConvNetwork(sds, convs, (R_, R_), wrp)
+    cells = g["cells"]
+    T, B = cells.shape
+    flips = total = 0
+    for step in range(T):
+        x = np.zeros((B, 1, R_ * R_), np.float32)
+        x[np.arange(B), 0, cells[step]] = 1
+        cur = x.reshape(B, 1, R_, R_)
+        for i, l in enumerate(net.layers):
+            if l.state is None:
+                l.init_state(B)
+            l.state[0][...] = g["tr/%d/in_eps0" % i][step]
+            l.state[1][...] = g["tr/%d/in_eps1" % i][step]
+            if wrp > 0:
+                l.state[2][...] = g["tr/%d/in_arp" % i][step]
+            o, p, pv, v, s = l.forward(cur)
+            v_ref = g["tr/%d/v" % i][step]
+            if step + 1 < T:
+                assert np.array_equal(l.state[0], g["tr/%d/in_eps0" % i][step + 1])
+                assert np.array_equal(l.state[1], g["tr/%d/in_eps1" % i][step + 1])
+            bnd = band(l.state[1], sds[i]["i2h.weight"], sds[i]["i2h.bias"], (3, 3))
+            bnd = bnd + EPS * np.abs(v_ref)
+            assert np.all(np.abs(v - v_ref) <= bnd)
+            mism = (v > 0) != (v_ref > 0)
+            assert np.all(np.abs(v_ref)[mism] <= bnd[mism])
+            flips += int(mism.sum()); total += mism.size
+            np.testing.assert_allclose(pv, g["tr/%d/pv" % i][step], atol=LOGIT_TOL, rtol=0)
+            if not mism.any():
+                np.testing.assert_allclose(p, g["p/%d" % i][step], atol=LOGIT_TOL, rtol=0)
+                if i == 2:
+                    np.testing.assert_allclose(o, g["o_last"][step], atol=LOGIT_TOL, rtol=0)
+            # next layer is fed the REFERENCE spikes (teacher forcing across layers too)
+            cur = unpack_bits(g["spikes/%d" % i][step], v.size // B).reshape(v.shape)
+    print("%s: %d/%d spike flips inside band" % (name, flips, total))
+
+
+def test_g2_full_size_input_forced(golden):
+    """radio_ml_conv.yaml R=16 T=128 B=2: every layer is fed the reference's input spikes and runs FREE over all T
+    (per-step reference state is not stored at this size).  A neuron may deviate only after a step where its own
+    |v| sat inside the rounding band; the count is reported and must be tiny."""
+    g = golden("g2_radio_r16_t128_b2.npz")
+    R_ = 16
+    convs = [dict(padding=3, pooling=1)] * 3
+    sds = [g.sub("sd/%d/" % i) for i in range(3)]
+    net = C.OracleConvNetwork(sds, convs, (R_, R_), 1.0)
+    cells = g["cells"]
+    T, B = cells.shape
+    n_neur = 32 * R_ * R_
+    dirty = [np.zeros((B, n_neur), bool) for _ in range(3)]     # neurons whose history has legitimately forked
+    n_first = [0, 0, 0]
+    for step in range(T):
+        x = np.zeros((B, 1, R_ * R_), np.float32)
+        x[np.arange(B), 0, cells[step]] = 1
+        cur = x.reshape(B, 1, R_, R_)
+        for i, l in enumerate(net.layers):
+            o, p, pv, v, s = l.forward(cur)
+            s_ref = unpack_bits(g["spikes/%d" % i][step], n_neur)
+            mism = (s.reshape(B, -1) != s_ref)
+            new = mism & ~dirty[i]
+            if new.any():
+                bnd = band(l.state[1], sds[i]["i2h.weight"], sds[i]["i2h.bias"], (3, 3)).reshape(B, -1)
+                assert np.all(np.abs(v.reshape(B, -1))[new] <= bnd[new]), "first flip outside the rounding band"
+                n_first[i] += int(new.sum())
+                dirty[i] |= new
+            clean = ~dirty[i].any(axis=1)
+            if clean.any():
+                np.testing.assert_allclose(p[clean], g["p/%d" % i][step][clean], atol=LOGIT_TOL, rtol=0)
+            cur = s_ref.reshape(v.shape)
+    print("forked neurons per layer:", n_first, "of", B * n_neur)
+    assert sum(n_first) <= 1e-4 * 3 * B * n_neur
+
+
+def test_g2_mnist_config1(golden):
+    """BASELINE config 1 geometry (28x28, pool 2/1/2, 16/24/32 ch, no refractory) through the C oracle."""
+    g = golden("g2_mnist_t50_b4.npz")
+    convs = [dict(padding=2, pooling=2), dict(padding=2, pooling=1), dict(padding=2, pooling=2)]
+    sds = [g.sub("sd/%d/" % i) for i in range(3)]
+    net = C.OracleConvNetwork(sds, convs, (28, 28), 0.0)
+    xs = unpack_bits(g["x"], 28 * 28)
+    T, B = xs.shape[:2]
+    nflip = 0
+    for step in range(10):
+        cur = xs[step].reshape(B, 1, 28, 28)
+        for i, l in enumerate(net.layers):
+            o, p, pv, v, s = l.forward(cur)
+            s_ref = unpack_bits(g["spikes/%d" % i][step], s[0].size).reshape(s.shape)
+            nflip += int((s != s_ref).sum())
+            if (s == s_ref).all() and nflip == 0:
+                np.testing.assert_allclose(p, g["p/%d" % i][step], atol=LOGIT_TOL, rtol=0)
+            cur = s_ref
+    assert nflip <= 8, nflip
+
+
+@pytest.mark.parametrize("case,wrp", [("rrp", 1.0), ("plain", 0.0), ("plain_rtau", 0.0)])
+def test_g7_dense(golden, case, wrp):
+    g = golden("g7_dense.npz")
+    layer = C.OracleDenseLayer(g.sub("g7/%s/sd/" % case), wrp)
+    for step in range(3):
+        e = lambda n: g["g7/%s/%s%d" % (case, n, step)]
+        if step > 0:
+            layer.state[0][...] = g["g7/%s/out_eps0%d" % (case, step - 1)]
+            layer.state[1][...] = g["g7/%s/out_eps1%d" % (case, step - 1)]
+            if wrp > 0:
+                layer.state[2][...] = g["g7/%s/out_arp%d" % (case, step - 1)]
+        s, p, pv, v = layer.forward(e("x"))
+        assert np.array_equal(layer.state[0], e("out_eps0"))
+        assert np.array_equal(layer.state[1], e("out_eps1"))
+        sd = g.sub("g7/%s/sd/" % case)
+        bnd = 8 * EPS * (np.abs(layer.state[1]) @ np.abs(sd["i2h.weight"]).T + np.abs(sd["i2h.bias"])) \
+            + EPS * np.abs(e("v"))
+        assert np.all(np.abs(v - e("v")) <= bnd)
+        mism = s != e("o")
+        assert np.all(np.abs(e("v"))[mism] <= bnd[mism])
+        if not mism.any():
+            np.testing.assert_allclose(p, e("p"), atol=LOGIT_TOL, rtol=0)
+
+
+def test_argmax_vote_matches_reference_votes(golden):
+    g = golden("g4_votes.npz")
+    clout = g["clout"]
+    T, B = clout.shape
+    logits = np.zeros((T, B, 5), np.float32)
+    logits[np.arange(T)[:, None], np.arange(B)[None, :], clout] = 1.0
+    logits[0, 0, 4] = 1.0    # duplicate maximum: torch.argmax / first-max picks index 3 (the earlier one)
+    c2, vote = C.argmax_vote(logits)
+    assert np.array_equal(c2, clout)
+    assert np.array_equal(vote, g["pred"])
+    # vote window starting later (burn-in) == reference vote over clout[t_begin:]
+    from oracle.torch_ref import predictions_by_vote
+    _, v3 = C.argmax_vote(logits, t_begin=3)
+    assert np.array_equal(v3, predictions_by_vote(list(clout[3:])))
