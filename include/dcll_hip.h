@@ -84,12 +84,14 @@ int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *conv_h, int32_t *conv_
  *   i2o_W (target, c_out*ph*pw), i2o_b (target)        out_W,out_b: output_ layer, NULL unless output_layer
  *   out_s  (B,c_out,ph,pw) pooled spikes          out_p (B,target) local readout      out_o (B,target) or NULL
  *   out_pv (B,c_out,ph,pw) pooled sigmoid         out_v (B,c_out,ch,cw) = pvmem (+arp) before pooling, may be NULL
+ *   scratch 2*B*c_out*ch*cw floats, required iff pooling != 1 (un-pooled spikes and sigmoid), else may be NULL
+ *   i2o_W / out_p may be NULL to skip the local readout (then the call is ContinuousConv2D.forward + pool).
  */
 int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
                        const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
                        float *eps0, float *eps1, float *arp,
                        const float *i2o_W, const float *i2o_b, const float *out_W, const float *out_b,
-                       float *out_s, float *out_p, float *out_o, float *out_pv, float *out_v,
+                       float *out_s, float *out_p, float *out_o, float *out_pv, float *out_v, float *scratch,
                        int32_t B, void *stream);
 
 /* One timestep of DenseDCLLlayer.forward — drop-in for dcll/pytorch_libdcll.py:250-255 (dropout = identity). */

@@ -1,0 +1,124 @@
+"""ctypes binding of libdcll_hip.so (include/dcll_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a DCLLHipError is raised.  The product never
+imports oracle/.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "libdcll_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
+ABI_VERSION = 1
+
+
+class DCLLHipError(RuntimeError):
+    pass
+
+
+class DCLLUnsupported(NotImplementedError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """dcll_conv_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("c_in", "c_out", "h", "w", "kh", "kw", "pad_h", "pad_w", "stride", "dilation", "groups",
+                 "pool_h", "pool_w", "target", "output_layer", "tau_is_tensor", "refractory")] + \
+               [("alpharp", ctypes.c_float), ("wrp", ctypes.c_float)]
+
+
+class DenseDesc(ctypes.Structure):
+    """dcll_dense_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("in_features", "out_features", "target", "tau_is_tensor",
+                                               "refractory")] + \
+               [("alpharp", ctypes.c_float), ("wrp", ctypes.c_float)]
+
+
+_P, _I32, _I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+_DP = ctypes.POINTER(ConvDesc)
+_DDP = ctypes.POINTER(DenseDesc)
+_IP = ctypes.POINTER(ctypes.c_int32)
+
+# every symbol include/dcll_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "dcll_version": (_I32, []),
+    "dcll_last_error": (ctypes.c_char_p, []),
+    "dcll_conv_out_shape": (_I32, [_DP, _IP, _IP, _IP, _IP]),
+    "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_I32, _P]),
+    "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
+    "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 10 + [_I32, _I32, _P]),
+    "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_I32, _I32, _P]),
+    "dcll_readout": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "dcll_argmax_vote": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "dcll_iq_encode": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "dcll_unpack_spikes": (_I32, [_P, _P, _I64, _P]),
+    "dcll_pack_spikes": (_I32, [_P, _P, _I64, _P]),
+}
+
+
+def build(force=False):
+    """Compile csrc/dcll_hip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(CSRC, "dcll_hip.hip")
+    hdr = os.path.join(os.path.dirname(_PKG), "include", "dcll_hip.h")
+    stale = (not os.path.exists(SO_PATH)) or any(
+        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(SO_PATH) for f in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-B", "-C", CSRC])
+    return SO_PATH
+
+
+_lib = None
+
+
+def get():
+    """The loaded library with typed entry points; raises DCLLHipError if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise DCLLHipError(
+                "libdcll_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C %s`. There is no CPU fallback for the DCLL layer forward." % (SO_PATH, CSRC))
+        try:
+            lib = ctypes.CDLL(SO_PATH)
+        except OSError as e:
+            raise DCLLHipError("cannot load %s: %s" % (SO_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError here = header/library mismatch: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dcll_version() != ABI_VERSION:
+            raise DCLLHipError("libdcll_hip.so ABI %d != binding ABI %d" % (lib.dcll_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc == DCLL_OK:
+        return
+    msg = get().dcll_last_error().decode("utf-8", "replace")
+    if rc == DCLL_ERR_UNSUPPORTED:
+        raise DCLLUnsupported("%s: %s" % (what, msg))
+    if rc == DCLL_ERR_INVALID:
+        raise ValueError("%s: %s" % (what, msg))
+    raise DCLLHipError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  The tensor must be contiguous and live on a GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DCLLHipError("DCLL HIP kernels need tensors on an MI355X ('cuda') device, got %s — there is no CPU "
+                           "fallback" % t.device)
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,804 @@
+// dcll_hip.hip — hand-written gfx950 (MI355X, CDNA4) kernels + the C ABI of include/dcll_hip.h.
+//
+// Replaces, for the DCLL hot path of ohjay/snn-modulation-classification:
+//   Conv2dDCLLlayer.forward          dcll/pytorch_libdcll.py:599-608
+//   ContinuousConv2D.forward         dcll/pytorch_libdcll.py:407-426
+//   ContinuousRelativeRefractoryConv2D.forward   dcll/pytorch_libdcll.py:485-509
+//   DenseDCLLlayer.forward / CLLDense*Module.forward   :250-255, :131-148, :171-195
+//   DCLLClassification.forward (argmax per step) + get_predictions_by_vote   :722-729, :44-56
+//   iq2spiketrain cell quantisation  data/utils.py:60-82
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
+// -ffp-contract=off is part of the arithmetic contract: the trace lines are three separately rounded ops.
+//
+// Kernels
+//   k_lif_seq_c32      the hot kernel: one 32->32 7x7 layer, ALL T timesteps, one sample per workgroup.
+//                      8 waves; wave w owns input channels 4w..4w+3 (a K-slice of the implicit GEMM):
+//                      their eps0/eps1 traces (registers + a zero-padded LDS image) and the 2x49 weight
+//                      fragments of v_mfma_f32_32x32x2_f32 (weight-stationary in VGPRs).  The fp32
+//                      accumulator of a 32-channel x 32-pixel tile is handed from wave w to wave w+1 through LDS,
+//                      so the result is ONE fmaf chain in the pinned order of include/dcll_hip.h; waves run
+//                      skewed by one tile (a systolic chain), one s_barrier per tile-stage.
+//   k_lif_seq_c1       first layer (c_in = 1, one input spike per step given as a cell index): VALU fmaf chain.
+//   k_trace / k_conv_lif / k_pool   generic per-step path (any geometry, state in HBM) — the exact drop-in for
+//                      `.forward`; same pinned order.
+//   k_dense_lif        DenseDCLLlayer step.
+//   k_readout          fp32-MFMA GEMM for i2o / output_ over many rows.
+//   k_argmax, k_vote   per-step argmax and vote.
+//   k_iq_encode, k_pack, k_unpack     glue.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dcll_hip.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *msg, const char *who = nullptr)
+{
+    if (who) snprintf(g_err, sizeof(g_err), "%s: %s", who, msg);
+    else snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+#define HIP_CHECK_LAUNCH(name)                                                              \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) {                                                             \
+            snprintf(g_err, sizeof(g_err), "%s: %s", name, hipGetErrorString(e_));          \
+            return DCLL_ERR_LAUNCH;                                                         \
+        }                                                                                   \
+    } while (0)
+
+extern "C" int dcll_version(void) { return DCLL_ABI_VERSION; }
+extern "C" const char *dcll_last_error(void) { return g_err; }
+
+static inline void conv_shape(const dcll_conv_desc *d, int *ch, int *cw, int *ph, int *pw)
+{
+    *ch = d->h + 2 * d->pad_h - d->kh + 1;
+    *cw = d->w + 2 * d->pad_w - d->kw + 1;
+    *ph = (*ch + 2 * ((d->pool_h - 1) / 2) - d->pool_h) / d->pool_h + 1;
+    *pw = (*cw + 2 * ((d->pool_w - 1) / 2) - d->pool_w) / d->pool_w + 1;
+}
+
+static int check_desc(const dcll_conv_desc *d)
+{
+    if (!d) return fail(DCLL_ERR_INVALID, "null descriptor");
+    if (d->c_in < 1 || d->c_out < 1 || d->h < 1 || d->w < 1 || d->kh < 1 || d->kw < 1 || d->pad_h < 0 ||
+        d->pad_w < 0 || d->pool_h < 1 || d->pool_w < 1 || d->target < 0)
+        return fail(DCLL_ERR_INVALID, "descriptor has a non-positive dimension");
+    if (d->stride != 1 || d->dilation != 1 || d->groups != 1)
+        return fail(DCLL_ERR_UNSUPPORTED, "stride/dilation/groups other than 1 are not implemented");
+    int ch, cw, ph, pw;
+    conv_shape(d, &ch, &cw, &ph, &pw);
+    if (ch < 1 || cw < 1 || ph < 1 || pw < 1) return fail(DCLL_ERR_INVALID, "empty conv/pool output");
+    return DCLL_OK;
+}
+
+extern "C" int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *ch, int32_t *cw, int32_t *ph, int32_t *pw)
+{
+    int rc = check_desc(d);
+    if (rc) return rc;
+    int a, b, c, e;
+    conv_shape(d, &a, &b, &c, &e);
+    if (ch) *ch = a;
+    if (cw) *cw = b;
+    if (ph) *ph = c;
+    if (pw) *pw = e;
+    return DCLL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_dev(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// dcll/pytorch_libdcll.py:493-494 — (x*tau_s) + (alphas*eps0) ; (alpha*eps1) + (eps0'*tau_m); every op rounded.
+__device__ __forceinline__ void trace_update(float x, float alpha, float tau_m, float alphas, float tau_s,
+                                             float &e0, float &e1)
+{
+    float a = x * tau_s;
+    float b = alphas * e0;
+    e0 = a + b;
+    float c = alpha * e1;
+    float d = e0 * tau_m;
+    e1 = c + d;
+}
+
+// :497-503 — returns v, updates arp, sets s.
+__device__ __forceinline__ float refractory(float pvmem, float &arp, float alpharp, float wrp, bool &s)
+{
+    float a = alpharp * arp;
+    float v = pvmem + a;
+    s = v > 0.0f;
+    float sw = s ? wrp : 0.0f;      // s*wrp, exact
+    arp = a - sw;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// generic per-step path (state in HBM, any geometry)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_trace(const float *__restrict__ x, const float *__restrict__ alpha, const float *__restrict__ tau_m,
+                        const float *__restrict__ alphas, const float *__restrict__ tau_s, float *__restrict__ eps0,
+                        float *__restrict__ eps1, long n, long per_sample, int tau_is_tensor)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        long q = tau_is_tensor ? (i % per_sample) : 0;
+        float e0 = eps0[i], e1 = eps1[i];
+        trace_update(x[i], alpha[q], tau_m[q], alphas[q], tau_s[q], e0, e1);
+        eps0[i] = e0;
+        eps1[i] = e1;
+    }
+}
+
+// one thread per conv output element (b, co, y, x); pinned fmaf chain (cp, ky, kx, h).
+__global__ void k_conv_lif(dcll_conv_desc d, int ch, int cw, const float *__restrict__ eps1,
+                           const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ arp,
+                           float *__restrict__ s_full, float *__restrict__ pv_full, float *__restrict__ v_out, long n)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int xx = (int)(i % cw);
+    long r = i / cw;
+    int y = (int)(r % ch);
+    r /= ch;
+    int co = (int)(r % d.c_out);
+    long b = r / d.c_out;
+    const float *e = eps1 + b * d.c_in * d.h * d.w;
+    const float *w = W + (long)co * d.c_in * d.kh * d.kw;
+    float acc = bias ? bias[co] : 0.0f;
+    const int npair = (d.c_in + 1) >> 1;
+    for (int cp = 0; cp < npair; ++cp)
+        for (int ky = 0; ky < d.kh; ++ky) {
+            int yy = y + ky - d.pad_h;
+            bool yin = yy >= 0 && yy < d.h;
+            for (int kx = 0; kx < d.kw; ++kx) {
+                int xq = xx + kx - d.pad_w;
+                bool in = yin && xq >= 0 && xq < d.w;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    int ci = 2 * cp + hh;
+                    if (ci < d.c_in) {
+                        float ev = in ? e[((long)ci * d.h + yy) * d.w + xq] : 0.0f;
+                        acc = __builtin_fmaf(ev, w[((long)ci * d.kh + ky) * d.kw + kx], acc);
+                    }
+                }
+            }
+        }
+    float v = acc;
+    bool s;
+    if (d.refractory) {
+        float a = arp[i];
+        v = refractory(acc, a, d.alpharp, d.wrp, s);
+        arp[i] = a;
+    } else {
+        s = v > 0.0f;
+    }
+    if (v_out) v_out[i] = v;
+    s_full[i] = s ? 1.0f : 0.0f;
+    pv_full[i] = sigmoidf_dev(v);
+}
+
+// MaxPool2d(kernel=stride=pool, padding=(pool-1)/2), one thread per pooled element.
+__global__ void k_pool(dcll_conv_desc d, int ch, int cw, int ph, int pw, const float *__restrict__ s_full,
+                       const float *__restrict__ pv_full, float *__restrict__ s_out, float *__restrict__ pv_out, long n)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int px = (int)(i % pw);
+    long r = i / pw;
+    int py = (int)(r % ph);
+    long bc = r / ph;
+    const float *sp = s_full + bc * ch * cw, *pp = pv_full + bc * ch * cw;
+    float ms = -INFINITY, mp = -INFINITY;
+    int y0 = py * d.pool_h - (d.pool_h - 1) / 2, x0 = px * d.pool_w - (d.pool_w - 1) / 2;
+    for (int dy = 0; dy < d.pool_h; ++dy)
+        for (int dx = 0; dx < d.pool_w; ++dx) {
+            int yy = y0 + dy, xq = x0 + dx;
+            if (yy < 0 || yy >= ch || xq < 0 || xq >= cw) continue;
+            ms = fmaxf(ms, sp[yy * cw + xq]);
+            mp = fmaxf(mp, pp[yy * cw + xq]);
+        }
+    s_out[i] = ms;
+    pv_out[i] = mp;
+}
+
+// DenseDCLLlayer step: one thread per (b, o); chain over input features in natural order (pairs (2cp,2cp+1)).
+__global__ void k_dense_lif(dcll_dense_desc d, const float *__restrict__ eps1, const float *__restrict__ W,
+                            const float *__restrict__ bias, float *__restrict__ arp, float *__restrict__ s_out,
+                            float *__restrict__ pv_out, float *__restrict__ v_out, long n)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int o = (int)(i % d.out_features);
+    long b = i / d.out_features;
+    const float *e = eps1 + b * d.in_features;
+    const float *w = W + (long)o * d.in_features;
+    float acc = bias ? bias[o] : 0.0f;
+    for (int k = 0; k < d.in_features; ++k) acc = __builtin_fmaf(e[k], w[k], acc);
+    float v = acc;
+    bool s;
+    if (d.refractory) {
+        float a = arp[i];
+        v = refractory(acc, a, d.alpharp, d.wrp, s);
+        arp[i] = a;
+    } else {
+        s = v > 0.0f;
+    }
+    if (v_out) v_out[i] = v;
+    if (s_out) s_out[i] = s ? 1.0f : 0.0f;
+    if (pv_out) pv_out[i] = sigmoidf_dev(v);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// readout GEMM: out[r,n] = sum_k pv[r,k] * Wt[n,k] + bias[n]      (i2o / output_, :602-606), fp32 MFMA
+//   workgroup = 4 waves = 128 rows x 32 columns; K in chunks of 32 staged through LDS (row stride 33: conflict-free
+//   column reads of the v_mfma_f32_32x32x2_f32 fragments).
+// ------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RO_ROWS = 128, RO_KC = 32, RO_LD = 33;
+
+__global__ __launch_bounds__(256) void k_readout(const float *__restrict__ pv, const float *__restrict__ Wt,
+                                                  const float *__restrict__ bias, float *__restrict__ out,
+                                                  long rows, int K, int N)
+{
+    __shared__ float sA[RO_ROWS * RO_LD];
+    __shared__ float sB[32 * RO_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long row0 = (long)blockIdx.x * RO_ROWS;
+    const int n0 = blockIdx.y * 32;
+    const int col = tid & 31, rsub = tid >> 5;     // 8 row groups of 32 consecutive k
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += RO_KC) {
+        const int k = k0 + col;
+        const bool kin = k < K;
+#pragma unroll
+        for (int i = 0; i < RO_ROWS / 8; ++i) {
+            int rr = rsub + 8 * i;
+            long gr = row0 + rr;
+            sA[rr * RO_LD + col] = (kin && gr < rows) ? pv[gr * K + k] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int nn = rsub + 8 * i;
+            sB[nn * RO_LD + col] = (kin && n0 + nn < N) ? Wt[(long)(n0 + nn) * K + k] : 0.0f;
+        }
+        __syncthreads();
+        const float *a = sA + (wave * 32 + (lane & 31)) * RO_LD + (lane >> 5);
+        const float *b = sB + (lane & 31) * RO_LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < RO_KC / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[2 * kk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int n = n0 + (lane & 31);
+    if (n < N) {
+        const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            long gr = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gr < rows) out[gr * N + n] = acc[r] + bn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// argmax per (t,b) (first maximum, like torch.argmax) and vote per b (Counter.most_common(1): ties -> first seen)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_argmax(const float *__restrict__ logits, int32_t *__restrict__ clout, long rows, int N)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float *l = logits + i * N;
+    int best = 0;
+    float bv = l[0];
+    for (int n = 1; n < N; ++n) {
+        float v = l[n];
+        if (v > bv) { bv = v; best = n; }
+    }
+    clout[i] = best;
+}
+
+constexpr int VOTE_MAXN = 64;
+__global__ __launch_bounds__(64) void k_vote(const int32_t *__restrict__ clout, int32_t *__restrict__ vote, int T,
+                                              int B, int N, int t_begin)
+{
+    __shared__ int cnt[VOTE_MAXN * 64];
+    __shared__ int first[VOTE_MAXN * 64];
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    for (int n = 0; n < N; ++n) { cnt[n * 64 + threadIdx.x] = 0; first[n * 64 + threadIdx.x] = T; }
+    if (b >= B) return;
+    for (int t = t_begin; t < T; ++t) {
+        int c = clout[(long)t * B + b];
+        if (cnt[c * 64 + threadIdx.x]++ == 0) first[c * 64 + threadIdx.x] = t;
+    }
+    int best = -1, bc = 0, bf = 0;
+    for (int n = 0; n < N; ++n) {
+        int c = cnt[n * 64 + threadIdx.x], f = first[n * 64 + threadIdx.x];
+        if (c == 0) continue;
+        if (best < 0 || c > bc || (c == bc && f < bf)) { best = n; bc = c; bf = f; }
+    }
+    vote[b] = best;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// glue: IQ -> cell index, pack / unpack
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_iq_encode(const float *__restrict__ iq, const float *__restrict__ thr_i,
+                            const float *__restrict__ thr_q, int32_t *__restrict__ cells, int B, int L, int t0, int T,
+                            int w, int h)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)T * B) return;
+    int b = (int)(i % B), t = (int)(i / B);
+    float vi = iq[((long)b * 2 + 0) * L + t0 + t];
+    float vq = iq[((long)b * 2 + 1) * L + t0 + t];
+    int ci = 0, cq = 0;
+    for (int j = 0; j < w - 1; ++j) ci += vi >= thr_i[j];
+    for (int j = 0; j < h - 1; ++j) cq += vq >= thr_q[j];
+    cells[i] = cq * w + ci;
+}
+
+__global__ void k_unpack(const uint32_t *__restrict__ packed, float *__restrict__ dense, long nwords)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per output float
+    if (i >= nwords * 32) return;
+    dense[i] = (float)((packed[i >> 5] >> (i & 31)) & 1u);
+}
+
+__global__ void k_pack(const float *__restrict__ dense, uint32_t *__restrict__ packed, long nwords)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per input float; wave = 2 words
+    bool bit = (i < nwords * 32) && dense[i] != 0.0f;
+    unsigned long long m = __ballot(bit);
+    int lane = threadIdx.x & 63;
+    if (lane == 0 && (i >> 5) < nwords) packed[i >> 5] = (uint32_t)m;
+    if (lane == 32 && (i >> 5) < nwords) packed[i >> 5] = (uint32_t)(m >> 32);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// first layer sequence kernel: c_in == 1, 16x16 plane, 7x7 pad 3, pool 1, c_out <= 32.
+//   one workgroup (256 threads = one per pixel) per sample, all T steps; eps0/eps1 of the pixel in registers, eps1
+//   mirrored into a zero-padded 22x22 LDS plane; each thread gathers its 49 taps once per step and runs the fmaf
+//   chain (tap order = the pinned order for c_in == 1) for every output channel with wave-uniform weights.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int PADW = 22;
+
+template <bool REFRACTORY>
+__global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
+                                                    const float *__restrict__ W, const float *__restrict__ bias,
+                                                    const float *__restrict__ tau4, float *__restrict__ eps0_g,
+                                                    float *__restrict__ eps1_g, float *__restrict__ arp_g,
+                                                    uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
+                                                    float *__restrict__ v_out, int T, int B, float alpharp, float wrp)
+{
+    __shared__ float plane[PADW * PADW];
+    const int b = blockIdx.x, pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63, wave = pix >> 6;
+    const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];
+    for (int i = pix; i < PADW * PADW; i += 256) plane[i] = 0.0f;
+    float e0 = eps0_g[(long)b * 256 + pix], e1 = eps1_g[(long)b * 256 + pix];
+    float arp[32];
+#pragma unroll
+    for (int co = 0; co < 32; ++co) arp[co] = (REFRACTORY && co < c_out) ? arp_g[((long)b * c_out + co) * 256 + pix] : 0.0f;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int cell = cells[(long)t * B + b];
+        trace_update(cell == pix ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0, e1);
+        plane[(y + 3) * PADW + x + 3] = e1;
+        __syncthreads();
+        float tap[49];
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) tap[ky * 7 + kx] = plane[(y + ky) * PADW + x + kx];
+        __syncthreads();
+        const long obase = ((long)t * B + b) * c_out;
+#pragma unroll
+        for (int co = 0; co < 32; ++co) {
+            if (co < c_out) {       // wave-uniform
+                const float *w = W + co * 49;
+                float acc = bias[co];
+#pragma unroll
+                for (int k = 0; k < 49; ++k) acc = __builtin_fmaf(tap[k], w[k], acc);
+                float v = acc;
+                bool s;
+                if (REFRACTORY) v = refractory(acc, arp[co], alpharp, wrp, s);
+                else s = v > 0.0f;
+                unsigned long long m = __ballot(s);
+                if (spk_out) {
+                    if (lane == 0) spk_out[(obase + co) * 8 + wave * 2] = (uint32_t)m;
+                    if (lane == 32) spk_out[(obase + co) * 8 + wave * 2 + 1] = (uint32_t)(m >> 32);
+                }
+                if (pv_out) pv_out[(obase + co) * 256 + pix] = sigmoidf_dev(v);
+                if (v_out) v_out[(obase + co) * 256 + pix] = v;
+            }
+        }
+    }
+    eps0_g[(long)b * 256 + pix] = e0;
+    eps1_g[(long)b * 256 + pix] = e1;
+    if (REFRACTORY) {
+#pragma unroll
+        for (int co = 0; co < 32; ++co)
+            if (co < c_out) arp_g[((long)b * c_out + co) * 256 + pix] = arp[co];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// THE HOT KERNEL: 32 -> 32 channels, 7x7 pad 3, 16x16 plane, pool 1, all T steps, one sample per workgroup.
+//
+// Implicit GEMM per step:  V[co, pix] = bias[co] + sum_k Wm[co, k] * E[k, pix],  k = (ci, ky, kx), K = 1568.
+//   MFMA v_mfma_f32_32x32x2_f32: A = Wm fragment (lane: co = lane&31, k = lane>>5), B = E fragment (lane: pixel =
+//   lane&31, k = lane>>5), D[co][pix] with pixel on the lane and 16 channels in registers.  The two k of one
+//   instruction are the input-channel pair (2cp, 2cp+1) at the same tap, so both halves of the wave read LDS at
+//   one immediate offset from a per-lane base.  The instruction is, bit for bit, acc = fmaf(a1,b1,fmaf(a0,b0,acc)).
+//
+// LDS image of eps1 (zero padding shared between rows and between channels):
+//   element (ci, y, x), y,x in [-3,18]  at float offset  ci*361 + (y+3)*19 + (x+3);   only 0<=y,x<16 is ever written.
+//   (x=16..18 of row y aliases x=-3..-1 of row y+1; rows 16..18 of channel c alias rows -3..-1 of channel c+1.)
+//
+// Stage g (one s_barrier per stage): wave w computes tile q = g - w (step t = q>>3, pixel tile m = q&7 = image rows
+//   2m, 2m+1): takes the accumulator of wave w-1 from slot[w-1][(g-1)&1] (wave 0: bias), adds its 98 MFMAs, puts it
+//   in slot[w][g&1].  Wave (g&7) additionally finishes tile g-8 (handed over by wave 7): refractory trace, threshold,
+//   sigmoid, ballot-packed spikes; it keeps the arp of "its" tile m = w in 16 registers for the whole sequence.
+//   At m == 0 a wave first advances the traces of its own 4 input channels by one step (input bits of step t).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int NWAVE = 8, CPW = 4, ROWF = 19, CHF = 361;
+constexpr int EPS1_FLOATS = 32 * CHF + 3 * ROWF + 3 + 61;     // 11673 -> covers (ci=31, y=18, x=18) + slack
+constexpr int SLOT_FLOATS = 16 * 64;
+
+template <bool REFRACTORY>
+__global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, const float *__restrict__ tau4,
+                                                      float *__restrict__ eps0_g, float *__restrict__ eps1_g,
+                                                      float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
+                                                      float *__restrict__ pv_out, float *__restrict__ v_out, int T,
+                                                      int B, float alpharp, float wrp)
+{
+    __shared__ __attribute__((aligned(16))) float lds[EPS1_FLOATS + 3 + NWAVE * 2 * SLOT_FLOATS + 32];
+    float *img = lds;
+    float *slots = lds + ((EPS1_FLOATS + 3) & ~3);
+    float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, kept scalar
+    const long b = blockIdx.x;
+
+    for (int i = tid; i < ((EPS1_FLOATS + 3) & ~3); i += 512) img[i] = 0.0f;
+    if (tid < 32) sbias[tid] = bias[tid];
+
+    // weight fragments: A[co = j][k = h] of MFMA (cp, tap) = W[j][4w + 2cp + h][tap]
+    float wf[2][49];
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+        for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
+
+    // trace state of my 4 channels: element i (0..15): ci_local = i>>2, pix = (i&3)*64 + lane.
+    // eps0 lives in registers, eps1 only in the LDS image (offset ioff + c*CHF + (i&3)*4*ROWF).
+    float e0[16];
+    const int ioff = (4 * w) * CHF + ((lane >> 4) + 3) * ROWF + (lane & 15) + 3;
+    __syncthreads();        // image zeroed before the state is written into it
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        long g = (b * 32 + 4 * w + (i >> 2)) * 256 + (i & 3) * 64 + lane;
+        e0[i] = eps0_g[g];
+        img[ioff + (i >> 2) * CHF + (i & 3) * 4 * ROWF] = eps1_g[g];
+    }
+    // refractory trace of "my" output tile m = w:  reg r <-> co = (r&3)+8*(r>>2)+4h, pixel = 32w + j
+    float arp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        arp[r] = REFRACTORY ? arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 32 * w + j] : 0.0f;
+
+    // input spike words of my 4 channels for step t: 32 consecutive uint32, lane l < 32 holds word l
+    const uint32_t *in_base = spk_in + (b * 32 + 4 * w) * 8;
+    const long in_step = (long)B * 32 * 8;
+    uint32_t words = (T > 0 && lane < 32) ? in_base[lane] : 0u;
+
+    // per-lane base of the B-fragment reads: channel 4w+h, pixel row (j>>4), col (j&15); tile m adds 2 rows
+    const int bbase = (4 * w + h) * CHF + (j >> 4) * ROWF + (j & 15);
+    __syncthreads();
+
+    const int nstage = 8 * T + 9;
+    for (int g = 0; g < nstage; ++g) {
+        const int q = g - w;
+        if (q >= 0 && q < 8 * T) {
+            const int m = q & 7;
+            if (m == 0) {
+                // advance my traces to step t = q>>3 and refresh my part of the LDS image
+                uint32_t cur = words;
+                const int tn = (q >> 3) + 1;
+                if (tn < T && lane < 32) words = in_base[(long)tn * in_step + lane];
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) {
+                    const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
+                    const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int i = c * 4 + ii;
+                        uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, c * 8 + ii * 2);
+                        uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, c * 8 + ii * 2 + 1);
+                        uint32_t ww = h ? w1 : w0;
+                        float xin = ((ww >> j) & 1u) ? 1.0f : 0.0f;
+                        float *ip = img + ioff + c * CHF + ii * 4 * ROWF;
+                        float e1 = *ip;
+                        trace_update(xin, ta, tm, tas, ts, e0[i], e1);
+                        *ip = e1;
+                    }
+                }
+            }
+            f32x16 acc;
+            if (w == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+            } else {
+                const f32x4 *sp = (const f32x4 *)(slots + ((w - 1) * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + lane;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 v4 = sp[c * 64];
+                    acc[4 * c + 0] = v4[0]; acc[4 * c + 1] = v4[1]; acc[4 * c + 2] = v4[2]; acc[4 * c + 3] = v4[3];
+                }
+            }
+            const float *bp = img + bbase + m * 2 * ROWF;
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][ky * 7 + kx],
+                                                                   bp[cp * 2 * CHF + ky * ROWF + kx], acc, 0, 0, 0);
+            f32x4 *dp = (f32x4 *)(slots + (w * 2 + (g & 1)) * SLOT_FLOATS) + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 v4 = {acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                dp[c * 64] = v4;
+            }
+        }
+        const int qe = g - 8;
+        if ((g & 7) == w && qe >= 0 && qe < 8 * T) {
+            // finish tile qe (pixel tile m = w of step te): slot[7][(g-1)&1] holds bias + full K chain
+            const int te = qe >> 3;
+            const f32x4 *sp = (const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + lane;
+            const long obase = ((long)te * B + b) * 32;
+            uint32_t myword = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 v4 = sp[c * 64];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * c + rr;
+                    const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float v = v4[rr];
+                    bool s;
+                    if (REFRACTORY) v = refractory(v4[rr], arp[r], alpharp, wrp, s);
+                    else s = v > 0.0f;
+                    unsigned long long mk = __ballot(s);
+                    uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                    myword = (j == r) ? mine : myword;
+                    if (pv_out) pv_out[(obase + co) * 256 + 32 * w + j] = sigmoidf_dev(v);
+                    if (v_out) v_out[(obase + co) * 256 + 32 * w + j] = v;
+                }
+            }
+            if (spk_out && j < 16) spk_out[(obase + (j & 3) + 8 * (j >> 2) + 4 * h) * 8 + w] = myword;
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        long g = (b * 32 + 4 * w + (i >> 2)) * 256 + (i & 3) * 64 + lane;
+        eps0_g[g] = e0[i];
+        eps1_g[g] = img[ioff + (i >> 2) * CHF + (i & 3) * 4 * ROWF];
+    }
+    if (REFRACTORY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 32 * w + j] = arp[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+static int launch_readout(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
+                          hipStream_t st)
+{
+    if (rows == 0 || N == 0) return DCLL_OK;
+    dim3 grid(nblk(rows, RO_ROWS), (N + 31) / 32);
+    hipLaunchKernelGGL(k_readout, grid, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    HIP_CHECK_LAUNCH("k_readout");
+    return DCLL_OK;
+}
+
+extern "C" int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out, int64_t rows, int32_t K,
+                            int32_t N, void *stream)
+{
+    if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1) return fail(DCLL_ERR_INVALID, "dcll_readout: bad argument");
+    return launch_readout(pv, Wt, bias, out, rows, K, N, (hipStream_t)stream);
+}
+
+extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
+                                  const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
+                                  float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
+                                  const float *out_W, const float *out_b, float *out_s, float *out_p, float *out_o,
+                                  float *out_pv, float *out_v, float *scratch, int32_t B, void *stream)
+{
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !W || !alpha || !tau_m || !alphas || !tau_s || !eps0 || !eps1 || !out_s || !out_pv)
+        return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: null pointer");
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: refractory layer needs arp");
+    if (B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: negative batch");
+    if (B == 0) return DCLL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int ch, cw, ph, pw;
+    conv_shape(d, &ch, &cw, &ph, &pw);
+    const long per = (long)d->c_in * d->h * d->w, nin = per * B;
+    const long nconv = (long)B * d->c_out * ch * cw, npool = (long)B * d->c_out * ph * pw;
+    hipLaunchKernelGGL(k_trace, dim3(nblk(nin, 256) > 4096 ? 4096 : nblk(nin, 256)), dim3(256), 0, st, x, alpha, tau_m,
+                       alphas, tau_s, eps0, eps1, nin, per, d->tau_is_tensor);
+    HIP_CHECK_LAUNCH("k_trace");
+    const bool pooled = !(d->pool_h == 1 && d->pool_w == 1);
+    // without pooling the conv kernel writes s / pv straight into the outputs; with pooling the un-pooled maps go to
+    // the caller's scratch (2 * B*c_out*ch*cw floats) and k_pool produces the outputs.
+    float *s_full = out_s, *pv_full = out_pv;
+    if (pooled) {
+        if (!scratch) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: pooling layer needs scratch");
+        s_full = scratch;
+        pv_full = scratch + nconv;
+    }
+    hipLaunchKernelGGL(k_conv_lif, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, eps1, W, b, arp, s_full,
+                       pv_full, out_v, nconv);
+    HIP_CHECK_LAUNCH("k_conv_lif");
+    if (pooled) {
+        hipLaunchKernelGGL(k_pool, dim3(nblk(npool, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, s_full, pv_full, out_s,
+                           out_pv, npool);
+        HIP_CHECK_LAUNCH("k_pool");
+    }
+    const int K = d->c_out * ph * pw;
+    if (i2o_W && out_p) {
+        rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
+        if (rc) return rc;
+    }
+    if (d->output_layer) {
+        if (!out_W || !out_o) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: output layer needs out_W and out_o");
+        rc = launch_readout(out_pv, out_W, out_b, out_o, B, K, d->target, st);
+        if (rc) return rc;
+    }
+    return DCLL_OK;
+}
+
+extern "C" int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W, const float *b,
+                                   const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
+                                   float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
+                                   float *out_s, float *out_p, float *out_pv, float *out_v, int32_t B, void *stream)
+{
+    if (!d || d->in_features < 1 || d->out_features < 1) return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: bad descriptor");
+    if (!x || !W || !alpha || !tau_m || !alphas || !tau_s || !eps0 || !eps1 || !out_pv)
+        return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: null pointer");
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: refractory layer needs arp");
+    if (B < 0) return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: negative batch");
+    if (B == 0) return DCLL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long nin = (long)B * d->in_features, nout = (long)B * d->out_features;
+    hipLaunchKernelGGL(k_trace, dim3(nblk(nin, 256) > 4096 ? 4096 : nblk(nin, 256)), dim3(256), 0, st, x, alpha, tau_m,
+                       alphas, tau_s, eps0, eps1, nin, (long)d->in_features, d->tau_is_tensor);
+    HIP_CHECK_LAUNCH("k_trace");
+    hipLaunchKernelGGL(k_dense_lif, dim3(nblk(nout, 256)), dim3(256), 0, st, *d, eps1, W, b, arp, out_s, out_pv, out_v,
+                       nout);
+    HIP_CHECK_LAUNCH("k_dense_lif");
+    if (i2o_W && out_p) return launch_readout(out_pv, i2o_W, i2o_b, out_p, B, d->out_features, d->target, st);
+    return DCLL_OK;
+}
+
+static int check_seq_geometry(const dcll_conv_desc *d, int c_in, const char *who)
+{
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (d->c_in != c_in || d->c_out > 32 || (c_in == 32 && d->c_out != 32) || d->h != 16 || d->w != 16 || d->kh != 7 ||
+        d->kw != 7 || d->pad_h != 3 || d->pad_w != 3 || d->pool_h != 1 || d->pool_w != 1)
+        return fail(DCLL_ERR_UNSUPPORTED,
+                    "sequence kernel supports 7x7 pad 3 on a 16x16 plane, pool 1, c_out<=32 (==32 for c_in 32)", who);
+    return DCLL_OK;
+}
+
+extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+                                      const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
+                                      float *pv_out, float *v_out, int32_t T, int32_t B, void *stream)
+{
+    int rc = check_seq_geometry(d, 32, "dcll_conv_lif_sequence");
+    if (rc) return rc;
+    if (!spk_in || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: null pointer");
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: refractory layer needs arp");
+    if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: negative size");
+    if (T == 0 || B == 0) return DCLL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->refractory)
+        hipLaunchKernelGGL(k_lif_seq_c32<true>, dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out,
+                           pv_out, v_out, T, B, d->alpharp, d->wrp);
+    else
+        hipLaunchKernelGGL(k_lif_seq_c32<false>, dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out,
+                           pv_out, v_out, T, B, d->alpharp, d->wrp);
+    HIP_CHECK_LAUNCH("k_lif_seq_c32");
+    return DCLL_OK;
+}
+
+extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *W, const float *b,
+                                            const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
+                                            float *pv_out, float *v_out, int32_t T, int32_t B, void *stream)
+{
+    int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_cells");
+    if (rc) return rc;
+    if (!cells || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: null pointer");
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: refractory layer needs arp");
+    if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: negative size");
+    if (T == 0 || B == 0) return DCLL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->refractory)
+        hipLaunchKernelGGL(k_lif_seq_c1<true>, dim3(B), dim3(256), 0, st, d->c_out, cells, W, b, tau4, eps0, eps1, arp,
+                           spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
+    else
+        hipLaunchKernelGGL(k_lif_seq_c1<false>, dim3(B), dim3(256), 0, st, d->c_out, cells, W, b, tau4, eps0, eps1, arp,
+                           spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
+    HIP_CHECK_LAUNCH("k_lif_seq_c1");
+    return DCLL_OK;
+}
+
+extern "C" int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t T, int32_t B, int32_t N,
+                                int32_t t_begin, void *stream)
+{
+    if (!logits || !clout || T < 0 || B < 0 || N < 1) return fail(DCLL_ERR_INVALID, "dcll_argmax_vote: bad argument");
+    if (vote && N > VOTE_MAXN) return fail(DCLL_ERR_UNSUPPORTED, "dcll_argmax_vote: vote supports at most 64 classes");
+    if (T == 0 || B == 0) return DCLL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)T * B;
+    hipLaunchKernelGGL(k_argmax, dim3(nblk(rows, 256)), dim3(256), 0, st, logits, clout, rows, N);
+    HIP_CHECK_LAUNCH("k_argmax");
+    if (vote) {
+        hipLaunchKernelGGL(k_vote, dim3(nblk(B, 64)), dim3(64), 0, st, clout, vote, T, B, N, t_begin);
+        HIP_CHECK_LAUNCH("k_vote");
+    }
+    return DCLL_OK;
+}
+
+extern "C" int dcll_iq_encode(const float *iq, const float *thr_i, const float *thr_q, int32_t *cells, int32_t B,
+                              int32_t L, int32_t t0, int32_t T, int32_t w, int32_t h, void *stream)
+{
+    if (!iq || !thr_i || !thr_q || !cells || B < 0 || T < 0 || t0 < 0 || t0 + T > L || w < 1 || h < 1)
+        return fail(DCLL_ERR_INVALID, "dcll_iq_encode: bad argument");
+    if (T == 0 || B == 0) return DCLL_OK;
+    hipLaunchKernelGGL(k_iq_encode, dim3(nblk((long)T * B, 256)), dim3(256), 0, (hipStream_t)stream, iq, thr_i, thr_q,
+                       cells, B, L, t0, T, w, h);
+    HIP_CHECK_LAUNCH("k_iq_encode");
+    return DCLL_OK;
+}
+
+extern "C" int dcll_unpack_spikes(const uint32_t *packed, float *dense, int64_t nwords, void *stream)
+{
+    if (!packed || !dense || nwords < 0) return fail(DCLL_ERR_INVALID, "dcll_unpack_spikes: bad argument");
+    if (nwords == 0) return DCLL_OK;
+    hipLaunchKernelGGL(k_unpack, dim3(nblk(nwords * 32, 256)), dim3(256), 0, (hipStream_t)stream, packed, dense, (long)nwords);
+    HIP_CHECK_LAUNCH("k_unpack");
+    return DCLL_OK;
+}
+
+extern "C" int dcll_pack_spikes(const float *dense, uint32_t *packed, int64_t nwords, void *stream)
+{
+    if (!packed || !dense || nwords < 0) return fail(DCLL_ERR_INVALID, "dcll_pack_spikes: bad argument");
+    if (nwords == 0) return DCLL_OK;
+    hipLaunchKernelGGL(k_pack, dim3(nblk(nwords * 32, 256)), dim3(256), 0, (hipStream_t)stream, dense, packed, (long)nwords);
+    HIP_CHECK_LAUNCH("k_pack");
+    return DCLL_OK;
+}

@@ -1,0 +1,164 @@
+"""Tensor-level wrappers over the C ABI (include/dcll_hip.h): torch tensors in HBM in, torch tensors out.
+
+PyTorch is only the owner of device memory and streams here; all arithmetic happens in libdcll_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, DenseDesc, check, ptr, stream_ptr
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if hasattr(v, "__len__") else (int(v), int(v))
+
+
+def make_conv_desc(c_in, c_out, hw, kernel_size, padding, pooling, target, output_layer, tau_is_tensor, wrp,
+                   alpharp=.65, stride=1, dilation=1, groups=1):
+    (kh, kw), (pah, paw) = _pair(kernel_size), _pair(padding)
+    poh, pow_ = _pair(pooling) if pooling is not None else (1, 1)
+    return ConvDesc(int(c_in), int(c_out), int(hw[0]), int(hw[1]), kh, kw, pah, paw, int(stride), int(dilation),
+                    int(groups), poh, pow_, int(target), int(bool(output_layer)), int(bool(tau_is_tensor)),
+                    int(wrp > 0), float(alpharp), float(wrp))
+
+
+def conv_out_shape(desc):
+    v = [ctypes.c_int32() for _ in range(4)]
+    check(_lib.get().dcll_conv_out_shape(ctypes.byref(desc), *[ctypes.byref(i) for i in v]), "dcll_conv_out_shape")
+    return tuple(i.value for i in v)      # conv_h, conv_w, pool_h, pool_w
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t
+
+
+def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None,
+                  out_W=None, out_b=None, want_v=True):
+    """One Conv2dDCLLlayer.forward step (dcll/pytorch_libdcll.py:599-608); state tensors are updated in place.
+
+    Returns (s_pooled, p, o, pv_pooled, v) — p / o are None when the corresponding weights are None.
+    """
+    B = x.shape[0]
+    ch, cw, ph, pw = conv_out_shape(desc)
+    dev = x.device
+    x = _f32(x, "x").contiguous()
+    s = torch.empty((B, desc.c_out, ph, pw), device=dev, dtype=torch.float32)
+    pv = torch.empty_like(s)
+    v = torch.empty((B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if want_v else None
+    p = torch.empty((B, desc.target), device=dev, dtype=torch.float32) if i2o_W is not None else None
+    o = torch.empty((B, desc.target), device=dev, dtype=torch.float32) if desc.output_layer else None
+    pooled = not (desc.pool_h == 1 and desc.pool_w == 1)
+    scratch = torch.empty((2, B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if pooled else None
+    rc = _lib.get().dcll_conv_lif_step(
+        ctypes.byref(desc), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
+        ptr(eps0), ptr(eps1), ptr(arp), ptr(i2o_W), ptr(i2o_b), ptr(out_W), ptr(out_b),
+        ptr(s), ptr(p), ptr(o), ptr(pv), ptr(v), ptr(scratch), B, stream_ptr())
+    check(rc, "dcll_conv_lif_step")
+    return s, p, o, pv, v
+
+
+def dense_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None):
+    """One DenseDCLLlayer.forward step (dcll/pytorch_libdcll.py:250-255)."""
+    B = x.shape[0]
+    dev = x.device
+    x = _f32(x, "x").contiguous()
+    s = torch.empty((B, desc.out_features), device=dev, dtype=torch.float32)
+    pv, v = torch.empty_like(s), torch.empty_like(s)
+    p = torch.empty((B, desc.target), device=dev, dtype=torch.float32) if i2o_W is not None else None
+    rc = _lib.get().dcll_dense_lif_step(
+        ctypes.byref(desc), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
+        ptr(eps0), ptr(eps1), ptr(arp), ptr(i2o_W), ptr(i2o_b), ptr(s), ptr(p), ptr(pv), ptr(v), B, stream_ptr())
+    check(rc, "dcll_dense_lif_step")
+    return s, p, pv, v
+
+
+def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_pv=True,
+                      want_v=False, out=None):
+    """All T steps of one 32->32 layer in one launch (k_lif_seq_c32). spk_in: (T,B,32,8) int32 packed."""
+    dev = W.device
+    out = out or {}
+    words = desc.h * desc.w // 32
+    spk = out.get("spk") if want_spikes else None
+    if want_spikes and spk is None:
+        spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
+    pv = out.get("pv") if want_pv else None
+    if want_pv and pv is None:
+        pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
+    v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+    rc = _lib.get().dcll_conv_lif_sequence(ctypes.byref(desc), ptr(spk_in), ptr(W), ptr(b), ptr(tau4), ptr(eps0),
+                                           ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), T, B, stream_ptr())
+    check(rc, "dcll_conv_lif_sequence")
+    return spk, pv, v
+
+
+def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_pv=True,
+                            want_v=False, out=None):
+    """All T steps of the first layer (c_in = 1) from cell indices (T,B) int32 (k_lif_seq_c1)."""
+    dev = W.device
+    out = out or {}
+    words = desc.h * desc.w // 32
+    spk = out.get("spk") if want_spikes else None
+    if want_spikes and spk is None:
+        spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
+    pv = out.get("pv") if want_pv else None
+    if want_pv and pv is None:
+        pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
+    v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+    rc = _lib.get().dcll_conv_lif_sequence_cells(ctypes.byref(desc), ptr(cells), ptr(W), ptr(b), ptr(tau4),
+                                                 ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), T, B,
+                                                 stream_ptr())
+    check(rc, "dcll_conv_lif_sequence_cells")
+    return spk, pv, v
+
+
+def readout(pv2d, Wt, bias, out=None):
+    """out[r,n] = sum_k pv2d[r,k] Wt[n,k] + bias[n]  (i2o / output_), fp32 MFMA."""
+    rows, K = pv2d.shape
+    N = Wt.shape[0]
+    if Wt.shape[1] != K:
+        raise ValueError("readout: K mismatch %d vs %d" % (Wt.shape[1], K))
+    if out is None:
+        out = torch.empty((rows, N), device=pv2d.device, dtype=torch.float32)
+    check(_lib.get().dcll_readout(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), rows, K, N, stream_ptr()), "dcll_readout")
+    return out
+
+
+def argmax_vote(logits, t_begin=0, want_vote=True):
+    """logits (T,B,N) -> clout (T,B) int32, vote (B) int32."""
+    T, B, N = logits.shape
+    clout = torch.empty((T, B), device=logits.device, dtype=torch.int32)
+    vote = torch.empty((B,), device=logits.device, dtype=torch.int32) if want_vote else None
+    check(_lib.get().dcll_argmax_vote(ptr(logits), ptr(clout), ptr(vote), T, B, N, t_begin, stream_ptr()),
+          "dcll_argmax_vote")
+    return clout, vote
+
+
+def iq_encode(iq, thr_i, thr_q, t0, T, w, h):
+    """iq (B,2,L) fp32 -> cells (T,B) int32 = q*w + i."""
+    B, two, L = iq.shape
+    assert two == 2
+    cells = torch.empty((T, B), device=iq.device, dtype=torch.int32)
+    check(_lib.get().dcll_iq_encode(ptr(iq), ptr(thr_i), ptr(thr_q), ptr(cells), B, L, t0, T, w, h, stream_ptr()),
+          "dcll_iq_encode")
+    return cells
+
+
+def unpack_spikes(packed):
+    """(..., nw) int32 -> (..., nw*32) float32"""
+    packed = packed.contiguous()
+    dense = torch.empty(packed.shape[:-1] + (packed.shape[-1] * 32,), device=packed.device, dtype=torch.float32)
+    check(_lib.get().dcll_unpack_spikes(ptr(packed), ptr(dense), packed.numel(), stream_ptr()), "dcll_unpack_spikes")
+    return dense
+
+
+def pack_spikes(dense):
+    """(..., n) float32 with n % 32 == 0 -> (..., n/32) int32"""
+    dense = dense.contiguous()
+    if dense.shape[-1] % 32:
+        raise ValueError("pack_spikes: last dimension must be a multiple of 32")
+    packed = torch.empty(dense.shape[:-1] + (dense.shape[-1] // 32,), device=dense.device, dtype=torch.int32)
+    check(_lib.get().dcll_pack_spikes(ptr(dense), ptr(packed), packed.numel(), stream_ptr()), "dcll_pack_spikes")
+    return packed

@@ -1,0 +1,291 @@
+"""GPU parity tests proper: every HIP entry point of include/dcll_hip.h, called through the C ABI
+(snn_modulation_classification_amd.ops -> ctypes -> libdcll_hip.so), against the pinned-order C oracle
+(bit-exact for traces, v, spikes, arp) and against the golden vectors from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import unpack_bits
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4      # BASELINE.json north_star: class logits within 1e-4 fp32
+PV_TOL = 2e-6         # sigmoid: v_exp_f32/v_rcp_f32 vs libm expf, a few ulp of values in (0,1)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+G1_CASES = ["radio_l0", "radio_l1", "radio_l2_out", "radio_norp", "scalar_tau", "mnist_l0", "mnist_l2",
+            "ref_tuple", "pool3"]
+
+
+@pytest.mark.parametrize("case", G1_CASES)
+def test_step_vs_oracle_and_golden(golden, golden_meta, dev, case):
+    """dcll_conv_lif_step free-running for 3 steps == C oracle bit for bit; == reference within the band."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    g = golden("g1_layer_steps.npz")
+    m = golden_meta["g1"][case]
+    sd = g.sub("g1/%s/sd/" % case)
+    orc = C.OracleConvLayer(sd, m["im"], m["pad"], m["pool"], m["wrp"], m["alpharp"], m["output_layer"])
+    d = ops.make_conv_desc(m["cin"], m["cout"], m["im"], m["k"], m["pad"], m["pool"], 24, m["output_layer"],
+                           sd["i2h.alpha"].size > 1, m["wrp"], m["alpharp"])
+    ch, cw, ph, pw = ops.conv_out_shape(d)
+    assert (ch, cw, ph, pw) == (orc.ch, orc.cw, orc.ph, orc.pw)
+    B = m["B"]
+    t = {k: cu(v, dev) for k, v in sd.items()}
+    eps0 = torch.zeros((B, m["cin"]) + tuple(m["im"]), device=dev)
+    eps1 = torch.zeros_like(eps0)
+    arp = torch.zeros((B, m["cout"], ch, cw), device=dev)
+    for step in range(3):
+        x = g["g1/%s/x%d" % (case, step)]
+        s, p, o, pv, v = ops.conv_lif_step(d, cu(x, dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
+                                           t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1, arp,
+                                           t["i2o.weight"], t["i2o.bias"], t.get("output_.weight"),
+                                           t.get("output_.bias"))
+        oo, op, opv, ov, os_ = orc.forward(x)
+        assert bits_equal(eps0.cpu().numpy(), orc.state[0])
+        assert bits_equal(eps1.cpu().numpy(), orc.state[1])
+        assert bits_equal(v.cpu().numpy(), ov), np.abs(v.cpu().numpy() - ov).max()
+        assert np.array_equal(s.cpu().numpy(), os_)
+        if m["wrp"] > 0:
+            assert bits_equal(arp.cpu().numpy(), orc.state[2])
+        np.testing.assert_allclose(pv.cpu().numpy(), opv, atol=PV_TOL, rtol=0)
+        np.testing.assert_allclose(p.cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
+        if m["output_layer"]:
+            np.testing.assert_allclose(o.cpu().numpy(), oo, atol=LOGIT_TOL, rtol=0)
+        # against the reference itself (the oracle showed zero flips on these fixtures)
+        e = lambda n: g["g1/%s/%s%d" % (case, n, step)]
+        assert bits_equal(eps1.cpu().numpy(), e("out_eps1"))
+        assert np.array_equal(v.cpu().numpy() > 0, e("v") > 0)
+        np.testing.assert_allclose(p.cpu().numpy(), e("p"), atol=LOGIT_TOL, rtol=0)
+
+
+def _rand_layer(rng, cin, cout, k=7, gain=1.0):
+    n = cin * k * k
+    stdv = 1.0 / np.sqrt(n) / 250
+    W = rng.uniform(-stdv * 1e-2, stdv * 1e-2, size=(cout, cin, k, k)).astype(np.float32) * gain
+    b = rng.uniform(-stdv, stdv, size=(cout,)).astype(np.float32)
+    taum = rng.uniform(5, 35, size=cin) * 1e-3
+    taus = rng.uniform(5, 10, size=cin) * 1e-3
+    alpha = (1 - 1e-3 / taum).astype(np.float32)
+    alphas = (1 - 1e-3 / taus).astype(np.float32)
+    tau_m = (np.float32(1) / (np.float32(1) - alpha)).astype(np.float32)
+    tau_s = (np.float32(1) / (np.float32(1) - alphas)).astype(np.float32)
+    return W, b, alpha, tau_m, alphas, tau_s
+
+
+def _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, target=24, rng=None):
+    bc = lambda a: np.ascontiguousarray(np.broadcast_to(a[:, None, None], (a.shape[0],) + hw)).astype(np.float32)
+    K = W.shape[0] * hw[0] * hw[1]
+    return {"i2h.weight": W, "i2h.bias": b, "i2h.alpha": bc(alpha), "i2h.tau_m__dt": bc(tau_m),
+            "i2h.alphas": bc(alphas), "i2h.tau_s__dt": bc(tau_s),
+            "i2o.weight": rng.uniform(-.0055, .0055, size=(target, K)).astype(np.float32),
+            "i2o.bias": rng.uniform(-.0055, .0055, size=(target,)).astype(np.float32)}
+
+
+@pytest.mark.parametrize("wrp,T,B,zero_state", [(1.0, 24, 3, True), (0.0, 9, 2, True), (1.0, 10, 5, False)])
+def test_sequence_c32_vs_oracle(dev, wrp, T, B, zero_state):
+    """k_lif_seq_c32 (MFMA systolic chain, state on chip) == C oracle stepping, bit for bit, incl. final state."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(11)
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, (16, 16), rng=rng)
+    orc = C.OracleConvLayer(sd, (16, 16), 3, 1, wrp)
+    orc.init_state(B)
+    if not zero_state:
+        orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape)
+        orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape)
+        orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+    eps0, eps1, arp = [cu(s.copy(), dev) for s in orc.state]
+    x = (rng.uniform(size=(T, B, 32, 256)) < 0.08).astype(np.float32)
+    x[0] = (rng.uniform(size=(B, 32, 256)) < 0.5)          # first-step burst
+    d = ops.make_conv_desc(32, 32, (16, 16), 7, 3, 1, 24, False, True, wrp)
+    spk_in = ops.pack_spikes(cu(x, dev))
+    assert spk_in.shape == (T, B, 32, 8)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    spk, pv, v = ops.conv_lif_sequence(d, spk_in, cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp, T, B, want_v=True)
+    torch.cuda.synchronize()
+    spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T, B, 32, 16, 16)
+    v, pv = v.cpu().numpy(), pv.cpu().numpy()
+    for t in range(T):
+        oo, op, opv, ov, os_ = orc.forward(x[t].reshape(B, 32, 16, 16))
+        assert bits_equal(v[t], ov), (t, np.abs(v[t] - ov).max())
+        assert np.array_equal(spk_d[t], os_), t
+        np.testing.assert_allclose(pv[t], opv, atol=PV_TOL, rtol=0)
+    assert bits_equal(eps0.cpu().numpy(), orc.state[0])
+    assert bits_equal(eps1.cpu().numpy(), orc.state[1])
+    if wrp > 0:
+        assert bits_equal(arp.cpu().numpy(), orc.state[2])
+    assert 0.01 < spk_d[1:].mean() < 0.9, "degenerate test: spikes all equal"
+
+
+@pytest.mark.parametrize("wrp,cout", [(1.0, 32), (0.0, 32), (1.0, 8)])
+def test_sequence_c1_vs_oracle(dev, wrp, cout):
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(5)
+    T, B = 17, 4
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 1, cout, gain=3.0)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, (16, 16), rng=rng)
+    orc = C.OracleConvLayer(sd, (16, 16), 3, 1, wrp)
+    cells = rng.randint(0, 256, size=(T, B)).astype(np.int32)
+    d = ops.make_conv_desc(1, cout, (16, 16), 7, 3, 1, 24, False, True, wrp)
+    eps0 = torch.zeros((B, 1, 16, 16), device=dev)
+    eps1 = torch.zeros_like(eps0)
+    arp = torch.zeros((B, cout, 16, 16), device=dev)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    spk, pv, v = ops.conv_lif_sequence_cells(d, cu(cells, dev), cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp, T, B,
+                                             want_v=True)
+    spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T, B, cout, 16, 16)
+    v, pv = v.cpu().numpy(), pv.cpu().numpy()
+    for t in range(T):
+        x = np.zeros((B, 1, 256), np.float32)
+        x[np.arange(B), 0, cells[t]] = 1
+        oo, op, opv, ov, os_ = orc.forward(x.reshape(B, 1, 16, 16))
+        assert bits_equal(v[t], ov), (t, np.abs(v[t] - ov).max())
+        assert np.array_equal(spk_d[t], os_)
+        np.testing.assert_allclose(pv[t], opv, atol=PV_TOL, rtol=0)
+    assert bits_equal(eps0.cpu().numpy(), orc.state[0])
+    assert bits_equal(eps1.cpu().numpy(), orc.state[1])
+    if wrp > 0:
+        assert bits_equal(arp.cpu().numpy(), orc.state[2])
+
+
+def test_full_rollout_vs_reference_golden(golden, dev):
+    """radio_ml_conv.yaml, R=16, T=128, B=2: cells -> k_lif_seq_c1 -> k_lif_seq_c32 x2 -> readout -> argmax/vote,
+    free-running, against the REFERENCE's own spikes (bit-exact), logits (1e-4), per-step argmax and votes."""
+    from snn_modulation_classification_amd import ops
+    g = golden("g2_radio_r16_t128_b2.npz")
+    cells = g["cells"]
+    T, B = cells.shape
+    cur = None
+    for i in range(3):
+        sd = {k: cu(v, dev) for k, v in g.sub("sd/%d/" % i).items()}
+        cin = sd["i2h.weight"].shape[1]
+        d = ops.make_conv_desc(cin, 32, (16, 16), 7, 3, 1, 24, i == 2, True, 1.0)
+        tau4 = torch.stack([sd[k][:, 0, 0] for k in ("i2h.alpha", "i2h.tau_m__dt", "i2h.alphas", "i2h.tau_s__dt")])
+        tau4 = tau4.contiguous()
+        eps0 = torch.zeros((B, cin, 16, 16), device=dev)
+        eps1 = torch.zeros_like(eps0)
+        arp = torch.zeros((B, 32, 16, 16), device=dev)
+        if i == 0:
+            spk, pv, _ = ops.conv_lif_sequence_cells(d, cu(cells, dev), sd["i2h.weight"], sd["i2h.bias"], tau4, eps0,
+                                                     eps1, arp, T, B)
+        else:
+            spk, pv, _ = ops.conv_lif_sequence(d, cur, sd["i2h.weight"], sd["i2h.bias"], tau4, eps0, eps1, arp, T, B)
+        ref = g["spikes/%d" % i].view(np.int32).reshape(T, B, 32, 8)
+        assert np.array_equal(spk.cpu().numpy(), ref), "layer %d spike trains differ from the reference" % i
+        p = ops.readout(pv.reshape(T * B, -1), sd["i2o.weight"], sd["i2o.bias"]).reshape(T, B, 24)
+        np.testing.assert_allclose(p.cpu().numpy(), g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+        logits = p
+        if i == 2:
+            o = ops.readout(pv.reshape(T * B, -1), sd["output_.weight"], sd["output_.bias"]).reshape(T, B, 24)
+            np.testing.assert_allclose(o.cpu().numpy(), g["o_last"], atol=LOGIT_TOL, rtol=0)
+            logits = o
+        clout, vote = ops.argmax_vote(logits)
+        # argmax may differ only where the reference's top two logits are closer than the tolerance
+        ref_logits = g["o_last"] if i == 2 else g["p/%d" % i]
+        top2 = np.sort(ref_logits, axis=-1)[..., -2:]
+        close = (top2[..., 1] - top2[..., 0]) < 2 * LOGIT_TOL
+        mism = clout.cpu().numpy() != g["clout/%d" % i]
+        assert not (mism & ~close).any()
+        if not mism.any():
+            assert np.array_equal(vote.cpu().numpy(), g["vote/%d" % i])
+        cur = spk
+        for nm, st in (("eps0", eps0), ("eps1", eps1), ("arp", arp)):
+            exp = g["final/%d/%s" % (i, nm)]
+            if nm == "arp":
+                np.testing.assert_allclose(st.cpu().numpy(), exp, atol=1e-6, rtol=0)
+            else:
+                assert bits_equal(st.cpu().numpy(), exp), (i, nm)
+
+
+@pytest.mark.parametrize("rows,K,N", [(1, 8192, 24), (300, 8192, 24), (37, 2704, 10), (129, 100, 32), (5, 24, 10)])
+def test_readout_gemm(dev, rows, K, N):
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(0)
+    pv = rng.uniform(0, 1, size=(rows, K)).astype(np.float32)
+    Wt = rng.uniform(-.01, .01, size=(N, K)).astype(np.float32)
+    b = rng.uniform(-.01, .01, size=(N,)).astype(np.float32)
+    out = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev)).cpu().numpy()
+    ref = (pv.astype(np.float64) @ Wt.astype(np.float64).T + b).astype(np.float32)
+    np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
+
+
+def test_argmax_vote_vs_oracle(dev):
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(3)
+    T, B, N = 40, 200, 24
+    logits = rng.randn(T, B, N).astype(np.float32)
+    logits[:, :50] = np.round(logits[:, :50])          # many exact ties -> first maximum must win
+    logits[:, 50:60, :] = 0.0                            # all equal -> class 0
+    for tb in (0, 7):
+        c_ref, v_ref = C.argmax_vote(logits, t_begin=tb)
+        c, v = ops.argmax_vote(cu(logits, dev), t_begin=tb)
+        assert np.array_equal(c.cpu().numpy(), c_ref)
+        assert np.array_equal(v.cpu().numpy(), v_ref)
+
+
+def test_pack_unpack_roundtrip(dev):
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(1)
+    x = (rng.uniform(size=(7, 3, 32, 256)) < 0.3).astype(np.float32)
+    p = ops.pack_spikes(cu(x, dev))
+    assert np.array_equal(p.cpu().numpy().view(np.uint8).reshape(7, 3, -1),
+                          np.packbits(x.reshape(7, 3, -1).astype(np.uint8), axis=-1, bitorder="little"))
+    assert np.array_equal(ops.unpack_spikes(p).cpu().numpy().reshape(x.shape), x)
+
+
+def test_dense_step_vs_oracle(golden, dev):
+    from snn_modulation_classification_amd import ops
+    from snn_modulation_classification_amd._lib import DenseDesc
+    from oracle import c_oracle as C
+    g = golden("g7_dense.npz")
+    for case, wrp in (("rrp", 1.0), ("plain", 0.0), ("plain_rtau", 0.0)):
+        sd = g.sub("g7/%s/sd/" % case)
+        orc = C.OracleDenseLayer(sd, wrp)
+        t = {k: cu(v, dev) for k, v in sd.items()}
+        d = DenseDesc(40, 24, 10, int(sd["i2h.alpha"].size > 1), int(wrp > 0), .65, wrp)
+        eps0 = torch.zeros((5, 40), device=dev)
+        eps1 = torch.zeros_like(eps0)
+        arp = torch.zeros((5, 24), device=dev)
+        for step in range(3):
+            x = g["g7/%s/x%d" % (case, step)]
+            s, p, pv, v = ops.dense_lif_step(d, cu(x, dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
+                                             t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1,
+                                             arp, t["i2o.weight"], t["i2o.bias"])
+            os_, op, opv, ov = orc.forward(x)
+            assert bits_equal(v.cpu().numpy(), ov)
+            assert np.array_equal(s.cpu().numpy(), os_)
+            assert bits_equal(eps1.cpu().numpy(), orc.state[1])
+            np.testing.assert_allclose(p.cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
+            np.testing.assert_allclose(p.cpu().numpy(), g["g7/%s/p%d" % (case, step)], atol=LOGIT_TOL, rtol=0)
+
+
+def test_error_conventions(dev):
+    """Bad geometry -> DCLLUnsupported (NotImplementedError); nulls -> ValueError; never a crash."""
+    from snn_modulation_classification_amd import ops, _lib
+    d = ops.make_conv_desc(32, 32, (20, 20), 7, 3, 1, 24, False, True, 1.0)
+    z = torch.zeros(4, device=dev)
+    with pytest.raises(NotImplementedError):
+        ops.conv_lif_sequence(d, z.int(), z, z, z, z, z, z, 1, 1)
+    d2 = ops.make_conv_desc(1, 4, (8, 8), 3, 1, 1, 10, False, False, 0.0, stride=2)
+    with pytest.raises(NotImplementedError):
+        ops.conv_out_shape(d2)
+    with pytest.raises(_lib.DCLLHipError):
+        ops.readout(torch.zeros(2, 4), torch.zeros(3, 4), None)      # CPU tensors: no CPU fallback
