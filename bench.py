@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Headline benchmark: IQ windows/sec of the DCLL LIF timestep loop (radio_ml_conv.yaml, 16x16 I/Q plane, T=128).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic IQ windows already resident in HBM:
+encode (IQ -> cells, on device) -> net.zero_states() + net.reset() -> all T steps of all three layers (fused
+sequence kernels) -> readouts -> per-step argmax + vote -> per-class tallies (all-reduced over ranks).
+That is the span of the reference's test_radio_ml.py:142-146 plus its input encoding (:133-135).
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` for the dominant kernel
+(k_lif_seq_c32, fp32 MFMA bound) and `cpu_baseline` (the torch-CPU port of the reference timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from snn_modulation_classification_amd import parallel  # noqa: E402
+from snn_modulation_classification_amd.data.utils import IQEncoder  # noqa: E402
+from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec  # noqa: E402
+
+T_STEPS, R, L_IQ, N_CLASSES = 128, 16, 128, 24
+# algorithmic FLOPs of one k_lif_seq_c32 launch per sample per step: 2 * c_out * (c_in*7*7) * H*W
+FLOP_C32_PER_SAMPLE_STEP = 2 * 32 * (32 * 49) * 256
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PEAK_HBM_GBS = 8000.0
+
+
+def build_net(batch, device):
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks",
+                                           "radio_ml_conv.yaml"))
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(args, (1, R, R), batch, convs, N_CLASSES, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    return net, convs
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask, capped by a cgroup-v2 quota if one is set."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(net, convs, cells_cpu, gpu_votes, n_windows):
+    """The reference's CPU PyTorch path (oracle/torch_ref.py: same eager op sequence, fixture-verified against the
+    imported reference) on this host's cores: reset -> T-loop of test(x[t]) -> votes, on a bounded sample."""
+    from oracle import torch_ref
+    sds = [{k: v.detach().cpu() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
+    ref = torch_ref.RefConvNetwork(sds, convs, wrp=1.0)
+    cells = cells_cpu[:, :n_windows].long()
+    T = cells.shape[0]
+    x = torch.zeros(T, n_windows, R * R)
+    x.scatter_(2, cells.unsqueeze(-1), 1.0)
+    x = x.reshape(T, n_windows, 1, R, R)
+    with torch.no_grad():
+        # pick the thread count that is fastest on this host (an over-subscribed OpenMP pool is far slower)
+        cand = sorted({c for c in (8, 16, 32, 64, usable_cores()) if c <= usable_cores()} or {1})
+        best = None
+        for c in cand:
+            torch.set_num_threads(c)
+            ref.reset(True)
+            ref.test(x[0])                  # warm up oneDNN primitives
+            t0 = time.perf_counter()
+            for t in range(1, 4):
+                ref.test(x[t])
+            dtc = time.perf_counter() - t0
+            log("cpu baseline calibration: %d threads -> %.3f s / 3 steps" % (c, dtc))
+            if best is None or dtc < best[1]:
+                best = (c, dtc)
+        cores = best[0]
+        torch.set_num_threads(cores)
+        ref.reset(True)                     # start from zero state again
+        t0 = time.perf_counter()
+        for t in range(T):
+            ref.test(x[t])
+        votes = ref.votes()
+        dt = time.perf_counter() - t0
+    agree = float(np.mean(votes[-1] == gpu_votes[:n_windows]))
+    return {"value": n_windows / dt, "unit": "IQ windows/s", "cores": cores, "kind": "port",
+            "sample": "%d windows x T=%d, 16x16 plane, torch %s CPU (%d threads), %.1f s" %
+                      (n_windows, T, torch.__version__, torch.get_num_threads(), dt),
+            "vote_agreement_with_gpu": agree}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="IQ windows per GPU per step (weak scaling)")
+    ap.add_argument("--cpu-windows", type=int, default=256, help="CPU baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank, local_rank, world = parallel.init_process_group()
+    assert world == a.gpus, "launch with torchrun --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B = a.batch
+
+    net, convs = build_net(B, dev)
+    enc = IQEncoder(R, R, device=dev)
+    g = torch.Generator().manual_seed(1 + rank)          # every rank its own shard of the synthetic batch
+    iq = (0.4 * torch.randn(B, 2, L_IQ, generator=g)).to(dev)
+    labels = torch.randint(0, N_CLASSES, (B,), generator=g).to(dev)
+    prof = {}
+
+    def step(profile=None):
+        cells = enc(iq, T_STEPS, t0=0)
+        net.zero_states()
+        net.reset()
+        res = net.test_sequence(cells, collect=False, profile=profile)
+        tal = parallel.allreduce_tallies(parallel.tallies(res["vote"], labels, N_CLASSES))
+        return cells, res, tal
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("rank %d/%d: network built, B=%d per GPU" % (rank, world, B))
+    for _ in range(a.warmup):
+        step()
+    fence()
+    log("warmup done")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cells, res, tal = step(profile=prof)
+    fence()
+    dt = time.perf_counter() - t0
+    log("timed region done: %.3f s for %d steps" % (dt, a.steps))
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # dominant kernel: HIP-event time of every k_lif_seq_c32 launch of the timed region (same stream as the launch)
+    c32_ms = [s.elapsed_time(e) for s, e in prof.get("lif_c32", [])]
+    avg_c32_s = float(np.mean(c32_ms)) / 1e3 if c32_ms else float("nan")
+    flop_per_launch = FLOP_C32_PER_SAMPLE_STEP * T_STEPS * B
+    achieved = flop_per_launch / avg_c32_s / 1e12
+    kernel_ms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in prof.items()}
+    cm, acc = parallel.split_tallies(tal, N_CLASSES)
+
+    if rank == 0:
+        out = {
+            "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": world * B * a.steps / dt,
+            "unit": "IQ windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "radio_ml_conv.yaml, 16x16 I/Q plane, T=128, arp=1.0, random_tau, batch %d per GPU "
+                                   "(north_star headline batch), synthetic IQ 0.4*randn(B,2,128), seeded init" % B,
+                       "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [R, R],
+                       "parallelism": "batch shards, %d rank(s), tally all-reduce only" % world},
+            "roofline": {"kernel": "k_lif_seq_c32", "bound": "mfma", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": avg_c32_s * 1e3, "launches": len(c32_ms),
+                         "algorithmic_flop_per_launch": flop_per_launch},
+            "kernel_ms_per_launch": kernel_ms,
+            "vote_accuracy_vs_random_labels": [float(x) for x in acc.cpu()],
+        }
+        if world == 1 and a.cpu_windows > 0:
+            out["cpu_baseline"] = cpu_baseline(net, convs, cells.cpu(), res["vote"][-1].cpu().numpy(),
+                                               min(a.cpu_windows, B))
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

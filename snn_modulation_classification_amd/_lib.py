@@ -82,6 +82,10 @@ def get():
             raise DCLLHipError(
                 "libdcll_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C %s`. There is no CPU fallback for the DCLL layer forward." % (SO_PATH, CSRC))
+        # torch first: PyTorch-ROCm bundles its own libamdhip64.so.7; whichever HIP runtime is mapped first serves
+        # BOTH torch and this library (same SONAME), and the kernels must run in the runtime that owns torch's
+        # streams and allocations.
+        import torch  # noqa: F401
         try:
             lib = ctypes.CDLL(SO_PATH)
         except OSError as e:

@@ -1,0 +1,533 @@
+"""DCLL layers and slices with the reference's public surface, computed by libdcll_hip.so on an MI355X.
+
+Mirrors the names, constructor keywords, attributes, state-dict keys, return tuples and exception types of the
+reference module dcll/pytorch_libdcll.py so `networks.ConvNetwork`, `train.py` and `test_radio_ml.py` keep working:
+
+    ContinuousConv2D / ContinuousRelativeRefractoryConv2D     reference :296-429 / :432-509
+    Conv2dDCLLlayer                                           reference :512-612
+    CLLDenseModule / CLLDenseRRPModule / DenseDCLLlayer       reference :72-148 / :151-195 / :198-266
+    DCLLBase / DCLLClassification                             reference :615-718 / :721-749
+    get_predictions_by_vote / accuracy_by_vote                reference :44-61
+
+What is different by design: `.forward` does not run torch ops — it hands device pointers to the HIP kernels
+through the C ABI (include/dcll_hip.h).  There is no CPU path: a tensor that is not on a GPU raises DCLLHipError.
+Layers also expose `forward_sequence(...)`, the whole-T fast path (state on chip for all T steps).
+Local learning (`train_dcll`, reference :690-718) is SURVEY.md 8(f)-2 and not implemented in this round.
+"""
+import logging
+import math
+from collections import Counter, namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .. import ops
+from .._lib import DenseDesc
+
+logger = logging.getLogger(__name__)
+
+device = 'cuda'      # same module-level switch as the reference (:34); 'cuda' is the MI355X under ROCm
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# vote helpers (host side, reference :44-61)
+# ---------------------------------------------------------------------------------------------------------------
+def _mode_first_seen(row):
+    """Most common entry; among equally common ones the first that appears (Counter.most_common(1))."""
+    return Counter(row).most_common(1)[0][0]
+
+
+def get_predictions_by_vote(pvoutput, labels):
+    """pvoutput: T arrays of per-sample argmax; labels: (T,B,C) one-hot tensor.  -> (pred (B), label (B))."""
+    votes = np.asarray(pvoutput).T
+    lab = labels.detach().cpu().numpy().argmax(axis=2).T
+    pred = np.array([_mode_first_seen(r) for r in votes], dtype=np.float64)
+    labv = np.array([_mode_first_seen(r) for r in lab], dtype=np.float64)
+    return pred, labv
+
+
+def accuracy_by_vote(pvoutput, labels):
+    pred, labv = get_predictions_by_vote(pvoutput, labels)
+    return float(np.mean(pred == labv))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conv LIF dynamics
+# ---------------------------------------------------------------------------------------------------------------
+def _as_pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class ContinuousConv2D(nn.Module):
+    """Two leaky traces on the input + conv + threshold / sigmoid (reference :296-429)."""
+    NeuronState = namedtuple('NeuronState', ('eps0', 'eps1'))
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=2, dilation=1, groups=1, bias=True,
+                 alpha=.95, alphas=.9, act=nn.Sigmoid(), random_tau=False, spiking=True, **kwargs):
+        super().__init__()
+        if in_channels % groups != 0:
+            raise ValueError('in_channels must be divisible by groups')
+        if out_channels % groups != 0:
+            raise ValueError('out_channels must be divisible by groups')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _as_pair(kernel_size)
+        self.padding = _as_pair(padding)
+        self.stride, self.dilation, self.groups = stride, dilation, groups
+        self.random_tau = random_tau
+        self.act = act
+        self.spiking = spiking
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+        self._set_tau(torch.Tensor([alpha]), torch.Tensor([alphas]))
+        self.wrp = 0.
+        self.alpharp = .65
+        self.state = None
+
+    # -- parameters ---------------------------------------------------------------------------------------------
+    def _set_tau(self, alpha, alphas):
+        """alpha -> tau/dt = 1/(1-alpha) in fp32, as Parameters without grad (reference :349-356, :398-405)."""
+        self.alpha = nn.Parameter(alpha, requires_grad=False)
+        self.tau_m__dt = nn.Parameter(1. / (1 - self.alpha), requires_grad=False)
+        self.alphas = nn.Parameter(alphas, requires_grad=False)
+        self.tau_s__dt = nn.Parameter(1. / (1 - self.alphas), requires_grad=False)
+
+    def reset_parameters(self):
+        """W ~ U(+-1e-2/(250 sqrt n)), b ~ U(+-1/(250 sqrt n)), n = C_in*kH*kW (reference :359-366)."""
+        n = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        stdv = 1. / math.sqrt(n) / 250
+        self.weight.data.uniform_(-stdv * 1e-2, stdv * 1e-2)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def randomize_tau(self, im_dims, low=[5, 5], high=[10, 35]):
+        """tau_m ~ U(5,35) ms, tau_s ~ U(5,10) ms per input channel, stored as (C,H,W) (reference :391-405).
+        Draw order (membrane first) and float64 -> float32 conversion follow the reference."""
+        taum = np.random.uniform(low[1], high[1], size=[self.in_channels]) * 1e-3
+        taus = np.random.uniform(low[0], high[0], size=[self.in_channels]) * 1e-3
+        shape = (self.in_channels, im_dims[0], im_dims[1])
+        expand = lambda t: np.ascontiguousarray(np.broadcast_to(t[:, None, None], shape))
+        dev = self.weight.device
+        self._set_tau(torch.Tensor(1 - 1e-3 / expand(taum)).to(dev), torch.Tensor(1 - 1e-3 / expand(taus)).to(dev))
+
+    def get_output_shape(self, im_dims):
+        h = (im_dims[0] + 2 * self.padding[0] - self.dilation * (self.kernel_size[0] - 1) - 1) // self.stride + 1
+        w = (im_dims[1] + 2 * self.padding[1] - self.dilation * (self.kernel_size[1] - 1) - 1) // self.stride + 1
+        return h, w
+
+    # -- state --------------------------------------------------------------------------------------------------
+    def _alloc_state(self, batch_size, im_dims, init_value):
+        dev = self.weight.device
+        shape = (batch_size, self.in_channels, im_dims[0], im_dims[1])
+        return [torch.zeros(shape, device=dev) + init_value, torch.zeros(shape, device=dev) + init_value]
+
+    def init_state(self, batch_size, im_dims, init_value=0):
+        self.state = self.NeuronState(*self._alloc_state(batch_size, im_dims, init_value))
+        if self.random_tau:
+            self.randomize_tau(im_dims)
+            self.random_tau = False          # the plain variant randomises once (reference :385-387)
+        return self.state
+
+    def _check_batch(self, input):
+        if self.state is None or not (input.shape[0] == self.state.eps0.shape[0] == self.state.eps1.shape[0]):
+            old = -1 if self.state is None else self.state.eps0.shape[0]
+            logger.warning("Batch size changed from {} to {} since last iteration. Reallocating states."
+                           .format(old, input.shape[0]))
+            self.init_state(input.shape[0], input.shape[2:4])
+
+    # -- HIP descriptors ----------------------------------------------------------------------------------------
+    def make_desc(self, im_dims, pooling=(1, 1), target=0, output_layer=False):
+        return ops.make_conv_desc(self.in_channels, self.out_channels, im_dims, self.kernel_size, self.padding,
+                                  pooling, target, output_layer, self.alpha.numel() > 1, self.wrp, self.alpharp,
+                                  self.stride, self.dilation, self.groups)
+
+    def tau_per_channel(self):
+        """(4, C_in) tensor [alpha, tau_m, alphas, tau_s] if the time constants do not vary over (H,W), else None."""
+        rows = []
+        for t in (self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt):
+            if t.numel() == 1:
+                rows.append(t.detach().reshape(1).expand(self.in_channels))
+            else:
+                flat = t.detach().reshape(self.in_channels, -1)
+                if not bool((flat == flat[:, :1]).all()):
+                    return None
+                rows.append(flat[:, 0])
+        return torch.stack(rows).contiguous()
+
+    def _step(self, input, pooling=(1, 1), i2o=None, output_=None):
+        """Run one step through dcll_conv_lif_step; returns (s_pooled, p, o, pv_pooled, v)."""
+        if not self.spiking:
+            raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
+        self._check_batch(input)
+        desc = self.make_desc(input.shape[2:4], pooling, 0 if i2o is None else i2o.weight.shape[0],
+                              output_ is not None)
+        st = self.state
+        arp = st.arp if len(st) > 2 else None
+        with torch.no_grad():
+            return ops.conv_lif_step(
+                desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt,
+                st.eps0, st.eps1, arp,
+                None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
+                None if output_ is None else output_.weight, None if output_ is None else output_.bias)
+
+    def forward(self, input):
+        """-> (output spikes, pv, pvmem), un-pooled (reference :407-426)."""
+        s, _, _, pv, v = self._step(input)
+        return s, pv, v
+
+
+class ContinuousRelativeRefractoryConv2D(ContinuousConv2D):
+    """Adds the relative-refractory trace on the output (reference :432-509)."""
+    NeuronState = namedtuple('NeuronState', ('eps0', 'eps1', 'arp'))
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=2, dilation=1, groups=1, bias=True,
+                 alpha=.95, alphas=.9, alpharp=.65, wrp=1, act=nn.Sigmoid(), random_tau=False, **kwargs):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, alpha,
+                         alphas, act)
+        self.wrp = wrp
+        self.alpharp = alpharp
+        self.tau_rp__dt = 1. / (1 - self.alpharp)
+        self.random_tau = random_tau
+
+    def init_state(self, batch_size, im_dims, init_value=0):
+        oh, ow = self.get_output_shape(im_dims)
+        st = self._alloc_state(batch_size, im_dims, init_value)
+        st.append(torch.zeros((batch_size, self.out_channels, oh, ow), device=self.weight.device))
+        self.state = self.NeuronState(*st)
+        if self.random_tau:
+            # observable quirk: this variant never clears the flag, so EVERY init_state re-draws the
+            # time constants (reference :479-481) — kept so that seeded runs match the reference.
+            self.randomize_tau(im_dims)
+        return self.state
+
+    def forward(self, input):
+        """-> (output spikes, pv, pvmem + arp), un-pooled (reference :485-509)."""
+        if not self.spiking:
+            raise Exception('Refractory not allowed in non-spiking mode')
+        s, _, _, pv, v = self._step(input)
+        return s, pv, v
+
+
+class Conv2dDCLLlayer(nn.Module):
+    """LIF conv + max-pool + frozen local readout (+ trainable output readout on the last layer), reference :512-612."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, im_dims=(28, 28), target_size=10, pooling=None,
+                 stride=1, dilation=1, padding=2, alpha=.95, alphas=.9, alpharp=.65, wrp=0, act=nn.Sigmoid(),
+                 lc_dropout=False, lc_ampl=.5, spiking=True, random_tau=False, output_layer=False):
+        super().__init__()
+        self.im_dims = tuple(im_dims)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lc_ampl = lc_ampl
+        self.output_layer = output_layer
+        if pooling is not None:
+            self.pooling = _as_pair(pooling) if not hasattr(pooling, '__len__') else tuple(pooling)
+        else:
+            self.pooling = (1, 1)
+        self.kernel_size = kernel_size
+        self.target_size = target_size
+        if wrp > 0:
+            if not spiking:
+                raise Exception('Non-spiking not allowed with refractory neurons')
+            self.i2h = ContinuousRelativeRefractoryConv2D(
+                in_channels, out_channels, kernel_size, padding=padding, dilation=dilation, stride=stride,
+                alpha=alpha, alphas=alphas, alpharp=alpharp, wrp=wrp, act=act, random_tau=random_tau)
+        else:
+            self.i2h = ContinuousConv2D(
+                in_channels, out_channels, kernel_size, padding=padding, dilation=dilation, stride=stride,
+                alpha=alpha, alphas=alphas, act=act, spiking=spiking, random_tau=random_tau)
+        conv_shape = self.i2h.get_output_shape(self.im_dims)
+        ph_, pw_ = self.pooling
+        # what nn.MaxPool2d(kernel=stride=pooling, padding=(pooling-1)//2) yields (reference :545-549, :567)
+        pooled = ((conv_shape[0] + 2 * ((ph_ - 1) // 2) - ph_) // ph_ + 1,
+                  (conv_shape[1] + 2 * ((pw_ - 1) // 2) - pw_) // pw_ + 1)
+        self.output_shape = torch.Size(pooled)
+        flat = self.get_flat_size()
+        if flat != out_channels * pooled[0] * pooled[1]:
+            # the reference sizes i2o from conv_shape // pooling (:593-597) and would fail in F.linear here
+            raise RuntimeError('pooled map %s does not match conv_shape // pooling %s'
+                               % (tuple(pooled), self.get_output_shape()))
+        self.i2o = nn.Linear(flat, target_size, bias=True)
+        self.i2o.weight.requires_grad = False
+        self.i2o.bias.requires_grad = False
+        if lc_dropout is not False:
+            raise NotImplementedError('lc_dropout is not implemented by the HIP path (ConvNetwork passes False)')
+        if output_layer:
+            self.output_ = nn.Linear(flat, target_size, bias=True)
+        self.reset_lc_parameters()
+
+    def reset_lc_parameters(self):
+        stdv = self.lc_ampl / math.sqrt(self.i2o.weight.size(1))
+        self.i2o.weight.data.uniform_(-stdv, stdv)
+        if self.i2o.bias is not None:
+            self.i2o.bias.data.uniform_(-stdv, stdv)
+
+    def get_output_shape(self):
+        conv_shape = self.i2h.get_output_shape(self.im_dims)
+        return conv_shape[0] // self.pooling[0], conv_shape[1] // self.pooling[1]
+
+    def get_flat_size(self):
+        h, w = self.get_output_shape()
+        return int(h * w * self.out_channels)
+
+    def forward(self, input):
+        """-> (output, pvoutput, pv, pvmem): next-layer spikes (or output_ logits on the last layer), local
+        readout logits, pooled sigmoid, un-pooled membrane (reference :599-608) — one C-ABI call."""
+        s, p, o, pv, v = self.i2h._step(input, self.pooling, self.i2o, self.output_ if self.output_layer else None)
+        return (o if self.output_layer else s), p, pv, v
+
+    def init_hiddens(self, batch_size, init_value=0):
+        self.i2h.init_state(batch_size, self.im_dims, init_value=init_value)
+        return self
+
+    # -- whole-sequence fast path ---------------------------------------------------------------------------------
+    def sequence_kind(self):
+        """'cells' / 'packed' if a fused all-T kernel exists for this geometry (include/dcll_hip.h), else None."""
+        i = self.i2h
+        ok = (self.im_dims == (16, 16) and i.kernel_size == (7, 7) and i.padding == (3, 3) and
+              self.pooling == (1, 1) and i.stride == 1 and i.dilation == 1 and i.groups == 1 and
+              i.out_channels <= 32 and i.bias is not None and i.spiking)
+        if not ok or i.tau_per_channel() is None:
+            return None
+        if i.in_channels == 1:
+            return 'cells'
+        if i.in_channels == 32 and i.out_channels == 32:
+            return 'packed'
+        return None
+
+    def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None):
+        """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,8) int32 ('packed').
+        Neuron state is read from / written back to self.i2h.state.  -> (packed spikes, pv (T,B,C,H,W))."""
+        i2h = self.i2h
+        if i2h.state is None or i2h.state.eps0.shape[0] != B:
+            i2h.init_state(B, self.im_dims)
+        desc = i2h.make_desc(self.im_dims, self.pooling, self.target_size, self.output_layer)
+        tau4 = i2h.tau_per_channel()
+        st = i2h.state
+        arp = st.arp if len(st) > 2 else None
+        fn = ops.conv_lif_sequence_cells if kind == 'cells' else ops.conv_lif_sequence
+        with torch.no_grad():
+            spk, pv, _ = fn(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp, T, B,
+                            want_spikes=want_spikes, out=buffers)
+        return spk, pv
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dense LIF dynamics (reference :72-266)
+# ---------------------------------------------------------------------------------------------------------------
+class CLLDenseModule(nn.Module):
+    NeuronState = namedtuple('NeuronState', ['eps0', 'eps1'])
+
+    def __init__(self, in_channels, out_channels, bias=True, alpha=.9, alphas=.85, act=nn.Sigmoid(), spiking=True,
+                 random_tau=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+        self.act = act
+        self.random_tau = random_tau
+        self._set_tau(torch.Tensor([alpha]), torch.Tensor([alphas]))
+        self.spiking = spiking
+        self.wrp, self.alpharp = 0., .65
+        self.state = None
+
+    _set_tau = ContinuousConv2D._set_tau
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv * 1e-2, stdv * 1e-2)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def _alloc_state(self, batch_size, init_value):
+        dev = self.weight.device
+        return [torch.zeros(batch_size, self.in_channels, device=dev) + init_value,
+                torch.zeros(batch_size, self.in_channels, device=dev) + init_value]
+
+    def init_state(self, batch_size, init_value=0):
+        self.state = self.NeuronState(*self._alloc_state(batch_size, init_value))
+        if self.random_tau:
+            self.randomize_tau()
+        return self.state
+
+    def randomize_tau(self, low=[5, 5], high=[10, 35]):
+        taum = np.random.uniform(low[1], high[1], size=[self.in_channels]) * 1e-3
+        taus = np.random.uniform(low[0], high[0], size=[self.in_channels]) * 1e-3
+        dev = self.weight.device
+        self._set_tau(torch.Tensor(1 - 1e-3 / taum).to(dev), torch.Tensor(1 - 1e-3 / taus).to(dev))
+
+    def _step(self, input, i2o=None):
+        if not self.spiking:
+            raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
+        if self.state is None or not (input.shape[0] == self.state.eps0.shape[0] == self.state.eps1.shape[0]):
+            old = -1 if self.state is None else self.state.eps0.shape[0]
+            logger.warning("Batch size changed from {} to {} since last iteration. Reallocating states."
+                           .format(old, input.shape[0]))
+            self.init_state(input.shape[0])
+        desc = DenseDesc(self.in_channels, self.out_channels, 0 if i2o is None else i2o.weight.shape[0],
+                         int(self.alpha.numel() > 1), int(self.wrp > 0), float(self.alpharp), float(self.wrp))
+        st = self.state
+        with torch.no_grad():
+            return ops.dense_lif_step(desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas,
+                                      self.tau_s__dt, st.eps0, st.eps1, st.arp if len(st) > 2 else None,
+                                      None if i2o is None else i2o.weight, None if i2o is None else i2o.bias)
+
+    def forward(self, input):
+        s, _, pv, v = self._step(input)
+        return s, pv, v
+
+
+class CLLDenseRRPModule(CLLDenseModule):
+    NeuronState = namedtuple('NeuronState', ('eps0', 'eps1', 'arp'))
+
+    def __init__(self, in_channels, out_channels, bias=True, alpha=.95, alphas=.9, alpharp=.65, wrp=100,
+                 act=nn.Sigmoid(), spiking=True, random_tau=False):
+        super().__init__(in_channels, out_channels, bias, alpha, alphas, act, spiking=spiking, random_tau=random_tau)
+        self.wrp = wrp
+        self.alpharp = alpharp
+
+    def init_state(self, batch_size, init_value=0):
+        st = self._alloc_state(batch_size, init_value)
+        st.append(torch.zeros(batch_size, self.out_channels, device=self.weight.device) + init_value)
+        self.state = self.NeuronState(*st)
+        return self.state
+
+    def forward(self, input):
+        if not self.spiking:
+            raise Exception('Refractory not allowed in non-spiking mode')
+        return super().forward(input)
+
+
+class DenseDCLLlayer(nn.Module):
+    def __init__(self, in_channels, out_channels, target_size=None, bias=True, alpha=.9, alphas=.85, alpharp=.65,
+                 wrp=0., act=nn.Sigmoid(), lc_dropout=False, lc_ampl=.5, spiking=True, random_tau=False,
+                 output_layer=False):
+        if target_size is None:
+            target_size = out_channels
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lc_ampl = lc_ampl
+        self.target_size = target_size
+        self.output_layer = False          # the reference forces this (:222)
+        if wrp > 0:
+            self.i2h = CLLDenseRRPModule(in_channels, out_channels, alpha=alpha, alphas=alphas, alpharp=alpharp,
+                                         wrp=wrp, bias=bias, act=act, spiking=spiking, random_tau=random_tau)
+        else:
+            self.i2h = CLLDenseModule(in_channels, out_channels, alpha=alpha, alphas=alphas, bias=bias, act=act,
+                                      spiking=spiking, random_tau=random_tau)
+        self.i2o = nn.Linear(out_channels, target_size, bias=bias)
+        self.i2o.weight.requires_grad = False
+        if bias:
+            self.i2o.bias.requires_grad = False
+        self.input_size = self.out_channels
+        self.reset_lc_parameters()
+        if lc_dropout is not False:
+            raise NotImplementedError('lc_dropout is not implemented by the HIP path')
+
+    reset_lc_parameters = Conv2dDCLLlayer.reset_lc_parameters
+
+    def forward(self, input):
+        """-> (output spikes, pvoutput, pv, pvmem)  (reference :250-255)."""
+        s, p, pv, v = self.i2h._step(input.reshape(-1, self.in_channels), self.i2o)
+        return s, p, pv, v
+
+    def init_hiddens(self, batch_size, init_value=0):
+        self.i2h.init_state(batch_size, init_value=init_value)
+        return self
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# slices: per-step driver + vote collection (reference :615-749)
+# ---------------------------------------------------------------------------------------------------------------
+class DCLLBase(nn.Module):
+    num_instances = 0
+
+    def __init__(self, dclllayer, name='DCLLbase', batch_size=48, loss=torch.nn.MSELoss, optimizer=optim.SGD,
+                 kwargs_optimizer={'lr': 5e-5}, burnin=200, collect_stats=False):
+        super().__init__()
+        self.dclllayer = dclllayer
+        if loss is not None:
+            self.crit = loss().to(device)
+            self.output_crit = loss().to(device)
+        if optimizer is not None:
+            self.optimizer = optimizer(dclllayer.i2h.parameters(), **kwargs_optimizer)
+            if self.dclllayer.output_layer:
+                self.optimizer2 = optimizer(dclllayer.output_.parameters(), lr=1e-4)
+        self.burnin = burnin
+        self.batch_size = batch_size
+        self.collect_stats = collect_stats
+        self.init(self.batch_size)
+        self.stats_bins = np.linspace(0, 1, 20)
+        self.name = name
+        self.slice_id = DCLLBase.num_instances
+        DCLLBase.num_instances += 1
+
+    def init(self, batch_size, init_states=True):
+        self.clout = []
+        self.activity_hist = []
+        self.iter = 0
+        if init_states:
+            self.dclllayer.init_hiddens(batch_size, init_value=0)
+
+    def forward(self, input):
+        self.iter += 1
+        o, p, pv, pvmem = self.dclllayer.forward(input)
+        if self.collect_stats and (self.iter % 20) == 0:
+            # the reference histograms pv on the host (19 bins) and later keeps only the first and last bin
+            self.activity_hist.append(np.histogram(pv.detach().cpu().numpy(), bins=self.stats_bins)[0])
+        return o, p, pv, pvmem
+
+    def write_stats(self, writer, label, epoch):
+        writer.add_histogram(self.name + '/weight', self.dclllayer.i2h.weight.flatten(), epoch)
+        writer.add_histogram(self.name + '/bias', self.dclllayer.i2h.bias.flatten(), epoch)
+        if self.collect_stats and len(self.activity_hist):
+            pd = np.mean(self.activity_hist, axis=0)
+            pd = pd / pd.sum()
+            writer.add_scalar(self.name + '/low_pv/' + label, pd[0], epoch)
+            writer.add_scalar(self.name + '/high_pv/' + label, pd[-1], epoch)
+            print(self.name + ' low:{0:1.3} high:{1:1.3}'.format(pd[0], pd[-1]))
+
+    def train_dcll(self, input, target, do_train=True, regularize=0.05):
+        raise NotImplementedError(
+            'local learning (train_dcll, reference dcll/pytorch_libdcll.py:690-718) is not part of this build yet '
+            '(SURVEY.md 8(f)-2); the HIP path covers the forward / vote loop')
+
+
+class DCLLClassification(DCLLBase):
+    def forward(self, input, ignore_burnin=False):
+        o, p, pv, pvmem = super().forward(input)
+        if ignore_burnin or self.iter >= self.burnin:
+            logits = o if self.dclllayer.output_layer else p
+            self.clout.append(logits.argmax(1).detach().cpu().numpy())
+        return o, p, pv, pvmem
+
+    def set_sequence_result(self, clout_dev, n_steps):
+        """Install the per-step argmax of a whole-sequence run ((T,B) int32 on device) as `clout`."""
+        self.iter += n_steps
+        self.clout = list(clout_dev.cpu().numpy().astype(np.int64))
+
+    def write_stats(self, writer, label, epoch):
+        super().write_stats(writer, label, epoch)
+        writer.add_scalar(self.name + '/acc/' + label, self.acc, epoch)
+
+    def accuracy(self, targets):
+        begin = len(self.clout)
+        self.acc = accuracy_by_vote(self.clout, targets[-begin:])
+        return self.acc
+
+    def confusion_matrix(self, targets):
+        begin = len(self.clout)
+        pred, labv = get_predictions_by_vote(self.clout, targets[-begin:])
+        n = self.dclllayer.target_size
+        cm = np.zeros((n, n), dtype=int)
+        for p_, l_ in zip(pred, labv):
+            cm[int(p_), int(l_)] += 1
+        return cm

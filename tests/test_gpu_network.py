@@ -1,0 +1,153 @@
+"""GPU tests of the drop-in surface: the reference's builder / slice protocol driven exactly like test_radio_ml.py
+drives it (per-step net.test) and through the fused whole-sequence path, against the reference's golden outputs."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, unpack_bits
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(ROOT, "snn_modulation_classification_amd")
+LOGIT_TOL = 1e-4
+
+
+def _args(**kw):
+    a = dict(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    a.update(kw)
+    return Namespace(**a)
+
+
+def _radio_net(B, R_, **kw):
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(**kw), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    return net
+
+
+def _one_hot_labels(labels, T, n):
+    y = torch.zeros(T, len(labels), n)
+    y[:, np.arange(len(labels)), labels] = 1
+    return y
+
+
+def test_sequence_path_reproduces_reference_run(golden):
+    """Same seeds as the reference run that produced the golden file => same network; the fused path must give the
+    reference's per-step argmax, votes, accuracy and confusion matrix (radio_ml_conv.yaml, 16x16, T=128, B=2)."""
+    g = golden("g2_radio_r16_t128_b2.npz")
+    net = _radio_net(2, 16)
+    assert net.sequence_supported()
+    cells = torch.from_numpy(g["cells"]).cuda()
+    T, B = cells.shape
+    net.reset()
+    res = net.test_sequence(cells)
+    for i in range(3):
+        np.testing.assert_allclose(res["logits"][i].cpu().numpy(), g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+        assert np.array_equal(np.array(net.dcll_slices[i].clout), g["clout/%d" % i])
+        assert np.array_equal(res["vote"][i].cpu().numpy(), g["vote/%d" % i])
+    np.testing.assert_allclose(res["o"].cpu().numpy(), g["o_last"], atol=LOGIT_TOL, rtol=0)
+    y = _one_hot_labels(g["labels"], T, 24)
+    assert net.accuracy(y) == list(g["acc"])
+    assert np.array_equal(net.confusion_matrix(y), g["confusion"])
+
+
+def test_per_step_path_reproduces_reference_run(golden):
+    """The reference's own driving pattern (test_radio_ml.py:142-146): reset, T x net.test(x[t]), accuracy."""
+    from snn_modulation_classification_amd.data.utils import iq2spiketrain, to_one_hot
+    g = golden("g2_radio_r16_t128_b2.npz")
+    net = _radio_net(2, 16)
+    x = torch.from_numpy(g["iq"])
+    labels1h = to_one_hot(torch.from_numpy(g["labels"]), 24)
+    np.random.seed(3)
+    spikes, targets = iq2spiketrain(x, labels1h, out_w=16, out_h=16, max_duration=128)
+    test_input = torch.Tensor(spikes).to('cuda')
+    net.reset()
+    net.eval()
+    for t in range(128):
+        net.test(x=test_input[t])
+    for i in range(3):
+        assert np.array_equal(np.array(net.dcll_slices[i].clout), g["clout/%d" % i])
+    assert net.accuracy(torch.Tensor(targets)) == list(g["acc"])
+    for i, s in enumerate(net.dcll_slices):
+        for name in ("eps0", "eps1"):
+            assert np.array_equal(getattr(s.dclllayer.i2h.state, name).cpu().numpy(), g["final/%d/%s" % (i, name)])
+
+
+def test_sequence_equals_per_step_with_state_carry_over():
+    """Quirk Q3: net.reset() does not zero the neuron state; two consecutive batches through the fused path must
+    equal 2T per-step calls (state written back by the sequence kernels)."""
+    rng = np.random.RandomState(4)
+    T, B = 20, 5
+    cells = rng.randint(0, 256, size=(2, T, B)).astype(np.int32)
+    a, b = _radio_net(B, 16), _radio_net(B, 16)
+    for k in range(2):
+        a.reset()
+        b.reset()
+        ra = a.test_sequence(torch.from_numpy(cells[k]).cuda())
+        for t in range(T):
+            x = torch.zeros(B, 256)
+            x[torch.arange(B), torch.from_numpy(cells[k, t]).long()] = 1
+            b.test(x.reshape(B, 1, 16, 16).cuda())
+        for i in range(3):
+            for name in ("eps0", "eps1", "arp"):
+                sa = getattr(a.dcll_slices[i].dclllayer.i2h.state, name)
+                sb = getattr(b.dcll_slices[i].dclllayer.i2h.state, name)
+                assert torch.equal(sa, sb), (k, i, name)
+            assert np.array_equal(np.array(a.dcll_slices[i].clout), np.array(b.dcll_slices[i].clout))
+    a.zero_states()
+    assert all(float(t.abs().sum()) == 0 for s in a.dcll_slices for t in s.dclllayer.i2h.state)
+
+
+def test_mnist_config1_per_step(golden):
+    """BASELINE config 1 geometry on the GPU per-step path (28x28, pool 2/1/2, no refractory) vs the C oracle
+    (bit-exact spikes) and the reference (logits)."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from oracle import c_oracle as C
+    g = golden("g2_mnist_t50_b4.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "mnist_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(arp=0.0), (1, 28, 28), 4, convs, 10, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    assert not net.sequence_supported()
+    sds = [g.sub("sd/%d/" % i) for i in range(3)]
+    orc = C.OracleConvNetwork(sds, convs, (28, 28), 0.0)
+    xs = unpack_bits(g["x"], 28 * 28)
+    T, B = xs.shape[:2]
+    net.reset()
+    for t in range(T):
+        x = xs[t].reshape(B, 1, 28, 28)
+        cur = torch.from_numpy(x).cuda()
+        outs = orc.step(x)
+        for i, s in enumerate(net.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            np.testing.assert_allclose(p.cpu().numpy(), outs[i]["p"], atol=LOGIT_TOL, rtol=0)
+            if i < 2:
+                assert np.array_equal(o.cpu().numpy(), outs[i]["s"]), (t, i)
+            cur = o
+    agree = np.mean([np.mean(np.array(net.dcll_slices[i].clout) == g["clout/%d" % i]) for i in range(3)])
+    assert agree > 0.99
+
+
+def test_device_iq_encoder_equals_host_encoder():
+    from snn_modulation_classification_amd.data.utils import IQEncoder, iq2cells, cell_thresholds
+    torch.manual_seed(0)
+    B, L, T = 64, 128, 96
+    x = 0.4 * torch.randn(B, 2, 1, L)
+    thr = torch.from_numpy(cell_thresholds(-1, 1, 16))
+    x[:15, 0, 0, 5] = thr                      # exactly on / just below every cell boundary
+    x[:15, 1, 0, 7] = torch.from_numpy(np.nextafter(thr.numpy(), np.float32(-9)))
+    x[20, 0, 0, :4] = torch.tensor([-3.0, 3.0, 1.0, -1.0])
+    np.random.seed(5)
+    host, t0 = iq2cells(x, out_w=16, out_h=16, max_duration=T)
+    enc = IQEncoder(16, 16, device='cuda')
+    np.random.seed(5)
+    dev = enc(x.cuda(), T)
+    assert np.array_equal(dev.cpu().numpy(), host.numpy())

@@ -1,0 +1,252 @@
+"""CPU-side tests of the host layer (no GPU, no compute through the HIP library): encoders, YAML builder, network
+construction / state-dict layout / seeded-init parity with the reference, vote helpers, ABI symbol table."""
+import os
+import re
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, unpack_bits
+
+PKG = os.path.join(ROOT, "snn_modulation_classification_amd")
+
+
+# ---------------------------------------------------------------------------------------------- C ABI / loading
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "dcll_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcll_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from snn_modulation_classification_amd import _lib
+    lib = _lib.get()
+    syms = _declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), "libdcll_hip.so lacks %s declared in include/dcll_hip.h" % s
+        assert s in _lib.SIGNATURES, "binding lacks a signature for %s" % s
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.dcll_version() == _lib.ABI_VERSION
+    assert lib.dcll_last_error() is not None
+
+
+def test_desc_struct_layout_matches_header():
+    import ctypes
+    from snn_modulation_classification_amd import _lib
+    assert ctypes.sizeof(_lib.ConvDesc) == 17 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.DenseDesc) == 5 * 4 + 2 * 4
+    from oracle import c_oracle
+    assert [f[0] for f in _lib.ConvDesc._fields_] == [f[0] for f in c_oracle.ConvDesc._fields_]
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly on CPU tensors instead of computing somewhere else."""
+    from snn_modulation_classification_amd import _lib
+    from snn_modulation_classification_amd.dcll import pytorch_libdcll as L
+    layer = L.Conv2dDCLLlayer(1, 4, kernel_size=3, padding=1, pooling=1, im_dims=(8, 8), target_size=5, wrp=1.0)
+    layer.init_hiddens(2)
+    with pytest.raises(_lib.DCLLHipError):
+        layer.forward(torch.zeros(2, 1, 8, 8))
+    dl = L.DenseDCLLlayer(6, 4, target_size=3).init_hiddens(2)
+    with pytest.raises(_lib.DCLLHipError):
+        dl.forward(torch.zeros(2, 6))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(PKG):
+        for fn in files:
+            if fn.endswith(".py") or fn.endswith(".hip"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+    for fn in ("train.py", "test_radio_ml.py"):
+        p = os.path.join(ROOT, fn)
+        if os.path.exists(p):
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", open(p).read(), flags=re.M), fn
+
+
+# ---------------------------------------------------------------------------------------------- encoders
+@pytest.mark.parametrize("R_,T", [(16, 64), (16, 32), (28, 64), (28, 32), (128, 64), (128, 32)])
+def test_iq2spiketrain_matches_reference(golden, R_, T):
+    from snn_modulation_classification_amd.data import utils as U
+    g = golden("g3_iq2spiketrain.npz")
+    x = torch.from_numpy(g["R%d_T%d/x" % (R_, T)])
+    B = x.shape[0]
+    y = U.to_one_hot(torch.arange(B) % 24, 24)
+    np.random.seed(11)
+    st, tg = U.iq2spiketrain(x, y, out_w=R_, out_h=R_, max_duration=T)
+    assert st.dtype == np.float64 and st.shape == (T, B, 1, R_, R_)
+    assert st.sum() == T * B
+    assert np.array_equal(st.reshape(T, B, -1).argmax(-1), g["R%d_T%d/cell" % (R_, T)])
+    assert np.array_equal(np.asarray(tg, dtype=np.float32), g["R%d_T%d/target" % (R_, T)])
+    np.random.seed(11)
+    cells, t0 = U.iq2cells(x, out_w=R_, out_h=R_, max_duration=T)
+    assert t0 == int(g["R%d_T%d/t0" % (R_, T)])
+    assert np.array_equal(cells.numpy(), g["R%d_T%d/cell" % (R_, T)])
+
+
+def test_iq2spiketrain_rect_bounds_no_gamma(golden):
+    from snn_modulation_classification_amd.data import utils as U
+    g = golden("g3_iq2spiketrain.npz")
+    x = torch.from_numpy(g["rect/x"])
+    y = U.to_one_hot(torch.arange(5) % 24, 24)
+    np.random.seed(12)
+    st, _ = U.iq2spiketrain(x, y, out_w=20, out_h=12, min_I=-2, max_I=1.5, min_Q=-0.5, max_Q=0.75,
+                            max_duration=32, do_gamma=False)
+    assert np.array_equal(st.reshape(32, 5, -1).argmax(-1), g["rect/cell"])
+
+
+def test_image2spiketrain_matches_reference(golden):
+    from snn_modulation_classification_amd.data import utils as U
+    g = golden("g8_image2spiketrain.npz")
+    np.random.seed(21)
+    a, tg = U.image2spiketrain(g["x"], g["y"], (1, 6, 6), gain=100, min_duration=19, max_duration=20)
+    assert a.shape == (20, 3, 1, 6, 6)
+    assert np.array_equal(a.reshape(20, 3, -1), unpack_bits(g["spikes"], 36))
+    assert np.array_equal(np.asarray(tg), g["target"])
+
+
+def test_cell_thresholds_reproduce_host_quantiser():
+    """Device encoder contract: cell = #{j: x >= thr[j]} == host quantiser on full vector groups."""
+    from snn_modulation_classification_amd.data import utils as U
+    rng = np.random.RandomState(0)
+    for R_ in (16, 28):
+        thr = U.cell_thresholds(-1, 1, R_)
+        assert np.all(np.diff(thr) > 0)
+        x = np.concatenate([rng.randn(4096).astype(np.float32) * 0.6, thr, np.nextafter(thr, np.float32(-9)),
+                            np.array([-5, -1, 0, 1, 5], np.float32)])
+        x = x[:len(x) // 64 * 64]
+        host = U._quantise(torch.from_numpy(x), -1, 1, R_, True).numpy()
+        dev_rule = (x[:, None] >= thr[None, :]).sum(1)
+        assert np.array_equal(host, dev_rule)
+
+
+# ---------------------------------------------------------------------------------------------- builder
+def test_load_network_spec_matches_reference(golden_meta):
+    from snn_modulation_classification_amd.networks import load_network_spec
+    for name, ref in golden_meta["g5"].items():
+        got = load_network_spec(os.path.join(PKG, "networks", name))
+        norm = [{k: (list(v) if isinstance(v, tuple) else v) for k, v in d.items()} for d in got]
+        assert norm == ref, name
+        for d in got:
+            for v in d.values():
+                assert isinstance(v, (int, tuple))
+
+
+def _args(**kw):
+    a = dict(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    a.update(kw)
+    return Namespace(**a)
+
+
+@pytest.fixture
+def cpu_device(monkeypatch):
+    """Construction (parameters, state-dict) is legal on CPU; only forward needs the GPU."""
+    from snn_modulation_classification_amd.dcll import pytorch_libdcll as L
+    monkeypatch.setattr(L, "device", "cpu")
+    return L
+
+
+@pytest.mark.parametrize("fixture,R_,B,kw", [
+    ("g2_radio_r16_t128_b2.npz", 16, 2, {}),
+    ("g2_radio_r8_t32_b3_traces.npz", 8, 3, dict(netscale=0.25)),
+    ("g2_radio_r8_t24_b2_norp_traces.npz", 8, 2, dict(netscale=0.25, arp=0.0, random_tau=False))])
+def test_seeded_network_equals_reference_state_dict(golden, cpu_device, fixture, R_, B, kw):
+    """Same seeds, same constructor call order => the SAME parameters as the reference (weights, frozen readouts
+    and the thrice re-drawn time constants of quirk Q4), and the same state-dict keys and shapes."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    g = golden(fixture)
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(**kw), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    sd = net.state_dict()
+    ref_keys = sorted("dcll_slices.%d.dclllayer.%s" % (i, k) for i in range(3) for k in g.sub("sd/%d/" % i))
+    assert sorted(sd.keys()) == ref_keys
+    for i in range(3):
+        for k, v in g.sub("sd/%d/" % i).items():
+            mine = sd["dcll_slices.%d.dclllayer.%s" % (i, k)].numpy()
+            assert mine.shape == v.shape, k
+            assert np.array_equal(mine, v), (i, k)
+    if kw.get("arp", 1.0) > 0:
+        assert net.sequence_supported() == (R_ == 16)
+    # a reference state-dict loads into the build's module tree
+    net.load_state_dict({("dcll_slices.%d.dclllayer.%s" % (i, k)): torch.from_numpy(v)
+                         for i in range(3) for k, v in g.sub("sd/%d/" % i).items()})
+
+
+def test_mnist_network_shapes(golden, cpu_device):
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    g = golden("g2_mnist_t50_b4.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "mnist_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(arp=0.0), (1, 28, 28), 4, convs, 10, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    shapes = [tuple(s.dclllayer.output_shape) for s in net.dcll_slices]
+    assert shapes == [(13, 13), (11, 11), (4, 4)]
+    for i in range(3):
+        for k, v in g.sub("sd/%d/" % i).items():
+            assert np.array_equal(net.state_dict()["dcll_slices.%d.dclllayer.%s" % (i, k)].numpy(), v), (i, k)
+    assert not net.sequence_supported()
+
+
+def test_layer_surface(cpu_device):
+    L = cpu_device
+    layer = L.Conv2dDCLLlayer(3, 8, kernel_size=(1, 3), padding=(0, 1), pooling=(1, 2), im_dims=(1, 64),
+                              target_size=24, wrp=1.0, random_tau=True, output_layer=True)
+    assert layer.init_hiddens(5) is layer
+    assert isinstance(layer.i2h, L.ContinuousRelativeRefractoryConv2D)
+    assert layer.i2h.state._fields == ('eps0', 'eps1', 'arp')
+    assert tuple(layer.i2h.state.arp.shape) == (5, 8, 1, 64)
+    assert tuple(layer.output_shape) == (1, 32) and layer.get_flat_size() == 8 * 32
+    assert layer.i2h.alpha.shape == (3, 1, 64) and not layer.i2h.alpha.requires_grad
+    assert not layer.i2o.weight.requires_grad and layer.output_.weight.requires_grad
+    assert [n for n, p in layer.named_parameters() if p.requires_grad] == \
+        ['i2h.weight', 'i2h.bias', 'output_.weight', 'output_.bias']
+    plain = L.Conv2dDCLLlayer(1, 4, kernel_size=5, im_dims=(28, 28), pooling=2, wrp=0)
+    assert isinstance(plain.i2h, L.ContinuousConv2D) and not isinstance(plain.i2h, L.ContinuousRelativeRefractoryConv2D)
+    assert plain.init_hiddens(2).i2h.state._fields == ('eps0', 'eps1')
+    with pytest.raises(ValueError):
+        L.ContinuousConv2D(3, 4, 3, groups=2)
+    with pytest.raises(Exception):
+        L.Conv2dDCLLlayer(1, 4, wrp=1.0, spiking=False)
+    d = L.DenseDCLLlayer(10, 6, target_size=3, wrp=1.0, output_layer=True)
+    assert d.output_layer is False and isinstance(d.i2h, L.CLLDenseRRPModule)
+
+
+# ---------------------------------------------------------------------------------------------- votes
+def test_vote_helpers_match_reference(golden):
+    from snn_modulation_classification_amd.dcll import pytorch_libdcll as L
+    g = golden("g4_votes.npz")
+    clout = list(g["clout"])
+    T, B = g["clout"].shape
+    y = torch.zeros(T, B, 5)
+    y[:, np.arange(B), g["labels"]] = 1
+    pred, labv = L.get_predictions_by_vote(clout, y)
+    assert np.array_equal(pred.astype(np.int64), g["pred"])
+    assert np.array_equal(labv.astype(np.int64), g["labv"])
+    assert L.accuracy_by_vote(clout, y) == float(g["acc"])
+
+
+def test_classification_slice_bookkeeping(cpu_device):
+    L = cpu_device
+    layer = L.Conv2dDCLLlayer(1, 4, kernel_size=3, padding=1, pooling=1, im_dims=(8, 8), target_size=5, wrp=1.0)
+    s = L.DCLLClassification(layer, name='conv0', batch_size=3, loss=None, optimizer=None, burnin=4)
+    assert s.iter == 0 and s.clout == [] and layer.i2h.state.eps0.shape[0] == 3
+    s.set_sequence_result(torch.tensor([[0, 1, 2], [0, 1, 1], [3, 1, 1]], dtype=torch.int32), 3)
+    assert s.iter == 3 and len(s.clout) == 3
+    y = torch.zeros(3, 3, 5)
+    y[:, 0, 0] = 1; y[:, 1, 1] = 1; y[:, 2, 2] = 1
+    assert s.accuracy(y) == pytest.approx(2 / 3)
+    cm = s.confusion_matrix(y)
+    assert cm[0, 0] == 1 and cm[1, 1] == 1 and cm[1, 2] == 1 and cm.sum() == 3
+    with pytest.raises(NotImplementedError):
+        s.train_dcll(torch.zeros(3, 1, 8, 8), y[0])
+    s.init(3, init_states=False)
+    assert s.iter == 0 and s.clout == []
