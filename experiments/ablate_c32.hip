@@ -1,0 +1,46 @@
+// Ablation timing of k_lif_seq_c32 (diagnostic, not product): which part of a stage costs what.
+#include "../snn_modulation_classification_amd/csrc/dcll_hip.hip"
+#include <vector>
+template <int AB>
+static float run(int B, int T, bool want_pv)
+{
+    size_t nin = (size_t)T * B * 32 * 8;
+    uint32_t *spk_in, *spk_out; float *W, *bias, *tau4, *e0, *e1, *arp, *pv;
+    hipMalloc(&spk_in, nin * 4); hipMalloc(&spk_out, nin * 4);
+    hipMemset(spk_in, 0x11, nin * 4);
+    hipMalloc(&W, 32 * 32 * 49 * 4); hipMalloc(&bias, 128); hipMalloc(&tau4, 512);
+    std::vector<float> hw(32 * 32 * 49, 1e-6f), hb(32, 1e-4f), ht(128, 0.9f);
+    hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(bias, hb.data(), 128, hipMemcpyHostToDevice);
+    hipMemcpy(tau4, ht.data(), 512, hipMemcpyHostToDevice);
+    size_t ns = (size_t)B * 32 * 256;
+    hipMalloc(&e0, ns * 4); hipMalloc(&e1, ns * 4); hipMalloc(&arp, ns * 4);
+    hipMemset(e0, 0, ns * 4); hipMemset(e1, 0, ns * 4); hipMemset(arp, 0, ns * 4);
+    hipMalloc(&pv, (size_t)T * ns * 4);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_lif_seq_c32<true, AB>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out,
+                           want_pv ? pv : nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    hipFree(spk_in); hipFree(spk_out); hipFree(W); hipFree(bias); hipFree(tau4); hipFree(e0); hipFree(e1); hipFree(arp); hipFree(pv);
+    return best;
+}
+int main()
+{
+    const int B = 1024, T = 128;
+    double ideal = 2.0 * 32 * 1568 * 256 * (double)T * B / 157.3e12 * 1e3;
+    printf("ideal at 157.3 TF: %.2f ms\n", ideal);
+    printf("full                         %.2f ms\n", run<0>(B, T, true));
+    printf("full, no pv store            %.2f ms\n", run<0>(B, T, false));
+    printf("no epilogue                  %.2f ms\n", run<1>(B, T, true));
+    printf("no trace update              %.2f ms\n", run<2>(B, T, true));
+    printf("no epilogue, no trace        %.2f ms\n", run<3>(B, T, true));
+    printf("no hand-off                  %.2f ms\n", run<4>(B, T, true));
+    printf("no epi/trace/hand-off        %.2f ms\n", run<7>(B, T, true));
+    return 0;
+}

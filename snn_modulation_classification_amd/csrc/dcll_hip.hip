@@ -443,21 +443,31 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__
 //   instruction are the input-channel pair (2cp, 2cp+1) at the same tap, so both halves of the wave read LDS at
 //   one immediate offset from a per-lane base.  The instruction is, bit for bit, acc = fmaf(a1,b1,fmaf(a0,b0,acc)).
 //
-// LDS image of eps1 (zero padding shared between rows and between channels):
+// LDS image of eps1 (zero padding shared between rows and between channels), DOUBLE-buffered by step parity:
 //   element (ci, y, x), y,x in [-3,18]  at float offset  ci*361 + (y+3)*19 + (x+3);   only 0<=y,x<16 is ever written.
 //   (x=16..18 of row y aliases x=-3..-1 of row y+1; rows 16..18 of channel c alias rows -3..-1 of channel c+1.)
 //
 // Stage g (one s_barrier per stage): wave w computes tile q = g - w (step t = q>>3, pixel tile m = q&7 = image rows
-//   2m, 2m+1): takes the accumulator of wave w-1 from slot[w-1][(g-1)&1] (wave 0: bias), adds its 98 MFMAs, puts it
-//   in slot[w][g&1].  Wave (g&7) additionally finishes tile g-8 (handed over by wave 7): refractory trace, threshold,
-//   sigmoid, ballot-packed spikes; it keeps the arp of "its" tile m = w in 16 registers for the whole sequence.
-//   At m == 0 a wave first advances the traces of its own 4 input channels by one step (input bits of step t).
+//   2m, 2m+1) from image[t&1]: takes the accumulator of wave w-1 from slot[w-1][(g-1)&1] (wave 0: bias), adds its 98
+//   MFMAs, puts it in slot[w][g&1]: a systolic chain, so every output is ONE fmaf chain in the pinned order.
+//
+// Measured on MI355X (experiments/overlap.hip): v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 vector ALUs, so every
+//   VALU instruction of either wave of a SIMD adds its cycles to the MFMA time — nothing hides under the partner's
+//   MFMAs — and all waves meet at the stage barrier.  The non-MFMA work is therefore spread evenly over the four SIMDs
+//   (waves w and w+4 share a SIMD) in every stage:
+//   - trace update: wave w advances ONE of its 4 input channels per stage, for step t+1, in stages m = 2c + (w>>2)
+//     of step t (reads image[t&1], writes image[(t+1)&1]; eps0 lives in registers);
+//   - epilogue of the tile handed over by wave 7 (refractory trace, threshold, sigmoid, ballot-packed spikes): split
+//     by accumulator register quad over the 4 waves with (w>>2) == (m&1); wave w owns quad w&3 (channels
+//     rr + 8*(w&3) + 4*(lane>>5)) of the tiles of its parity and keeps their 16 arp values in registers.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int NWAVE = 8, CPW = 4, ROWF = 19, CHF = 361;
-constexpr int EPS1_FLOATS = 32 * CHF + 3 * ROWF + 3 + 61;     // 11673 -> covers (ci=31, y=18, x=18) + slack
+constexpr int IMG_FLOATS = ((32 * CHF + 3 * ROWF + 3 + 61) + 3) & ~3;     // 11676 >= offset of (ci=31, y=18, x=18) + 1
 constexpr int SLOT_FLOATS = 16 * 64;
 
-template <bool REFRACTORY>
+// ABLATE is a diagnostic knob for experiments/ablate_c32.hip only (bit0: no epilogue, bit1: no trace update,
+// bit2: no accumulator hand-off); every product launch uses ABLATE = 0.
+template <bool REFRACTORY, int ABLATE = 0>
 __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
@@ -465,15 +475,15 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                                                       float *__restrict__ pv_out, float *__restrict__ v_out, int T,
                                                       int B, float alpharp, float wrp)
 {
-    __shared__ __attribute__((aligned(16))) float lds[EPS1_FLOATS + 3 + NWAVE * 2 * SLOT_FLOATS + 32];
-    float *img = lds;
-    float *slots = lds + ((EPS1_FLOATS + 3) & ~3);
+    __shared__ __attribute__((aligned(16))) float lds[2 * IMG_FLOATS + NWAVE * 2 * SLOT_FLOATS + 32];
+    float *slots = lds + 2 * IMG_FLOATS;
     float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, kept scalar
+    const int wq = w & 3, wpar = w >> 2;                          // epilogue quad / tile parity owned by this wave
     const long b = blockIdx.x;
 
-    for (int i = tid; i < ((EPS1_FLOATS + 3) & ~3); i += 512) img[i] = 0.0f;
+    for (int i = tid; i < 2 * IMG_FLOATS; i += 512) lds[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
 
     // weight fragments: A[co = j][k = h] of MFMA (cp, tap) = W[j][4w + 2cp + h][tap]
@@ -483,62 +493,130 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
 #pragma unroll
         for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
 
-    // trace state of my 4 channels: element i (0..15): ci_local = i>>2, pix = (i&3)*64 + lane.
-    // eps0 lives in registers, eps1 only in the LDS image (offset ioff + c*CHF + (i&3)*4*ROWF).
+    // trace state of my 4 channels: element (c, ii): channel 4w+c, pixel ii*64 + lane.  eps0 in registers, eps1 in
+    // the LDS images at float offset ioff + c*CHF + ii*4*ROWF.
     float e0[16];
     const int ioff = (4 * w) * CHF + ((lane >> 4) + 3) * ROWF + (lane & 15) + 3;
-    __syncthreads();        // image zeroed before the state is written into it
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        long g = (b * 32 + 4 * w + (i >> 2)) * 256 + (i & 3) * 64 + lane;
-        e0[i] = eps0_g[g];
-        img[ioff + (i >> 2) * CHF + (i & 3) * 4 * ROWF] = eps1_g[g];
-    }
-    // refractory trace of "my" output tile m = w:  reg r <-> co = (r&3)+8*(r>>2)+4h, pixel = 32w + j
-    float arp[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        arp[r] = REFRACTORY ? arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 32 * w + j] : 0.0f;
-
-    // input spike words of my 4 channels for step t: 32 consecutive uint32, lane l < 32 holds word l
-    const uint32_t *in_base = spk_in + (b * 32 + 4 * w) * 8;
+    // input spike words of step t for my channels: 32 consecutive uint32 (channel c, word 2*ii + h)
+    const uint32_t *in_lane = spk_in + (b * 32 + 4 * w) * 8 + h;
     const long in_step = (long)B * 32 * 8;
-    uint32_t words = (T > 0 && lane < 32) ? in_base[lane] : 0u;
+    __syncthreads();        // images zeroed
+
+    // one trace element update: input bit -> eps0 (register) and eps1 (src image -> dst image)
+    auto trace_elem = [&](uint32_t word, float &e0r, const float *src, float *dst, float ta, float tm, float tas,
+                          float ts) {
+        float xin = (float)((word >> j) & 1u);
+        float e1 = *src;
+        trace_update(xin, ta, tm, tas, ts, e0r, e1);
+        *dst = e1;
+    };
+
+    // prologue: state from HBM, advanced to step 0 with the input bits of step 0 -> image[0]
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
+        const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const long gidx = (b * 32 + 4 * w + c) * 256 + ii * 64 + lane;
+            e0[c * 4 + ii] = eps0_g[gidx];
+            float e1 = eps1_g[gidx];
+            if (!(ABLATE & 2)) {
+                float xin = (float)((in_lane[c * 8 + ii * 2] >> j) & 1u);
+                trace_update(xin, ta, tm, tas, ts, e0[c * 4 + ii], e1);
+            }
+            lds[ioff + c * CHF + ii * 4 * ROWF] = e1;
+        }
+    }
+    // refractory trace of my epilogue share: tiles m = 2k + wpar (k = 0..3), quad wq:
+    //   arp[k][rr] <-> channel rr + 8*wq + 4h, pixel 32*(2k+wpar) + j
+    float arp[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            arp[k][rr] = REFRACTORY ? arp_g[(b * 32 + rr + 8 * wq + 4 * h) * 256 + 32 * (2 * k + wpar) + j] : 0.0f;
 
     // per-lane base of the B-fragment reads: channel 4w+h, pixel row (j>>4), col (j&15); tile m adds 2 rows
     const int bbase = (4 * w + h) * CHF + (j >> 4) * ROWF + (j & 15);
+    // input words of my NEXT trace share (step 1, channel 0 first), fetched one share ahead
+    uint32_t pw[4] = {0u, 0u, 0u, 0u};
+    if (T > 1) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) pw[ii] = in_lane[in_step + ii * 2];
+    }
     __syncthreads();
 
     const int nstage = 8 * T + 9;
     for (int g = 0; g < nstage; ++g) {
+        // ---- (1) epilogue share: quad wq of tile qe = g - 8 (finished by wave 7 in the previous stage) ----
+        const int qe = g - 8;
+        if (!(ABLATE & 1) && qe >= 0 && qe < 8 * T && ((qe & 1) == wpar)) {
+            const int te = qe >> 3, me = qe & 7;
+            const f32x4 v4 = *((const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + wq * 64 + lane);
+            const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
+            const int pix = 32 * me + j;
+            auto quad = [&](float (&ar)[4]) {
+                uint32_t myword = 0;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    float v = v4[rr];
+                    bool s;
+                    if (REFRACTORY) v = refractory(v4[rr], ar[rr], alpharp, wrp, s);
+                    else s = v > 0.0f;
+                    unsigned long long mk = __ballot(s);
+                    uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                    myword = (j == rr) ? mine : myword;
+                    if (pv_out) pv_out[(obase + rr) * 256 + pix] = sigmoidf_dev(v);
+                    if (v_out) v_out[(obase + rr) * 256 + pix] = v;
+                }
+                if (spk_out && j < 4) spk_out[(obase + j) * 8 + me] = myword;
+            };
+            switch (me >> 1) {          // wave-uniform: keeps arp[][] statically indexed (registers)
+            case 0: quad(arp[0]); break;
+            case 1: quad(arp[1]); break;
+            case 2: quad(arp[2]); break;
+            default: quad(arp[3]); break;
+            }
+        }
         const int q = g - w;
         if (q >= 0 && q < 8 * T) {
-            const int m = q & 7;
-            if (m == 0) {
-                // advance my traces to step t = q>>3 and refresh my part of the LDS image
-                uint32_t cur = words;
-                const int tn = (q >> 3) + 1;
-                if (tn < T && lane < 32) words = in_base[(long)tn * in_step + lane];
+            const int m = q & 7, t = q >> 3;
+            float *img = lds + (t & 1) * IMG_FLOATS;
+            // ---- (2) trace share: channel c of step t+1 in stage m = 2c + wpar ----
+            if (!(ABLATE & 2) && ((m & 1) == wpar) && t + 1 < T) {
+                const int c = m >> 1;
+                const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
+                const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
+                const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3];
+                {   // prefetch the words of my next share: (t+1, c+1) or (t+2, 0)
+                    const int tn = (c < 3) ? t + 1 : t + 2, cn = (c + 1) & 3;
+                    if (tn < T) {
+                        const uint32_t *ip = in_lane + (long)tn * in_step + cn * 8;
 #pragma unroll
-                for (int c = 0; c < CPW; ++c) {
-                    const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
-                    const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int i = c * 4 + ii;
-                        uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, c * 8 + ii * 2);
-                        uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, c * 8 + ii * 2 + 1);
-                        uint32_t ww = h ? w1 : w0;
-                        float xin = ((ww >> j) & 1u) ? 1.0f : 0.0f;
-                        float *ip = img + ioff + c * CHF + ii * 4 * ROWF;
-                        float e1 = *ip;
-                        trace_update(xin, ta, tm, tas, ts, e0[i], e1);
-                        *ip = e1;
+                        for (int ii = 0; ii < 4; ++ii) pw[ii] = ip[ii * 2];
                     }
                 }
+                const float *src = img + ioff + c * CHF;
+                float *dst = lds + ((t + 1) & 1) * IMG_FLOATS + ioff + c * CHF;
+                switch (c) {            // wave-uniform: keeps e0[] statically indexed (registers)
+#define DCLL_TRACE_CASE(C)                                                                \
+    case C:                                                                               \
+        trace_elem(w0, e0[C * 4 + 0], src + 0 * 4 * ROWF, dst + 0 * 4 * ROWF, ta, tm, tas, ts); \
+        trace_elem(w1, e0[C * 4 + 1], src + 1 * 4 * ROWF, dst + 1 * 4 * ROWF, ta, tm, tas, ts); \
+        trace_elem(w2, e0[C * 4 + 2], src + 2 * 4 * ROWF, dst + 2 * 4 * ROWF, ta, tm, tas, ts); \
+        trace_elem(w3, e0[C * 4 + 3], src + 3 * 4 * ROWF, dst + 3 * 4 * ROWF, ta, tm, tas, ts); \
+        break;
+                    DCLL_TRACE_CASE(0)
+                    DCLL_TRACE_CASE(1)
+                    DCLL_TRACE_CASE(2)
+                    DCLL_TRACE_CASE(3)
+#undef DCLL_TRACE_CASE
+                }
             }
+            // ---- (3) my K-slice of the chain ----
             f32x16 acc;
-            if (w == 0) {
+            if (w == 0 || (ABLATE & 4)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
             } else {
@@ -549,61 +627,53 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                     acc[4 * c + 0] = v4[0]; acc[4 * c + 1] = v4[1]; acc[4 * c + 2] = v4[2]; acc[4 * c + 3] = v4[3];
                 }
             }
+            // 14 rows of 7 taps (row = (cp, ky)); the B fragments of row r+1 are fetched from LDS before the MFMAs of
+            // row r are issued (explicit double buffer, order pinned with sched_barrier).
             const float *bp = img + bbase + m * 2 * ROWF;
+            float bq[2][7];
 #pragma unroll
-            for (int cp = 0; cp < 2; ++cp)
+            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = bp[kx];
 #pragma unroll
-                for (int ky = 0; ky < 7; ++ky)
+            for (int r = 0; r < 14; ++r) {
+                if (r + 1 < 14) {
+                    const int cpn = (r + 1) / 7, kyn = (r + 1) % 7;
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][ky * 7 + kx],
-                                                                   bp[cp * 2 * CHF + ky * ROWF + kx], acc, 0, 0, 0);
-            f32x4 *dp = (f32x4 *)(slots + (w * 2 + (g & 1)) * SLOT_FLOATS) + lane;
+                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = bp[cpn * 2 * CHF + kyn * ROWF + kx];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 v4 = {acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
-                dp[c * 64] = v4;
+                for (int kx = 0; kx < 7; ++kx)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r / 7][(r % 7) * 7 + kx], bq[r & 1][kx], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        const int qe = g - 8;
-        if ((g & 7) == w && qe >= 0 && qe < 8 * T) {
-            // finish tile qe (pixel tile m = w of step te): slot[7][(g-1)&1] holds bias + full K chain
-            const int te = qe >> 3;
-            const f32x4 *sp = (const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + lane;
-            const long obase = ((long)te * B + b) * 32;
-            uint32_t myword = 0;
+            f32x4 *dp = (f32x4 *)(slots + (w * 2 + (g & 1)) * SLOT_FLOATS) + lane;
+            if (ABLATE & 4) {
+                if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.678f) dp[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 v4 = sp[c * 64];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int r = 4 * c + rr;
-                    const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float v = v4[rr];
-                    bool s;
-                    if (REFRACTORY) v = refractory(v4[rr], arp[r], alpharp, wrp, s);
-                    else s = v > 0.0f;
-                    unsigned long long mk = __ballot(s);
-                    uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-                    myword = (j == r) ? mine : myword;
-                    if (pv_out) pv_out[(obase + co) * 256 + 32 * w + j] = sigmoidf_dev(v);
-                    if (v_out) v_out[(obase + co) * 256 + 32 * w + j] = v;
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 v4 = {acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                    dp[c * 64] = v4;
                 }
             }
-            if (spk_out && j < 16) spk_out[(obase + (j & 3) + 8 * (j >> 2) + 4 * h) * 8 + w] = myword;
         }
         __syncthreads();
     }
 
+    // state back to HBM: eps1 of the last step lives in image[(T-1)&1]
+    const float *fin = lds + ((T - 1) & 1) * IMG_FLOATS;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        long g = (b * 32 + 4 * w + (i >> 2)) * 256 + (i & 3) * 64 + lane;
-        eps0_g[g] = e0[i];
-        eps1_g[g] = img[ioff + (i >> 2) * CHF + (i & 3) * 4 * ROWF];
+        long gidx = (b * 32 + 4 * w + (i >> 2)) * 256 + (i & 3) * 64 + lane;
+        eps0_g[gidx] = e0[i];
+        eps1_g[gidx] = fin[ioff + (i >> 2) * CHF + (i & 3) * 4 * ROWF];
     }
     if (REFRACTORY) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 32 * w + j] = arp[r];
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                arp_g[(b * 32 + rr + 8 * wq + 4 * h) * 256 + 32 * (2 * k + wpar) + j] = arp[k][rr];
     }
 }
 
