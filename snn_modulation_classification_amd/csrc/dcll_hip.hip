@@ -95,7 +95,8 @@ extern "C" int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *ch, int32_t
 // ------------------------------------------------------------------------------------------------------------
 // shared device helpers
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_dev(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// pv = 1/(1+exp(-v)): v_exp_f32 + v_rcp_f32 (each ~1 ulp); pv is not bit-pinned (include/dcll_hip.h), |err| ~1e-7.
+__device__ __forceinline__ float sigmoidf_dev(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // dcll/pytorch_libdcll.py:493-494 — (x*tau_s) + (alphas*eps0) ; (alpha*eps1) + (eps0'*tau_m); every op rounded.
 __device__ __forceinline__ void trace_update(float x, float alpha, float tau_m, float alphas, float tau_s,
@@ -467,7 +468,7 @@ constexpr int SLOT_FLOATS = 16 * 64;
 
 // ABLATE is a diagnostic knob for experiments/ablate_c32.hip only (bit0: no epilogue, bit1: no trace update,
 // bit2: no accumulator hand-off); every product launch uses ABLATE = 0.
-template <bool REFRACTORY, int ABLATE = 0>
+template <bool REFRACTORY, int OUT = 3, int ABLATE = 0>      // OUT bit0: write pv, bit1: write v
 __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
@@ -497,18 +498,24 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
     // the LDS images at float offset ioff + c*CHF + ii*4*ROWF.
     float e0[16];
     const int ioff = (4 * w) * CHF + ((lane >> 4) + 3) * ROWF + (lane & 15) + 3;
-    // input spike words of step t for my channels: 32 consecutive uint32 (channel c, word 2*ii + h)
-    const uint32_t *in_lane = spk_in + (b * 32 + 4 * w) * 8 + h;
-    const long in_step = (long)B * 32 * 8;
+    // input spikes of step t for my channels: channel c = 8 consecutive uint32 = 4 x 64-bit masks; mask ii covers
+    // pixels ii*64 .. ii*64+63, i.e. bit l of mask ii is the input of (pixel ii*64 + lane l): the mask IS the lane mask
+    // of a v_cndmask.  Wave-uniform addresses -> scalar loads (lgkmcnt; no vmcnt traffic inside the stage loop).
+    const unsigned long long *in_wave = (const unsigned long long *)(spk_in + (b * 32 + 4 * w) * 8);
+    const long in_step = (long)B * 32 * 4;      // in 64-bit units
     __syncthreads();        // images zeroed
 
-    // one trace element update: input bit -> eps0 (register) and eps1 (src image -> dst image)
-    auto trace_elem = [&](uint32_t word, float &e0r, const float *src, float *dst, float ta, float tm, float tas,
-                          float ts) {
-        float xin = (float)((word >> j) & 1u);
-        float e1 = *src;
-        trace_update(xin, ta, tm, tas, ts, e0r, e1);
-        *dst = e1;
+    // one trace element update: x*tau_s by lane mask -> eps0 (register) and eps1 (src image -> dst image);
+    // dcll/pytorch_libdcll.py:493-494, every op rounded separately.
+    auto trace_elem = [&](unsigned long long mask, float &e0r, const float *src, float *dst, float ta, float tm,
+                          float tas, float ts) {
+        float a;                                    // x * tau_s with x in {0,1}: exact select
+        asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(a) : "v"(ts), "s"(mask));
+        float bb = tas * e0r;
+        e0r = a + bb;
+        float cc = ta * (*src);
+        float dd = e0r * tm;
+        *dst = cc + dd;
     };
 
     // prologue: state from HBM, advanced to step 0 with the input bits of step 0 -> image[0]
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
             e0[c * 4 + ii] = eps0_g[gidx];
             float e1 = eps1_g[gidx];
             if (!(ABLATE & 2)) {
-                float xin = (float)((in_lane[c * 8 + ii * 2] >> j) & 1u);
+                float xin = (float)((in_wave[c * 4 + ii] >> lane) & 1ull);
                 trace_update(xin, ta, tm, tas, ts, e0[c * 4 + ii], e1);
             }
             lds[ioff + c * CHF + ii * 4 * ROWF] = e1;
@@ -539,12 +546,23 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
 
     // per-lane base of the B-fragment reads: channel 4w+h, pixel row (j>>4), col (j&15); tile m adds 2 rows
     const int bbase = (4 * w + h) * CHF + (j >> 4) * ROWF + (j & 15);
-    // input words of my NEXT trace share (step 1, channel 0 first), fetched one share ahead
-    uint32_t pw[4] = {0u, 0u, 0u, 0u};
+    // input masks of my NEXT trace share (step 1, channel 0 first), fetched one share ahead into SGPRs
+    unsigned long long pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
     if (T > 1) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) pw[ii] = in_lane[in_step + ii * 2];
+        const unsigned long long *ip = in_wave + in_step;
+        pw0 = ip[0]; pw1 = ip[1]; pw2 = ip[2]; pw3 = ip[3];
     }
+    // every prologue load (weights, state, arp) has landed before the stage loop: keeps vmcnt waits out of the loop
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) asm volatile("" ::"v"(arp[k][rr]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(e0[i]));
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+        for (int k = 0; k < 49; ++k) asm volatile("" ::"v"(wf[cp][k]));
     __syncthreads();
 
     const int nstage = 8 * T + 9;
@@ -555,7 +573,8 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
             const int te = qe >> 3, me = qe & 7;
             const f32x4 v4 = *((const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + wq * 64 + lane);
             const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
-            const int pix = 32 * me + j;
+            const long oelem = obase * 256 + 32 * me + j;                     // + rr*256
+            float *pvp = pv_out + oelem, *vp = v_out + oelem;
             auto quad = [&](float (&ar)[4]) {
                 uint32_t myword = 0;
 #pragma unroll
@@ -567,8 +586,8 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                     unsigned long long mk = __ballot(s);
                     uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
                     myword = (j == rr) ? mine : myword;
-                    if (pv_out) pv_out[(obase + rr) * 256 + pix] = sigmoidf_dev(v);
-                    if (v_out) v_out[(obase + rr) * 256 + pix] = v;
+                    if (OUT & 1) pvp[rr * 256] = sigmoidf_dev(v);
+                    if (OUT & 2) vp[rr * 256] = v;
                 }
                 if (spk_out && j < 4) spk_out[(obase + j) * 8 + me] = myword;
             };
@@ -588,13 +607,12 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                 const int c = m >> 1;
                 const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
                 const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
-                const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3];
-                {   // prefetch the words of my next share: (t+1, c+1) or (t+2, 0)
+                const unsigned long long w0 = pw0, w1 = pw1, w2 = pw2, w3 = pw3;
+                {   // prefetch the masks of my next share: (t+1, c+1) or (t+2, 0)
                     const int tn = (c < 3) ? t + 1 : t + 2, cn = (c + 1) & 3;
                     if (tn < T) {
-                        const uint32_t *ip = in_lane + (long)tn * in_step + cn * 8;
-#pragma unroll
-                        for (int ii = 0; ii < 4; ++ii) pw[ii] = ip[ii * 2];
+                        const unsigned long long *ip = in_wave + (long)tn * in_step + cn * 4;
+                        pw0 = ip[0]; pw1 = ip[1]; pw2 = ip[2]; pw3 = ip[3];
                     }
                 }
                 const float *src = img + ioff + c * CHF;
@@ -795,12 +813,26 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
     if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: negative size");
     if (T == 0 || B == 0) return DCLL_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (d->refractory)
-        hipLaunchKernelGGL(k_lif_seq_c32<true>, dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out,
-                           pv_out, v_out, T, B, d->alpharp, d->wrp);
-    else
-        hipLaunchKernelGGL(k_lif_seq_c32<false>, dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out,
-                           pv_out, v_out, T, B, d->alpharp, d->wrp);
+    const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
+#define DCLL_LAUNCH_C32(R, O)                                                                                         \
+    hipLaunchKernelGGL((k_lif_seq_c32<R, O>), dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, \
+                       pv_out, v_out, T, B, d->alpharp, d->wrp)
+    if (d->refractory) {
+        switch (out) {
+        case 0: DCLL_LAUNCH_C32(true, 0); break;
+        case 1: DCLL_LAUNCH_C32(true, 1); break;
+        case 2: DCLL_LAUNCH_C32(true, 2); break;
+        default: DCLL_LAUNCH_C32(true, 3); break;
+        }
+    } else {
+        switch (out) {
+        case 0: DCLL_LAUNCH_C32(false, 0); break;
+        case 1: DCLL_LAUNCH_C32(false, 1); break;
+        case 2: DCLL_LAUNCH_C32(false, 2); break;
+        default: DCLL_LAUNCH_C32(false, 3); break;
+        }
+    }
+#undef DCLL_LAUNCH_C32
     HIP_CHECK_LAUNCH("k_lif_seq_c32");
     return DCLL_OK;
 }
