@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Per-SNR evaluation of a DCLL network on RadioML IQ windows — MI355X build.
+
+Keeps the command line, the printed lines and the output files of the reference's test_radio_ml.py (flags :17-61;
+snr_evaluation.txt, confusion_matrix_snr_%d.npy, snr_evaluation_accs.npy :71,156-169) while the inner loop
+(:142-146) runs on the HIP kernels: the fused whole-sequence path when the network geometry has one
+(radio_ml_conv.yaml on a 16x16 I/Q plane), otherwise one C-ABI call per layer per step.
+
+Data: `--radio_ml_data_dir` must hold the per-(class, SNR) HDF5 split of RadioML 2018.01A that the reference's loader
+produces; reading it needs h5py (not in this image).  `--synthetic N` evaluates N seeded synthetic windows per SNR
+instead (the build's own generator: PSK/QAM constellations + AWGN), which is also what the tests use.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from snn_modulation_classification_amd.data.utils import IQEncoder, iq2spiketrain, to_one_hot
+from snn_modulation_classification_amd.dcll import pytorch_libdcll
+from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+
+TARGET_SIZE = 24      # hard-coded in the reference (test_radio_ml.py:78)
+
+
+def str2bool_like_reference(v):
+    """argparse `type=bool` of the reference: any non-empty string is True."""
+    return bool(v)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('--radio_ml_data_dir', type=str, default='2018.01', help='folder with the RadioML HDF5 file(s)')
+    p.add_argument('--per_h5_frac', type=float, default=0.5, metavar='N', help='fraction of each HDF5 file to use')
+    p.add_argument('--train_frac', type=float, default=0.9, metavar='N', help='train split (rest is test)')
+    p.add_argument('--network_spec', type=str, default=os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), 'snn_modulation_classification_amd', 'networks',
+        'radio_ml_conv.yaml'), metavar='S', help='YAML file describing the architecture')
+    p.add_argument('--I_resolution', type=int, default=128, metavar='N', help='I size of the I/Q plane image')
+    p.add_argument('--Q_resolution', type=int, default=128, metavar='N', help='Q size of the I/Q plane image')
+    p.add_argument('--I_bounds', type=float, default=(-1, 1), nargs=2, help='value range of the I axis')
+    p.add_argument('--Q_bounds', type=float, default=(-1, 1), nargs=2, help='value range of the Q axis')
+    p.add_argument('--restore_path', type=str, metavar='S', help='.pth state-dict to restore')
+    p.add_argument('--burnin', type=int, default=50, metavar='N', help='burnin')
+    p.add_argument('--batch_size_test', type=int, default=64, metavar='N', help='test batch size')
+    p.add_argument('--seed', type=int, default=1, metavar='S', help='random seed')
+    p.add_argument('--n_test_samples', type=int, default=128, metavar='N', help='test samples per SNR')
+    p.add_argument('--n_iters_test', type=int, default=1024, metavar='N', help='timesteps per sample')
+    p.add_argument('--alpha', type=float, default=.92, metavar='N', help='membrane time constant')
+    p.add_argument('--alphas', type=float, default=.85, metavar='N', help='synapse time constant')
+    p.add_argument('--alpharp', type=float, default=.65, metavar='N', help='refractory time constant')
+    p.add_argument('--arp', type=float, default=0, metavar='N', help='refractory weight (wrp)')
+    p.add_argument('--random_tau', type=str2bool_like_reference, default=True, help='randomize time constants')
+    p.add_argument('--beta', type=float, default=.95, metavar='N', help='Adam beta2 (unused at test time)')
+    p.add_argument('--lc_ampl', type=float, default=.5, metavar='N', help='local classifier init magnitude')
+    p.add_argument('--netscale', type=float, default=1., metavar='N', help='scale network width')
+    p.add_argument('--print_all_confusion_matrices', action='store_true')
+    # additions of this build
+    p.add_argument('--synthetic', type=int, default=0, metavar='N',
+                   help='evaluate N seeded synthetic IQ windows per SNR instead of reading HDF5')
+    p.add_argument('--out_dir', type=str, default=None, help='where to write results (default: dir of restore_path)')
+    p.add_argument('--no_sequence_path', action='store_true', help='force the per-step path (net.test per timestep)')
+    return p.parse_args(argv)
+
+
+def synthetic_modulation_batches(n, batch, snr_db, length, seed):
+    """Seeded stand-in for the RadioML loader: 24 constellation 'classes', AWGN at snr_db, unit power * 0.5."""
+    rng = np.random.RandomState(seed + 1000 * (snr_db + 50))
+    out = []
+    for _ in range(int(np.ceil(n / batch))):
+        labels = rng.randint(0, TARGET_SIZE, size=batch)
+        order = 2 + labels % 6                                  # points per ring
+        rings = 1 + labels // 6                                 # number of amplitude rings
+        k = rng.randint(0, 1 << 16, size=(batch, length))
+        phase = 2 * np.pi * (k % order[:, None]) / order[:, None] + 0.1 * labels[:, None]
+        amp = (1 + (k // 7) % rings[:, None]) / rings[:, None]
+        sym = amp * np.exp(1j * phase)
+        sym /= np.sqrt(np.mean(np.abs(sym) ** 2, axis=1, keepdims=True))
+        noise = (rng.randn(batch, length) + 1j * rng.randn(batch, length)) * np.sqrt(0.5 * 10 ** (-snr_db / 10))
+        x = 0.5 * (sym + noise)
+        iq = np.stack([x.real, x.imag], axis=1)[:, :, None, :].astype(np.float32)
+        out.append((torch.from_numpy(iq), torch.from_numpy(labels)))
+    return out
+
+
+def load_batches(args, snr, n_batches):
+    if args.synthetic:
+        return synthetic_modulation_batches(args.synthetic, args.batch_size_test, snr, max(args.n_iters_test, 128),
+                                            args.seed)[:n_batches]
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        sys.exit('Reading RadioML 2018.01A needs h5py, which is not installed here; pass --synthetic N to evaluate '
+                 'synthetic IQ windows (HDF5 reader: SURVEY.md 8(f)-4).')
+    sys.exit('The RadioML 2018.01A HDF5 reader is not part of this build yet (SURVEY.md 8(f)-4); use --synthetic N.')
+
+
+def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
+    """One batch through all timesteps; returns (per-layer accuracy list, confusion matrix of the last layer)."""
+    T = args.n_iters_test
+    if use_sequence:
+        cells = encoder(samples.to(pytorch_libdcll.device), T)         # IQ -> cells on the GPU
+        targets = labels1h.unsqueeze(0).repeat(T, 1, 1)
+        net.reset()
+        net.eval()
+        net.test_sequence(cells)
+    else:
+        spikes, targets = iq2spiketrain(samples, labels1h, out_w=args.I_resolution, out_h=args.Q_resolution,
+                                        min_I=args.I_bounds[0], max_I=args.I_bounds[1], min_Q=args.Q_bounds[0],
+                                        max_Q=args.Q_bounds[1], max_duration=T)
+        try:
+            test_input = torch.Tensor(spikes).to(pytorch_libdcll.device)
+        except RuntimeError as e:
+            print('Exception: ' + str(e) + '. Try to decrease your batch_size_test with the --batch_size_test argument.')
+            raise
+        net.reset()
+        net.eval()
+        for t in range(T):
+            net.test(x=test_input[t])
+    targets = torch.as_tensor(np.asarray(targets), dtype=torch.float32)
+    return net.accuracy(targets), net.confusion_matrix(targets)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    out_dir = args.out_dir or (os.path.dirname(args.restore_path) if args.restore_path else '.')
+    os.makedirs(out_dir or '.', exist_ok=True)
+    with open(os.path.join(out_dir, 'snr_evaluation.txt'), 'a+') as logfile:
+        def say(text):
+            print(text)
+            logfile.write(text + '\n')
+
+        im_dims = (1, args.Q_resolution, args.I_resolution)
+        n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
+        convs = load_network_spec(args.network_spec)
+        net = ConvNetwork(args, im_dims, args.batch_size_test, convs, TARGET_SIZE, act=torch.nn.Sigmoid(), loss=None,
+                          opt=None, opt_param={}, learning_rates=None, burnin=args.burnin)
+        if args.restore_path:
+            say('-' * 80)
+            if not os.path.isfile(args.restore_path):
+                say('ERROR: Cannot load `%s`.' % args.restore_path)
+                say('File does not exist! Aborting...')
+                sys.exit(0)
+            net.load_state_dict(torch.load(args.restore_path))
+            say('Loaded the SNN model from `%s`.' % args.restore_path)
+            say('-' * 80)
+        net = net.to(pytorch_libdcll.device)
+        net.reset(True)
+        use_sequence = net.sequence_supported() and not args.no_sequence_path
+        encoder = IQEncoder(args.I_resolution, args.Q_resolution, args.I_bounds, args.Q_bounds,
+                            device=pytorch_libdcll.device) if use_sequence else None
+
+        accs = []
+        snrs = np.array(range(6, 32, 2))
+        total_cm = np.zeros((TARGET_SIZE, TARGET_SIZE), dtype=int)
+        for snr in snrs:
+            t_start = time.time()
+            batches = load_batches(args, int(snr), n_test)
+            acc_test = np.zeros([len(batches), len(net.dcll_slices)])
+            cm = np.zeros((TARGET_SIZE, TARGET_SIZE), dtype=int)
+            for i, (samples, labels) in enumerate(batches):
+                acc_test[i, :], cm_i = evaluate_batch(net, args, samples, to_one_hot(labels, TARGET_SIZE), encoder,
+                                                      use_sequence)
+                cm += cm_i
+            acc = np.mean(acc_test, axis=0)
+            say('SNR {} \t Accuracy {} \t Time Elapsed {}'.format(str(snr).zfill(2), acc,
+                                                                   '%.2f s' % (time.time() - t_start)))
+            if args.print_all_confusion_matrices:
+                say('Confusion matrix:')
+                say(np.array2string(cm, max_line_width=300))
+            np.save(os.path.join(out_dir, 'confusion_matrix_snr_%d.npy' % snr), cm)
+            accs.append(acc)
+            total_cm += cm
+        say('---\nTotal confusion matrix:')
+        say(np.array2string(total_cm, max_line_width=300))
+        npy_out = os.path.join(out_dir, 'snr_evaluation_accs.npy')
+        np.save(npy_out, accs)
+        say('Wrote `%s`.' % npy_out)
+        try:                                  # plots are optional extras of the reference (:170-188)
+            import matplotlib
+            matplotlib.use('Agg')
+            import matplotlib.pyplot as plt
+            plt.imsave(os.path.join(out_dir, 'total_confusion_matrix.png'), total_cm, cmap='gray')
+        except Exception:
+            pass
+    return accs
+
+
+if __name__ == '__main__':
+    main()

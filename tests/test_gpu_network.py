@@ -151,3 +151,20 @@ def test_device_iq_encoder_equals_host_encoder():
     np.random.seed(5)
     dev = enc(x.cuda(), T)
     assert np.array_equal(dev.cpu().numpy(), host.numpy())
+
+
+def test_entry_point_test_radio_ml_synthetic(tmp_path):
+    """The evaluation CLI end to end on the GPU (script settings of the reference: 16x16, arp 1, burnin 20),
+    synthetic IQ; fused path and per-step path must write identical accuracies."""
+    import test_radio_ml
+    common = ['--I_resolution', '16', '--Q_resolution', '16', '--arp', '1.0', '--burnin', '20', '--n_iters_test', '24',
+              '--batch_size_test', '32', '--n_test_samples', '64', '--synthetic', '64']
+    a = test_radio_ml.main(common + ['--out_dir', str(tmp_path / 'seq')])
+    b = test_radio_ml.main(common + ['--out_dir', str(tmp_path / 'step'), '--no_sequence_path'])
+    assert len(a) == 13 and np.asarray(a).shape == (13, 3)
+    assert np.array_equal(np.asarray(a), np.asarray(b))
+    for d in ('seq', 'step'):
+        assert (tmp_path / d / 'snr_evaluation.txt').exists()
+        assert (tmp_path / d / 'snr_evaluation_accs.npy').exists()
+        assert (tmp_path / d / 'confusion_matrix_snr_6.npy').exists()
+        assert np.load(tmp_path / d / 'confusion_matrix_snr_30.npy').sum() == 64

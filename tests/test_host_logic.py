@@ -250,3 +250,37 @@ def test_classification_slice_bookkeeping(cpu_device):
         s.train_dcll(torch.zeros(3, 1, 8, 8), y[0])
     s.init(3, init_states=False)
     assert s.iter == 0 and s.clout == []
+
+
+# ---------------------------------------------------------------------------------------------- entry points
+# flag surface of the reference entry points (name -> default), transcribed as data from
+# reference test_radio_ml.py:17-61 and train.py:19-94
+REF_TEST_FLAGS = dict(radio_ml_data_dir='2018.01', per_h5_frac=0.5, train_frac=0.9, I_resolution=128,
+                      Q_resolution=128, I_bounds=(-1, 1), Q_bounds=(-1, 1), restore_path=None, burnin=50,
+                      batch_size_test=64, seed=1, n_test_samples=128, n_iters_test=1024, alpha=.92, alphas=.85,
+                      alpharp=.65, arp=0, random_tau=True, beta=.95, lc_ampl=.5, netscale=1.,
+                      print_all_confusion_matrices=False)
+REF_TRAIN_FLAGS = dict(data='RadioML', radio_ml_data_dir='2018.01', min_snr=6, max_snr=30, per_h5_frac=0.5,
+                       train_frac=0.9, just_ref=False, I_resolution=128, Q_resolution=128, I_bounds=(-1, 1),
+                       Q_bounds=(-1, 1), restore_path=None, burnin=50, batch_size=64, batch_size_test=64,
+                       n_steps=10000, no_save=False, seed=1, n_test_interval=20, n_test_samples=128, n_iters=1024,
+                       n_iters_test=1024, optim_type='Adam', loss_type='SmoothL1Loss', learning_rates=[1e-6],
+                       ref_lr=1e-3, alpha=.92, alphas=.85, alpharp=.65, arp=0, random_tau=True, beta=.95, lc_ampl=0.5,
+                       netscale=1., comment='', output='results')
+
+
+def test_entry_point_flag_surface():
+    import test_radio_ml
+    import train
+    a = vars(test_radio_ml.parse_args([]))
+    for k, v in REF_TEST_FLAGS.items():
+        assert k in a and a[k] == v, k
+    assert a['network_spec'].endswith('networks/radio_ml_conv.yaml') and os.path.isfile(a['network_spec'])
+    b = vars(train.parse_args([]))
+    for k, v in REF_TRAIN_FLAGS.items():
+        assert k in b and b[k] == v, k
+    assert b['ref_network_spec'].endswith('networks/radio_ml_conv_ref.yaml')
+    # the reference's `type=bool` quirk: any non-empty string is True
+    assert test_radio_ml.parse_args(['--random_tau', 'False']).random_tau is True
+    s = test_radio_ml.parse_args(['--I_bounds', '-2', '1.5', '--arp', '1.0', '--burnin', '20'])
+    assert s.I_bounds == [-2.0, 1.5] and s.arp == 1.0 and s.burnin == 20

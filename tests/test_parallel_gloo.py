@@ -1,0 +1,72 @@
+"""Multi-process path on CPU (gloo, world_size 2): batch sharding + the tally all-reduce that the 8-GPU run does
+over RCCL.  No data-path collective exists: shards are independent, only tallies are summed."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from snn_modulation_classification_amd import parallel
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 8, 4096, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_tallies_single_process():
+    votes = [torch.tensor([0, 1, 2, 2, 1]), torch.tensor([2, 2, 2, 2, 2])]
+    labels = torch.tensor([0, 1, 1, 2, 0])
+    t = parallel.allreduce_tallies(parallel.tallies(votes, labels, 3))
+    cm, acc = parallel.split_tallies(t, 3)
+    assert cm.shape == (2, 3, 3) and int(cm[0].sum()) == 5
+    assert cm[0, 2, 1] == 1 and cm[0, 1, 0] == 1 and cm[0, 0, 0] == 1
+    assert acc.tolist() == [3 / 5, 1 / 5]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, votes_np, labels_np, n_classes, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, lr, w = parallel.init_process_group(backend="gloo")
+    assert (r, w) == (rank, world)
+    a, b = parallel.shard_range(labels_np.shape[0], rank, world)
+    votes = [torch.from_numpy(v[a:b]) for v in votes_np]
+    t = parallel.allreduce_tallies(parallel.tallies(votes, torch.from_numpy(labels_np[a:b]), n_classes))
+    np.save(os.path.join(out_dir, "tally_%d.npy" % rank), t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_tally_allreduce_equals_single_process(tmp_path):
+    rng = np.random.RandomState(0)
+    n, n_classes = 1001, 24                 # odd size: ragged shards
+    votes_np = [rng.randint(0, n_classes, size=n).astype(np.int64) for _ in range(3)]
+    labels_np = rng.randint(0, n_classes, size=n).astype(np.int64)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, votes_np, labels_np, n_classes, str(tmp_path)), nprocs=2, join=True)
+    full = parallel.tallies([torch.from_numpy(v) for v in votes_np], torch.from_numpy(labels_np), n_classes).numpy()
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "tally_%d.npy" % rank))
+        assert np.array_equal(got, full)
+    cm, acc = parallel.split_tallies(torch.from_numpy(full), n_classes)
+    assert int(cm[0].sum()) == n
+    for i in range(3):
+        assert abs(float(acc[i]) - float(np.mean(votes_np[i] == labels_np))) < 1e-12

@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""Training entry point — flag surface of the reference's train.py (:19-94) on the MI355X build.
+
+What this build runs: the evaluation half of the reference's loop (train.py:263-294: every `n_test_interval` steps
+the test batches go through `net.test` / the fused sequence path, `acc_test.npy` and `parameters_{step}.pth` are
+written with the reference's state-dict keys).  What it does not run yet: the local-learning update
+(`net.learn` -> DCLLBase.train_dcll, reference dcll/pytorch_libdcll.py:690-718) and the non-spiking baseline CNN
+(ReferenceConvNetwork, networks/__init__.py:21-113, out of scope) — SURVEY.md 8(f)-2.  Asking for training steps
+therefore stops with a clear message instead of silently doing something else.
+"""
+import argparse
+import datetime
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+from snn_modulation_classification_amd.data.utils import to_one_hot
+from snn_modulation_classification_amd.dcll import pytorch_libdcll
+from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+import test_radio_ml as evaluation
+
+_NETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'snn_modulation_classification_amd', 'networks')
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='DCLL')
+    p.add_argument('--data', type=str, default='RadioML', choices=['MNIST', 'RadioML'], help='which data to use')
+    p.add_argument('--radio_ml_data_dir', type=str, default='2018.01', help='folder with the RadioML HDF5 file(s)')
+    p.add_argument('--min_snr', type=int, default=6, metavar='N', help='minimum SNR (inclusive)')
+    p.add_argument('--max_snr', type=int, default=30, metavar='N', help='maximum SNR (inclusive)')
+    p.add_argument('--per_h5_frac', type=float, default=0.5, metavar='N', help='fraction of each HDF5 file to use')
+    p.add_argument('--train_frac', type=float, default=0.9, metavar='N', help='train split')
+    p.add_argument('--network_spec', type=str, default=os.path.join(_NETS, 'radio_ml_conv.yaml'), metavar='S')
+    p.add_argument('--ref_network_spec', type=str, default=os.path.join(_NETS, 'radio_ml_conv_ref.yaml'), metavar='S')
+    p.add_argument('--just_ref', action='store_true', help='train only the non-spiking reference network')
+    p.add_argument('--I_resolution', type=int, default=128, metavar='N')
+    p.add_argument('--Q_resolution', type=int, default=128, metavar='N')
+    p.add_argument('--I_bounds', type=float, default=(-1, 1), nargs=2)
+    p.add_argument('--Q_bounds', type=float, default=(-1, 1), nargs=2)
+    p.add_argument('--restore_path', type=str, metavar='S', help='.pth state-dict to restore')
+    p.add_argument('--burnin', type=int, default=50, metavar='N')
+    p.add_argument('--batch_size', type=int, default=64, metavar='N')
+    p.add_argument('--batch_size_test', type=int, default=64, metavar='N')
+    p.add_argument('--n_steps', type=int, default=10000, metavar='N', help='number of steps to train')
+    p.add_argument('--no_save', type=evaluation.str2bool_like_reference, default=False, metavar='N')
+    p.add_argument('--seed', type=int, default=1, metavar='S')
+    p.add_argument('--n_test_interval', type=int, default=20, metavar='N')
+    p.add_argument('--n_test_samples', type=int, default=128, metavar='N')
+    p.add_argument('--n_iters', type=int, default=1024, metavar='N')
+    p.add_argument('--n_iters_test', type=int, default=1024, metavar='N')
+    p.add_argument('--optim_type', type=str, default='Adam', metavar='S')
+    p.add_argument('--loss_type', type=str, default='SmoothL1Loss', metavar='S')
+    p.add_argument('--learning_rates', type=float, default=[1e-6], nargs='+', metavar='N')
+    p.add_argument('--ref_lr', type=float, default=1e-3, metavar='N')
+    p.add_argument('--alpha', type=float, default=.92, metavar='N')
+    p.add_argument('--alphas', type=float, default=.85, metavar='N')
+    p.add_argument('--alpharp', type=float, default=.65, metavar='N')
+    p.add_argument('--arp', type=float, default=0, metavar='N')
+    p.add_argument('--random_tau', type=evaluation.str2bool_like_reference, default=True)
+    p.add_argument('--beta', type=float, default=.95, metavar='N')
+    p.add_argument('--lc_ampl', type=float, default=0.5, metavar='N')
+    p.add_argument('--netscale', type=float, default=1., metavar='N')
+    p.add_argument('--comment', type=str, default='')
+    p.add_argument('--output', type=str, default='results')
+    # additions of this build
+    p.add_argument('--synthetic', type=int, default=0, metavar='N', help='use N synthetic test windows')
+    p.add_argument('--eval_only', action='store_true', help='run the periodic evaluation once and save parameters')
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    if args.data != 'RadioML':
+        sys.exit('MNIST needs torchvision + a download (absent here); the MNIST geometry is covered by the tests.')
+    if args.just_ref:
+        sys.exit('ReferenceConvNetwork (plain CNN baseline) is outside the DCLL hot path and not part of this build.')
+    stamp = datetime.datetime.now().strftime('%b%d_%H-%M-%S')
+    out_dir = os.path.join(args.output, args.data, stamp)
+    os.makedirs(out_dir)
+    print('out dir: {}'.format(out_dir))
+
+    im_dims = (1, args.Q_resolution, args.I_resolution)
+    target_size = evaluation.TARGET_SIZE
+    opt = getattr(torch.optim, args.optim_type)
+    opt_param = {'betas': [0.0, args.beta], 'weight_decay': 10.0}
+    loss = getattr(torch.nn, args.loss_type)
+    convs = load_network_spec(args.network_spec)
+    net = ConvNetwork(args, im_dims, args.batch_size_test if args.eval_only else args.batch_size, convs, target_size,
+                      act=torch.nn.Sigmoid(), loss=loss, opt=opt, opt_param=opt_param,
+                      learning_rates=args.learning_rates, burnin=args.burnin)
+    if args.restore_path:
+        print('-' * 80)
+        if not os.path.isfile(args.restore_path):
+            print('ERROR: Cannot load `%s`.' % args.restore_path)
+            print('File does not exist! Aborting load...')
+        else:
+            net.load_state_dict(torch.load(args.restore_path))
+            print('Loaded the SNN model from `%s`.' % args.restore_path)
+        print('-' * 80)
+    net = net.to(pytorch_libdcll.device)
+    net.reset(True)
+
+    if not args.no_save:
+        with open(os.path.join(out_dir, 'args.txt'), 'w') as f:
+            f.write(str(args))
+        with open(os.path.join(out_dir, 'args.pkl'), 'wb') as f:
+            pickle.dump(vars(args), f)
+
+    if not args.eval_only:
+        sys.exit('The local-learning step (net.learn -> train_dcll, reference dcll/pytorch_libdcll.py:690-718) is not '
+                 'implemented on the HIP path yet (SURVEY.md 8(f)-2). Use --eval_only, or test_radio_ml.py.')
+
+    # the periodic evaluation block of the reference (train.py:263-303), once
+    n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
+    if not args.synthetic:
+        sys.exit('Reading RadioML HDF5 is not part of this build yet (SURVEY.md 8(f)-4); pass --synthetic N.')
+    batches = evaluation.synthetic_modulation_batches(args.synthetic, args.batch_size_test, args.max_snr,
+                                                      max(args.n_iters_test, 128), args.seed)[:n_test]
+    use_sequence = net.sequence_supported()
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    encoder = IQEncoder(args.I_resolution, args.Q_resolution, args.I_bounds, args.Q_bounds,
+                        device=pytorch_libdcll.device) if use_sequence else None
+    acc_test = np.empty([1, len(batches), len(net.dcll_slices)])
+    for i, (samples, labels) in enumerate(batches):
+        acc_test[0, i, :], _ = evaluation.evaluate_batch(net, args, samples, to_one_hot(labels, target_size), encoder,
+                                                         use_sequence)
+    print('[TEST]  Step {} \t Accuracy {} \t Ref {}'.format('00000', np.mean(acc_test[0], axis=0), 'N/A'))
+    if not args.no_save:
+        np.save(os.path.join(out_dir, 'acc_test.npy'), acc_test)
+        save_path = os.path.join(out_dir, 'parameters_{}.pth'.format(0))
+        torch.save(net.cpu().state_dict(), save_path)
+        net.to(pytorch_libdcll.device)
+        print('-' * 80)
+        print('Saved network parameters to `%s`.' % save_path)
+        print('-' * 80)
+    return out_dir
+
+
+if __name__ == '__main__':
+    main()
