@@ -115,7 +115,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="IQ windows per GPU per step (weak scaling)")
-    ap.add_argument("--cpu-windows", type=int, default=256, help="CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=2048, help="CPU baseline sample (0 = skip)")
+    ap.add_argument("--fuse-readout", type=int, default=0, help="1: readouts in the layer kernel's epilogue")
     a = ap.parse_args()
 
     rank, local_rank, world = parallel.init_process_group()
@@ -136,7 +137,7 @@ def main():
         cells = enc(iq, T_STEPS, t0=0)
         net.zero_states()
         net.reset()
-        res = net.test_sequence(cells, collect=False, profile=profile)
+        res = net.test_sequence(cells, collect=False, profile=profile, fuse_readout=bool(a.fuse_readout))
         tal = parallel.allreduce_tallies(parallel.tallies(res["vote"], labels, N_CLASSES))
         return cells, res, tal
 
@@ -168,6 +169,9 @@ def main():
     flop_per_launch = FLOP_C32_PER_SAMPLE_STEP * T_STEPS * B
     achieved = flop_per_launch / avg_c32_s / 1e12
     kernel_ms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in prof.items()}
+    if len(c32_ms) >= 2:        # the two 32->32 layers of a step (the output layer carries a second readout)
+        kernel_ms["lif_c32_layer1"] = float(np.mean(c32_ms[0::2]))
+        kernel_ms["lif_c32_layer2"] = float(np.mean(c32_ms[1::2]))
     cm, acc = parallel.split_tallies(tal, N_CLASSES)
 
     if rank == 0:

@@ -21,8 +21,8 @@ static float run(int B, int T, bool want_pv)
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
-        if (want_pv) hipLaunchKernelGGL((k_lif_seq_c32<true, 1, AB>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
-        else hipLaunchKernelGGL((k_lif_seq_c32<true, 0, AB>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        if (want_pv) hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0, AB>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        else hipLaunchKernelGGL((k_lif_seq_c32<true, 0, 0, AB>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;

@@ -111,10 +111,19 @@ int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W
  *   spk_out  (T,B,c_out,h*w/32) uint32  packed output spikes (same layout, feeds the next layer); may be NULL
  *   pv_out   (T,B,c_out,h,w) fp32       sigmoid(v) for the readout GEMM; may be NULL
  *   v_out    (T,B,c_out,h,w) fp32       debugging / parity only; may be NULL
+ *   fused local readout (n_ro = 24 or 48; 0 = none): ro_out (T,B,n_ro) = flatten(pv) . Wro^T + ro_b, i.e. i2o and,
+ *   stacked behind it on the output layer, output_ (:602-606), computed in the epilogue so that pv never leaves the
+ *   chip.  ro_Wp = the (n_ro, c_out*h*w) weight matrix re-laid-out by dcll_permute_readout; ro_b (n_ro).
  */
 int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                            const float *tau4, float *eps0, float *eps1, float *arp,
-                           uint32_t *spk_out, float *pv_out, float *v_out, int32_t T, int32_t B, void *stream);
+                           uint32_t *spk_out, float *pv_out, float *v_out,
+                           const float *ro_Wp, const float *ro_b, float *ro_out, int32_t n_ro,
+                           int32_t T, int32_t B, void *stream);
+
+/* Re-lay-out a readout matrix Wt (N, 32*16*16) [n][co][pix] for the fused epilogue of dcll_conv_lif_sequence:
+ * Wp[me][wq][n][lane][rr] with co = rr + 8*wq + 4*(lane>>5), pix = 32*me + (lane&31).  Wp has N*8192 floats. */
+int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void *stream);
 
 /*
  * First-layer sequence kernel (c_in==1): the input is exactly one spike per sample per step (iq2spiketrain,
@@ -127,7 +136,7 @@ int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, 
 
 /*
  * Local readout for many rows at once: out[r, n] = sum_k pv[r,k]*Wt[n,k] + bias[n]   (i2o / output_, :602-606),
- * fp32 MFMA.  rows = T*B, K = c_out*ph*pw, N = target (<= 32).
+ * fp32 MFMA.  rows = T*B, K = c_out*ph*pw, N = rows of Wt (e.g. i2o and output_ stacked: 48).
  */
 int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out,
                  int64_t rows, int32_t K, int32_t N, void *stream);

@@ -294,6 +294,74 @@ __global__ __launch_bounds__(256) void k_readout(const float *__restrict__ pv, c
     }
 }
 
+// Fast path of the readout GEMM for K % 32 == 0 and 16-byte aligned rows: 128 rows x (32*NT) columns per workgroup
+// (NT = 2 serves i2o and output_ of the output layer in ONE pass over pv), float4 global loads, the next K-chunk is
+// fetched into registers while the MFMAs of the current one run (register double buffer).
+template <int NT>
+__global__ __launch_bounds__(256) void k_readout_v4(const float *__restrict__ pv, const float *__restrict__ Wt,
+                                                     const float *__restrict__ bias, float *__restrict__ out,
+                                                     long rows, int K, int N)
+{
+    __shared__ float sA[RO_ROWS * RO_LD];
+    __shared__ float sB[NT * 32 * RO_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long row0 = (long)blockIdx.x * RO_ROWS;
+    const int kq = (tid & 7) * 4, rsub = tid >> 3;          // 8 threads x float4 = one 32-float K-chunk of a row
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    f32x4 ra[4], rb[NT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long gr = row0 + rsub + 32 * i;
+            ra[i] = gr < rows ? *(const f32x4 *)(pv + gr * K + k0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int nn = rsub + 32 * t;
+            rb[t] = nn < N ? *(const f32x4 *)(Wt + (long)nn * K + k0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += RO_KC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sA[(rsub + 32 * i) * RO_LD + kq + e] = ra[i][e];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sB[(rsub + 32 * t) * RO_LD + kq + e] = rb[t][e];
+        __syncthreads();
+        if (k0 + RO_KC < K) fetch(k0 + RO_KC);
+        const float *a = sA + (wave * 32 + (lane & 31)) * RO_LD + (lane >> 5);
+        const float *bb = sB + (lane & 31) * RO_LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < RO_KC / 2; ++kk) {
+            const float av = a[2 * kk];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[t * 32 * RO_LD + 2 * kk], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = t * 32 + (lane & 31);
+        if (n < N) {
+            const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long gr = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gr < rows) out[gr * N + n] = acc[t][r] + bn;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // argmax per (t,b) (first maximum, like torch.argmax) and vote per b (Counter.most_common(1): ties -> first seen)
 // ------------------------------------------------------------------------------------------------------------
@@ -468,17 +536,45 @@ constexpr int SLOT_FLOATS = 16 * 64;
 
 // ABLATE is a diagnostic knob for experiments/ablate_c32.hip only (bit0: no epilogue, bit1: no trace update,
 // bit2: no accumulator hand-off); every product launch uses ABLATE = 0.
-template <bool REFRACTORY, int OUT = 3, int ABLATE = 0>      // OUT bit0: write pv, bit1: write v
+// one DPP step of a wave-wide sum: v + (v moved by CTRL); lanes without a source add 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 64 lanes; the total is valid in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);      // row_mirror      -> every lane holds its 16-lane row sum
+    v = dpp_add<0x142, 0xA>(v);      // row_bcast15     -> rows 1,3 += previous row
+    v = dpp_add<0x143, 0xC>(v);      // row_bcast31     -> rows 2,3 += row 1
+    return v;
+}
+
+// NRO > 0 fuses the local readout(s) into the epilogue: logits[t][b][n] = sum_{co,pix} pv * Wro[n][co][pix] + b[n]
+// (i2o, and output_ stacked behind it on the last layer: dcll/pytorch_libdcll.py:602-606) with Wro pre-permuted to
+// the epilogue's register layout (dcll_permute_readout); pv then never travels through HBM.
+template <bool REFRACTORY, int OUT = 3, int NRO = 0, int ABLATE = 0>      // OUT bit0: write pv, bit1: write v
 __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
                                                       float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
-                                                      float *__restrict__ pv_out, float *__restrict__ v_out, int T,
-                                                      int B, float alpharp, float wrp)
+                                                      float *__restrict__ pv_out, float *__restrict__ v_out,
+                                                      const float *__restrict__ ro_Wp, const float *__restrict__ ro_b,
+                                                      float *__restrict__ ro_out, int T, int B, float alpharp,
+                                                      float wrp)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * IMG_FLOATS + NWAVE * 2 * SLOT_FLOATS + 32];
+    constexpr int NROA = NRO > 0 ? NRO : 1;
+    __shared__ __attribute__((aligned(16))) float lds[2 * IMG_FLOATS + NWAVE * 2 * SLOT_FLOATS + 32 + 2 * NWAVE * NRO];
     float *slots = lds + 2 * IMG_FLOATS;
     float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
+    float *ropart = sbias + 32;                 // [step parity][wave][NRO] lane-reduced partial logits
+    float racc[NROA];
+#pragma unroll
+    for (int n = 0; n < NROA; ++n) racc[n] = 0.0f;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, kept scalar
     const int wq = w & 3, wpar = w >> 2;                          // epilogue quad / tile parity owned by this wave
@@ -565,7 +661,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
         for (int k = 0; k < 49; ++k) asm volatile("" ::"v"(wf[cp][k]));
     __syncthreads();
 
-    const int nstage = 8 * T + 9;
+    const int nstage = 8 * T + (NRO > 0 ? 17 : 9);
     for (int g = 0; g < nstage; ++g) {
         // ---- (1) epilogue share: quad wq of tile qe = g - 8 (finished by wave 7 in the previous stage) ----
         const int qe = g - 8;
@@ -575,6 +671,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
             const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
             const long oelem = obase * 256 + 32 * me + j;                     // + rr*256
             float *pvp = pv_out + oelem, *vp = v_out + oelem;
+            float pvq[4];
             auto quad = [&](float (&ar)[4]) {
                 uint32_t myword = 0;
 #pragma unroll
@@ -586,7 +683,8 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                     unsigned long long mk = __ballot(s);
                     uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
                     myword = (j == rr) ? mine : myword;
-                    if (OUT & 1) pvp[rr * 256] = sigmoidf_dev(v);
+                    if ((OUT & 1) || NRO > 0) pvq[rr] = sigmoidf_dev(v);
+                    if (OUT & 1) pvp[rr * 256] = pvq[rr];
                     if (OUT & 2) vp[rr * 256] = v;
                 }
                 if (spk_out && j < 4) spk_out[(obase + j) * 8 + me] = myword;
@@ -596,6 +694,47 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
             case 1: quad(arp[1]); break;
             case 2: quad(arp[2]); break;
             default: quad(arp[3]); break;
+            }
+            if (NRO > 0) {
+                // my 4 pv values against the matching 4 readout weights of every class (16 B per lane per class,
+                // 1 KB contiguous per wave-load, L2 resident); partial sums stay in registers over my 4 tiles of a
+                // step.  Loads go out in batches of RO_CH before their FMAs (order pinned) so that one L2 round trip
+                // is paid per batch, not per class.
+                constexpr int RO_CH = (NRO > 24) ? 6 : 12;
+                const f32x4 *wp = (const f32x4 *)ro_Wp + (long)((me * 4 + wq) * NRO) * 64 + lane;
+#pragma unroll
+                for (int n0 = 0; n0 < NRO; n0 += RO_CH) {
+                    f32x4 wb[RO_CH];
+#pragma unroll
+                    for (int k = 0; k < RO_CH; ++k) wb[k] = wp[(n0 + k) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < RO_CH; ++k)
+                        racc[n0 + k] = __builtin_fmaf(pvq[0], wb[k][0], __builtin_fmaf(pvq[1], wb[k][1],
+                                       __builtin_fmaf(pvq[2], wb[k][2], __builtin_fmaf(pvq[3], wb[k][3], racc[n0 + k]))));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((me >> 1) == 3) {       // my last tile of step te: reduce over lanes, park in LDS, restart
+                    float *dst = ropart + ((te & 1) * NWAVE + w) * NRO;
+#pragma unroll
+                    for (int n = 0; n < NRO; ++n) {
+                        const float tot = wave_sum_to_lane63(racc[n]);
+                        if (lane == 63) dst[n] = tot;
+                        racc[n] = 0.0f;
+                    }
+                }
+            }
+        }
+        if (NRO > 0) {
+            // all 8 partials of step tc were parked by the end of stage 8*tc + 15: combine + bias -> logits
+            const int gc = g - 16;
+            if (gc >= 0 && (gc & 7) == 0 && (gc >> 3) < T && w == ((gc >> 3) & 7) && lane < NRO) {
+                const int tc = gc >> 3;
+                const float *src = ropart + ((tc & 1) * NWAVE) * NRO + lane;
+                float tot = ro_b[lane];
+#pragma unroll
+                for (int k = 0; k < NWAVE; ++k) tot += src[k * NRO];
+                ro_out[((long)tc * B + b) * NRO + lane] = tot;
             }
         }
         const int q = g - w;
@@ -695,6 +834,21 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
     }
 }
 
+// readout weights (N, 32*256) [n][co][pix]  ->  epilogue layout [me][wq][n][lane][rr]:
+//   co = rr + 8*wq + 4*(lane>>5), pix = 32*me + (lane&31)
+__global__ void k_permute_readout(const float *__restrict__ Wt, float *__restrict__ Wp, int N)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 8192) return;
+    int rr = i & 3, lane = (i >> 2) & 63;
+    int r = i >> 8;
+    int n = r % N;
+    r /= N;
+    int wq = r & 3, me = r >> 2;
+    int co = rr + 8 * wq + 4 * (lane >> 5), pix = 32 * me + (lane & 31);
+    Wp[i] = Wt[(long)n * 8192 + co * 256 + pix];
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
@@ -704,8 +858,15 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
                           hipStream_t st)
 {
     if (rows == 0 || N == 0) return DCLL_OK;
-    dim3 grid(nblk(rows, RO_ROWS), (N + 31) / 32);
-    hipLaunchKernelGGL(k_readout, grid, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0;
+    if (fast && N <= 32) {
+        hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    } else if (fast) {
+        hipLaunchKernelGGL(k_readout_v4<2>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    } else {
+        dim3 grid(nblk(rows, RO_ROWS), (N + 31) / 32);
+        hipLaunchKernelGGL(k_readout, grid, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    }
     HIP_CHECK_LAUNCH("k_readout");
     return DCLL_OK;
 }
@@ -802,37 +963,59 @@ static int check_seq_geometry(const dcll_conv_desc *d, int c_in, const char *who
     return DCLL_OK;
 }
 
+extern "C" int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void *stream)
+{
+    if (!Wt || !Wp || N < 1) return fail(DCLL_ERR_INVALID, "dcll_permute_readout: bad argument");
+    hipLaunchKernelGGL(k_permute_readout, dim3(nblk((long)N * 8192, 256)), dim3(256), 0, (hipStream_t)stream, Wt, Wp, N);
+    HIP_CHECK_LAUNCH("k_permute_readout");
+    return DCLL_OK;
+}
+
+template <bool R, int NRO>
+static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, const float *W, const float *b,
+                       const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
+                       float *v_out, const float *ro_Wp, const float *ro_b, float *ro_out, int T, float alpharp,
+                       float wrp)
+{
+#define DCLL_LAUNCH_C32(O)                                                                                             \
+    hipLaunchKernelGGL((k_lif_seq_c32<R, O, NRO>), dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp,     \
+                       spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out, T, B, alpharp, wrp)
+    switch (out) {
+    case 0: DCLL_LAUNCH_C32(0); break;
+    case 1: DCLL_LAUNCH_C32(1); break;
+    case 2: DCLL_LAUNCH_C32(2); break;
+    default: DCLL_LAUNCH_C32(3); break;
+    }
+#undef DCLL_LAUNCH_C32
+}
+
 extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                                       const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
-                                      float *pv_out, float *v_out, int32_t T, int32_t B, void *stream)
+                                      float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
+                                      float *ro_out, int32_t n_ro, int32_t T, int32_t B, void *stream)
 {
     int rc = check_seq_geometry(d, 32, "dcll_conv_lif_sequence");
     if (rc) return rc;
     if (!spk_in || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: refractory layer needs arp");
     if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: negative size");
+    if (n_ro != 0 && n_ro != 24 && n_ro != 48)
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout supports 24 or 48 rows (target 24)");
+    if (n_ro && (!ro_Wp || !ro_b || !ro_out)) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: fused readout needs ro_Wp, ro_b, ro_out");
     if (T == 0 || B == 0) return DCLL_OK;
     hipStream_t st = (hipStream_t)stream;
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
-#define DCLL_LAUNCH_C32(R, O)                                                                                         \
-    hipLaunchKernelGGL((k_lif_seq_c32<R, O>), dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, \
-                       pv_out, v_out, T, B, d->alpharp, d->wrp)
+#define DCLL_ARGS out, B, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out, T, d->alpharp, d->wrp
     if (d->refractory) {
-        switch (out) {
-        case 0: DCLL_LAUNCH_C32(true, 0); break;
-        case 1: DCLL_LAUNCH_C32(true, 1); break;
-        case 2: DCLL_LAUNCH_C32(true, 2); break;
-        default: DCLL_LAUNCH_C32(true, 3); break;
-        }
+        if (n_ro == 0) launch_c32<true, 0>(DCLL_ARGS);
+        else if (n_ro == 24) launch_c32<true, 24>(DCLL_ARGS);
+        else launch_c32<true, 48>(DCLL_ARGS);
     } else {
-        switch (out) {
-        case 0: DCLL_LAUNCH_C32(false, 0); break;
-        case 1: DCLL_LAUNCH_C32(false, 1); break;
-        case 2: DCLL_LAUNCH_C32(false, 2); break;
-        default: DCLL_LAUNCH_C32(false, 3); break;
-        }
+        if (n_ro == 0) launch_c32<false, 0>(DCLL_ARGS);
+        else if (n_ro == 24) launch_c32<false, 24>(DCLL_ARGS);
+        else launch_c32<false, 48>(DCLL_ARGS);
     }
-#undef DCLL_LAUNCH_C32
+#undef DCLL_ARGS
     HIP_CHECK_LAUNCH("k_lif_seq_c32");
     return DCLL_OK;
 }

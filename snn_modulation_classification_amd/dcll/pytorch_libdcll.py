@@ -299,9 +299,40 @@ class Conv2dDCLLlayer(nn.Module):
             return 'packed'
         return None
 
-    def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None):
+    def stacked_readout(self):
+        """(weight (24|48, K), bias) of i2o, with output_ stacked behind it on the output layer — one readout GEMM
+        then serves both (reference :602-606).  Cached until a weight tensor changes."""
+        mods = [self.i2o] + ([self.output_] if self.output_layer else [])
+        if len(mods) == 1:
+            return self.i2o.weight, self.i2o.bias
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        cache = getattr(self, '_stack_cache', None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, torch.cat([m.weight.detach() for m in mods], 0).contiguous(),
+                         torch.cat([m.bias.detach() for m in mods], 0).contiguous())
+            self._stack_cache = cache
+        return cache[1], cache[2]
+
+    def fused_readout_weights(self):
+        """(permuted weights, bias) of the readout(s) for the fused epilogue of the 'packed' sequence kernel:
+        i2o, with output_ stacked behind it on the output layer.  Cached until a weight tensor changes."""
+        mods = [self.i2o] + ([self.output_] if self.output_layer else [])
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        cache = getattr(self, '_ro_cache', None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                Wt = torch.cat([m.weight.detach() for m in mods], 0)
+                bias = torch.cat([m.bias.detach() for m in mods], 0).contiguous()
+                cache = (key, ops.permute_readout(Wt), bias)
+            self._ro_cache = cache
+        return cache[1], cache[2]
+
+    def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False):
         """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,8) int32 ('packed').
-        Neuron state is read from / written back to self.i2h.state.  -> (packed spikes, pv (T,B,C,H,W))."""
+        Neuron state is read from / written back to self.i2h.state.
+        -> (packed spikes, pv (T,B,C,H,W) or None, logits (T,B,24|48) or None).  With fuse_readout ('packed' only)
+        the readout(s) are computed in the kernel's epilogue and pv is not materialised."""
         i2h = self.i2h
         if i2h.state is None or i2h.state.eps0.shape[0] != B:
             i2h.init_state(B, self.im_dims)
@@ -309,11 +340,20 @@ class Conv2dDCLLlayer(nn.Module):
         tau4 = i2h.tau_per_channel()
         st = i2h.state
         arp = st.arp if len(st) > 2 else None
-        fn = ops.conv_lif_sequence_cells if kind == 'cells' else ops.conv_lif_sequence
         with torch.no_grad():
-            spk, pv, _ = fn(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp, T, B,
-                            want_spikes=want_spikes, out=buffers)
-        return spk, pv
+            if kind == 'cells':
+                spk, pv, _ = ops.conv_lif_sequence_cells(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,
+                                                         T, B, want_spikes=want_spikes, out=buffers)
+                return spk, pv, None
+            if fuse_readout:
+                Wp, rb = self.fused_readout_weights()
+                spk, _, _, logits = ops.conv_lif_sequence(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,
+                                                          T, B, want_spikes=want_spikes, want_pv=False, out=buffers,
+                                                          ro_Wp=Wp, ro_b=rb)
+                return spk, None, logits
+            spk, pv, _ = ops.conv_lif_sequence(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp, T, B,
+                                               want_spikes=want_spikes, out=buffers)
+        return spk, pv, None
 
 
 # ---------------------------------------------------------------------------------------------------------------

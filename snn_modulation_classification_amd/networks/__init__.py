@@ -98,8 +98,8 @@ class ConvNetwork(torch.nn.Module):
             self._seq_buffers[key] = dict(
                 spk=[torch.empty((T, B, C, H * W // 32), device=dev, dtype=torch.int32) for _ in range(2)],
                 pv=torch.empty((T, B, C, H, W), device=dev, dtype=torch.float32),
-                logits=[torch.empty((T * B, self.target_size), device=dev, dtype=torch.float32)
-                        for _ in range(self.num_layers + 1)])
+                ro=[torch.empty((T, B, self.target_size * (2 if i == self.num_layers - 1 else 1)), device=dev,
+                                dtype=torch.float32) for i in range(self.num_layers)])
         return self._seq_buffers[key]
 
     def zero_states(self):
@@ -109,10 +109,13 @@ class ConvNetwork(torch.nn.Module):
                 t.zero_()
 
     @torch.no_grad()
-    def test_sequence(self, cells, collect=True, profile=None):
+    def test_sequence(self, cells, collect=True, profile=None, fuse_readout=False):
         """Equivalent of `for t in range(T): net.test(x[t])` for input given as cell indices (T,B) int32 on device
         (one input spike per sample per step, what iq2spiketrain produces).  Fills every slice's `clout`.
 
+        `fuse_readout`: compute the readouts in the layer kernels' epilogue instead of materialising pv + a GEMM.
+        Measured slower on MI355X (re-streaming the 786 KB readout matrix per sample-step through L2 costs more than
+        the pv round trip through HBM: 124 vs 113 ms per layer launch at B=4096), hence off by default.
         `profile`: optional dict; (start, end) torch.cuda.Event pairs of every launch are appended under
         'lif_c1' / 'lif_c32' / 'readout' / 'vote' (events live on the current stream = the launch stream).
 
@@ -138,17 +141,30 @@ class ConvNetwork(torch.nn.Module):
         for i, s in enumerate(self.dcll_slices):
             L = s.dclllayer
             last = (i == self.num_layers - 1)
-            spk, pv = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B,
-                            'cells' if i == 0 else 'packed', want_spikes=not last,
-                            buffers=dict(spk=buf['spk'][i & 1], pv=buf['pv']))
-            pv2d = pv.reshape(T * B, -1)
-            p = timed('readout', ops.readout, pv2d, L.i2o.weight, L.i2o.bias, out=buf['logits'][i]).reshape(T, B, -1)
-            logits = p
-            if last:
-                logits = timed('readout', ops.readout, pv2d, L.output_.weight, L.output_.bias,
-                               out=buf['logits'][i + 1]).reshape(T, B, -1)
-                res['o'] = logits
-            clout, vote = timed('vote', ops.argmax_vote, logits)
+            fused = fuse_readout and i > 0
+            spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B,
+                                'cells' if i == 0 else 'packed', want_spikes=not last,
+                                buffers=dict(spk=buf['spk'][i & 1], pv=buf['pv'], ro=buf['ro'][i]),
+                                fuse_readout=fused)
+            if fused:
+                # readout(s) came out of the layer kernel's epilogue: (T,B,24) or, on the output layer, (T,B,48)
+                p = ro[..., :self.target_size]
+                logits = p
+                if last:
+                    logits = ro[..., self.target_size:]
+                    res['o'] = logits
+            else:
+                # readout GEMM over all (t, b) rows; on the output layer i2o and output_ share ONE pass over pv
+                pv2d = pv.reshape(T * B, -1)
+                Wt, bias = L.stacked_readout()
+                ro = timed('readout', ops.readout, pv2d, Wt, bias, out=buf['ro'][i].reshape(T * B, -1))
+                ro = ro.reshape(T, B, -1)
+                p = ro[..., :self.target_size]
+                logits = p
+                if last:
+                    logits = ro[..., self.target_size:]
+                    res['o'] = logits
+            clout, vote = timed('vote', ops.argmax_vote, logits.contiguous())
             res['logits'].append(p)
             res['clout'].append(clout)
             res['vote'].append(vote)

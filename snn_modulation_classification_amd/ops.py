@@ -75,9 +75,21 @@ def dense_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, 
     return s, p, pv, v
 
 
+def permute_readout(Wt):
+    """(N, 8192) readout matrix -> the fused epilogue's layout (dcll_permute_readout)."""
+    Wt = Wt.contiguous()
+    N, K = Wt.shape
+    if K != 8192:
+        raise ValueError("permute_readout: expected (N, 32*16*16) weights")
+    Wp = torch.empty(N * K, device=Wt.device, dtype=torch.float32)
+    check(_lib.get().dcll_permute_readout(ptr(Wt), ptr(Wp), N, stream_ptr()), "dcll_permute_readout")
+    return Wp
+
+
 def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_pv=True,
-                      want_v=False, out=None):
-    """All T steps of one 32->32 layer in one launch (k_lif_seq_c32). spk_in: (T,B,32,8) int32 packed."""
+                      want_v=False, out=None, ro_Wp=None, ro_b=None):
+    """All T steps of one 32->32 layer in one launch (k_lif_seq_c32). spk_in: (T,B,32,8) int32 packed.
+    With ro_Wp / ro_b the local readout(s) are fused: returns (spk, pv, v, logits (T,B,n_ro))."""
     dev = W.device
     out = out or {}
     words = desc.h * desc.w // 32
@@ -88,9 +100,18 @@ def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spik
     if want_pv and pv is None:
         pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
     v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+    n_ro, logits = 0, None
+    if ro_Wp is not None:
+        n_ro = ro_b.numel()
+        logits = out.get("ro")
+        if logits is None:
+            logits = torch.empty((T, B, n_ro), device=dev, dtype=torch.float32)
     rc = _lib.get().dcll_conv_lif_sequence(ctypes.byref(desc), ptr(spk_in), ptr(W), ptr(b), ptr(tau4), ptr(eps0),
-                                           ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), T, B, stream_ptr())
+                                           ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), ptr(ro_Wp), ptr(ro_b),
+                                           ptr(logits), n_ro, T, B, stream_ptr())
     check(rc, "dcll_conv_lif_sequence")
+    if ro_Wp is not None:
+        return spk, pv, v, logits
     return spk, pv, v
 
 

@@ -289,3 +289,46 @@ def test_error_conventions(dev):
         ops.conv_out_shape(d2)
     with pytest.raises(_lib.DCLLHipError):
         ops.readout(torch.zeros(2, 4), torch.zeros(3, 4), None)      # CPU tensors: no CPU fallback
+
+
+@pytest.mark.parametrize("n_ro,wrp", [(24, 1.0), (48, 1.0), (24, 0.0)])
+def test_sequence_c32_fused_readout(dev, n_ro, wrp):
+    """Readout fused into the epilogue (pv never leaves the chip) == readout GEMM over the materialised pv, and the
+    spikes / state are unchanged by the fusion."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(21)
+    T, B = 19, 3
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
+    Wro = rng.uniform(-.0055, .0055, size=(n_ro, 8192)).astype(np.float32)
+    bro = rng.uniform(-.0055, .0055, size=(n_ro,)).astype(np.float32)
+    x = (rng.uniform(size=(T, B, 32, 256)) < 0.1).astype(np.float32)
+    d = ops.make_conv_desc(32, 32, (16, 16), 7, 3, 1, 24, n_ro == 48, True, wrp)
+    spk_in = ops.pack_spikes(cu(x, dev))
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    st = lambda: [torch.zeros((B, 32, 16, 16), device=dev) for _ in range(3)]
+    sa, sb = st(), st()
+    spk_a, pv_a, _ = ops.conv_lif_sequence(d, spk_in, cu(W, dev), cu(b, dev), tau4, *sa, T, B)
+    ref = ops.readout(pv_a.reshape(T * B, -1), cu(Wro, dev), cu(bro, dev)).reshape(T, B, n_ro)
+    Wp = ops.permute_readout(cu(Wro, dev))
+    spk_b, pv_b, _, logits = ops.conv_lif_sequence(d, spk_in, cu(W, dev), cu(b, dev), tau4, *sb, T, B,
+                                                   want_pv=False, ro_Wp=Wp, ro_b=cu(bro, dev))
+    assert pv_b is None and logits.shape == (T, B, n_ro)
+    assert torch.equal(spk_a, spk_b)
+    for u, v in zip(sa, sb):
+        assert torch.equal(u, v)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref.cpu().numpy(), atol=1e-5, rtol=0)
+    exact = (pv_a.reshape(T, B, -1).cpu().numpy().astype(np.float64) @ Wro.astype(np.float64).T + bro)
+    np.testing.assert_allclose(logits.cpu().numpy(), exact, atol=LOGIT_TOL / 10, rtol=0)
+
+
+@pytest.mark.parametrize("rows,K,N", [(300, 8192, 48), (129, 64, 33), (1000, 8192, 24), (7, 32, 64)])
+def test_readout_gemm_fast_path(dev, rows, K, N):
+    """k_readout_v4 (K % 32 == 0): float4 loads, register double buffer, up to 64 stacked readout rows."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(1)
+    pv = rng.uniform(0, 1, size=(rows, K)).astype(np.float32)
+    Wt = rng.uniform(-.01, .01, size=(N, K)).astype(np.float32)
+    b = rng.uniform(-.01, .01, size=(N,)).astype(np.float32)
+    out = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev)).cpu().numpy()
+    ref = (pv.astype(np.float64) @ Wt.astype(np.float64).T + b).astype(np.float32)
+    np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
