@@ -603,13 +603,13 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
 
     // one trace element update: x*tau_s by lane mask -> eps0 (register) and eps1 (src image -> dst image);
     // dcll/pytorch_libdcll.py:493-494, every op rounded separately.
-    auto trace_elem = [&](unsigned long long mask, float &e0r, const float *src, float *dst, float ta, float tm,
-                          float tas, float ts) {
+    auto trace_elem = [&](unsigned long long mask, float &e0r, float e1, float *dst, float ta, float tm, float tas,
+                          float ts) {
         float a;                                    // x * tau_s with x in {0,1}: exact select
         asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(a) : "v"(ts), "s"(mask));
         float bb = tas * e0r;
         e0r = a + bb;
-        float cc = ta * (*src);
+        float cc = ta * e1;
         float dd = e0r * tm;
         *dst = cc + dd;
     };
@@ -756,13 +756,14 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                 }
                 const float *src = img + ioff + c * CHF;
                 float *dst = lds + ((t + 1) & 1) * IMG_FLOATS + ioff + c * CHF;
+                const float s0 = src[0], s1 = src[4 * ROWF], s2 = src[8 * ROWF], s3 = src[12 * ROWF];
                 switch (c) {            // wave-uniform: keeps e0[] statically indexed (registers)
 #define DCLL_TRACE_CASE(C)                                                                \
     case C:                                                                               \
-        trace_elem(w0, e0[C * 4 + 0], src + 0 * 4 * ROWF, dst + 0 * 4 * ROWF, ta, tm, tas, ts); \
-        trace_elem(w1, e0[C * 4 + 1], src + 1 * 4 * ROWF, dst + 1 * 4 * ROWF, ta, tm, tas, ts); \
-        trace_elem(w2, e0[C * 4 + 2], src + 2 * 4 * ROWF, dst + 2 * 4 * ROWF, ta, tm, tas, ts); \
-        trace_elem(w3, e0[C * 4 + 3], src + 3 * 4 * ROWF, dst + 3 * 4 * ROWF, ta, tm, tas, ts); \
+        trace_elem(w0, e0[C * 4 + 0], s0, dst + 0 * 4 * ROWF, ta, tm, tas, ts);           \
+        trace_elem(w1, e0[C * 4 + 1], s1, dst + 1 * 4 * ROWF, ta, tm, tas, ts);           \
+        trace_elem(w2, e0[C * 4 + 2], s2, dst + 2 * 4 * ROWF, ta, tm, tas, ts);           \
+        trace_elem(w3, e0[C * 4 + 3], s3, dst + 3 * 4 * ROWF, ta, tm, tas, ts);           \
         break;
                     DCLL_TRACE_CASE(0)
                     DCLL_TRACE_CASE(1)
@@ -786,6 +787,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
             }
             // 14 rows of 7 taps (row = (cp, ky)); the B fragments of row r+1 are fetched from LDS before the MFMAs of
             // row r are issued (explicit double buffer, order pinned with sched_barrier).
+            // 14 rows of 7 taps (row = (cp, ky)); the B fragments of row r+1 are fetched from LDS before the MFMAs of
+            // row r are issued (explicit double buffer, order pinned with sched_barrier).
+            // (Tried: four hand-made bases 256 dwords apart to spare the ~22 v_add per wave-stage that ds_read2_b32's
+            //  8-bit offsets cost — measured 20 % slower, the compiler's own pairing is better.)
             const float *bp = img + bbase + m * 2 * ROWF;
             float bq[2][7];
 #pragma unroll
