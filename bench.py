@@ -122,8 +122,8 @@ def main():
     rank, local_rank, world = parallel.init_process_group()
     assert world == a.gpus, "launch with torchrun --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", parallel.local_device(local_rank))
+    torch.cuda.set_device(dev)
     B = a.batch
 
     net, convs = build_net(B, dev)

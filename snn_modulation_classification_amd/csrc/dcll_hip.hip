@@ -239,6 +239,128 @@ __global__ void k_dense_lif(dcll_dense_desc d, const float *__restrict__ eps1, c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// backward of one Conv2dDCLLlayer step for local learning (DCLLBase.train_dcll, dcll/pytorch_libdcll.py:690-718).
+// Only i2h.weight / i2h.bias (through pv -> i2o -> loss, and optionally through pv / pvmem directly) and
+// output_.weight / output_.bias receive gradients: i2o is frozen (:570-571), the neuron state is detached (:504-507),
+// spikes come from `>` and output_ sees flatten.detach() (:606).  Gradients are not bit-pinned (fp32 sums).
+// ------------------------------------------------------------------------------------------------------------
+// g_v_full[b,co,y,x] = [this element is its pool window's (first) maximum of pv] * (g_pv[b,co,py,px] +
+//                      sum_n g_p[b,n] * i2o_W[n, flat(co,py,px)]) * pv*(1-pv)  +  g_v[b,co,y,x]
+__global__ void k_bwd_dv(dcll_conv_desc d, int ch, int cw, int ph, int pw, const float *__restrict__ v,
+                         const float *__restrict__ g_p, const float *__restrict__ g_pv, const float *__restrict__ g_v,
+                         const float *__restrict__ i2o_W, float *__restrict__ gvf, long n)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x = (int)(i % cw);
+    long r = i / cw;
+    int y = (int)(r % ch);
+    r /= ch;
+    int co = (int)(r % d.c_out);
+    long b = r / d.c_out;
+    const int pph = (d.pool_h - 1) / 2, ppw = (d.pool_w - 1) / 2;
+    const int py = (y + pph) / d.pool_h, px = (x + ppw) / d.pool_w;
+    float g = 0.0f;
+    const float pv = sigmoidf_dev(v[i]);
+    if (py < ph && px < pw) {
+        // am I the first maximum of my window (row-major scan, strict >, like MaxPool2d's forward)?
+        const float *vp = v + (b * d.c_out + co) * (long)ch * cw;
+        const int y0 = py * d.pool_h - pph, x0 = px * d.pool_w - ppw;
+        bool is_max = true;
+        for (int dy = 0; dy < d.pool_h && is_max; ++dy)
+            for (int dx = 0; dx < d.pool_w; ++dx) {
+                int yy = y0 + dy, xx = x0 + dx;
+                if (yy < 0 || yy >= ch || xx < 0 || xx >= cw || (yy == y && xx == x)) continue;
+                float q = sigmoidf_dev(vp[yy * cw + xx]);
+                bool before = (yy < y) || (yy == y && xx < x);
+                if (q > pv || (before && q == pv)) { is_max = false; break; }
+            }
+        if (is_max) {
+            const long pidx = ((b * d.c_out + co) * ph + py) * pw + px;
+            if (g_pv) g = g_pv[pidx];
+            if (g_p) {
+                const int K = d.c_out * ph * pw;
+                const int k = (co * ph + py) * pw + px;
+                float acc = 0.0f;
+                for (int nn = 0; nn < d.target; ++nn) acc = __builtin_fmaf(g_p[b * d.target + nn], i2o_W[(long)nn * K + k], acc);
+                g += acc;
+            }
+        }
+    }
+    float out = g * pv * (1.0f - pv);
+    if (g_v) out += g_v[i];
+    gvf[i] = out;
+}
+
+// dW[co,ci,ky,kx] = sum_{b,y,x} gvf[b,co,y,x] * eps1[b,ci,y+ky-pad,x+kx-pad];  db[co] = sum gvf[b,co,:,:]
+// one workgroup per (co, ci); thread = conv output position (strided), per-thread tap accumulators, LDS tree at the end.
+constexpr int WG_MAXTAPS = 64;
+__global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int cw, const float *__restrict__ gvf,
+                                                    const float *__restrict__ eps1, float *__restrict__ dW,
+                                                    float *__restrict__ db, int B)
+{
+    extern __shared__ float sm[];
+    const int co = blockIdx.x / d.c_in, ci = blockIdx.x % d.c_in;
+    const int HP = d.h + 2 * d.pad_h, WP = d.w + 2 * d.pad_w, ntap = d.kh * d.kw, npos = ch * cw;
+    float *e = sm;                    // zero-padded eps1 plane of (b, ci)
+    float *red = sm + HP * WP;        // 256 floats for reductions
+    float acc[WG_MAXTAPS];
+#pragma unroll
+    for (int t = 0; t < WG_MAXTAPS; ++t) acc[t] = 0.0f;
+    float accb = 0.0f;
+    for (int i = threadIdx.x; i < HP * WP; i += 256) e[i] = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        __syncthreads();
+        const float *ep = eps1 + ((long)b * d.c_in + ci) * d.h * d.w;
+        for (int i = threadIdx.x; i < d.h * d.w; i += 256) e[(i / d.w + d.pad_h) * WP + (i % d.w) + d.pad_w] = ep[i];
+        __syncthreads();
+        const float *gp = gvf + ((long)b * d.c_out + co) * npos;
+        for (int pos = threadIdx.x; pos < npos; pos += 256) {
+            const float g = gp[pos];
+            accb += g;
+            const float *eb = e + (pos / cw) * WP + (pos % cw);
+#pragma unroll
+            for (int t = 0; t < WG_MAXTAPS; ++t)
+                if (t < ntap) acc[t] = __builtin_fmaf(g, eb[(t / d.kw) * WP + (t % d.kw)], acc[t]);
+        }
+    }
+    // reduce every tap over the 256 threads
+    for (int t = 0; t <= ntap; ++t) {
+        float val = accb;           // t == ntap: the bias gradient
+#pragma unroll
+        for (int u = 0; u < WG_MAXTAPS; ++u) val = (u == t && t < ntap) ? acc[u] : val;
+        __syncthreads();
+        red[threadIdx.x] = val;
+        __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) {
+            if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (t < ntap) dW[((long)co * d.c_in + ci) * ntap + t] = red[0];
+            else if (ci == 0 && db) db[co] = red[0];
+        }
+    }
+}
+
+// d_outW[n,k] = sum_b g_o[b,n] * pvp[b,k];  d_outb[n] = sum_b g_o[b,n]      (output_ sees pv.detach())
+__global__ void k_bwd_outgrad(const float *__restrict__ g_o, const float *__restrict__ pvp, float *__restrict__ dW,
+                              float *__restrict__ db, int B, int N, int K)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * (K + 1)) return;
+    int n = (int)(i / (K + 1)), k = (int)(i % (K + 1));
+    float acc = 0.0f;
+    if (k < K) {
+        for (int b = 0; b < B; ++b) acc = __builtin_fmaf(g_o[(long)b * N + n], pvp[(long)b * K + k], acc);
+        dW[(long)n * K + k] = acc;
+    } else {
+        for (int b = 0; b < B; ++b) acc += g_o[(long)b * N + n];
+        db[n] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // readout GEMM: out[r,n] = sum_k pv[r,k] * Wt[n,k] + bias[n]      (i2o / output_, :602-606), fp32 MFMA
 //   workgroup = 4 waves = 128 rows x 32 columns; K in chunks of 32 staged through LDS (row stride 33: conflict-free
 //   column reads of the v_mfma_f32_32x32x2_f32 fragments).
@@ -954,6 +1076,38 @@ extern "C" int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, con
                        nout);
     HIP_CHECK_LAUNCH("k_dense_lif");
     if (i2o_W && out_p) return launch_readout(out_pv, i2o_W, i2o_b, out_p, B, d->out_features, d->target, st);
+    return DCLL_OK;
+}
+
+extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
+                                      const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
+                                      const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
+                                      float *scratch, int32_t B, void *stream)
+{
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!eps1 || !v || !dW || !scratch) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: null pointer");
+    if (g_p && !i2o_W) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: g_p needs i2o_W");
+    if (g_o && (!pv_pooled || !d_outW || !d_outb)) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: g_o needs pv_pooled, d_outW, d_outb");
+    if (d->kh * d->kw > WG_MAXTAPS) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: kernels up to 64 taps");
+    if (B < 1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    int ch, cw, ph, pw;
+    conv_shape(d, &ch, &cw, &ph, &pw);
+    const long nconv = (long)B * d->c_out * ch * cw;
+    hipLaunchKernelGGL(k_bwd_dv, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, v, g_p, g_pv, g_v, i2o_W,
+                       scratch, nconv);
+    HIP_CHECK_LAUNCH("k_bwd_dv");
+    const size_t lds = ((size_t)(d->h + 2 * d->pad_h) * (d->w + 2 * d->pad_w) + 256) * sizeof(float);
+    if (lds > 60 * 1024) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: input plane too large for the LDS-resident weight-gradient kernel");
+    hipLaunchKernelGGL(k_bwd_wgrad, dim3(d->c_out * d->c_in), dim3(256), lds, st, *d, ch, cw, scratch, eps1, dW, db, B);
+    HIP_CHECK_LAUNCH("k_bwd_wgrad");
+    if (g_o) {
+        const int K = d->c_out * ph * pw;
+        hipLaunchKernelGGL(k_bwd_outgrad, dim3(nblk((long)d->target * (K + 1), 256)), dim3(256), 0, st, g_o, pv_pooled,
+                           d_outW, d_outb, B, d->target, K);
+        HIP_CHECK_LAUNCH("k_bwd_outgrad");
+    }
     return DCLL_OK;
 }
 

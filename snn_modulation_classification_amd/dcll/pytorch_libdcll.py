@@ -12,7 +12,8 @@ reference module dcll/pytorch_libdcll.py so `networks.ConvNetwork`, `train.py` a
 What is different by design: `.forward` does not run torch ops — it hands device pointers to the HIP kernels
 through the C ABI (include/dcll_hip.h).  There is no CPU path: a tensor that is not on a GPU raises DCLLHipError.
 Layers also expose `forward_sequence(...)`, the whole-T fast path (state on chip for all T steps).
-Local learning (`train_dcll`, reference :690-718) is SURVEY.md 8(f)-2 and not implemented in this round.
+Local learning (`train_dcll`, reference :690-718) runs the same forward kernels inside an autograd node whose
+backward is dcll_conv_lif_backward; torch supplies only the loss module and the optimizer.
 """
 import logging
 import math
@@ -213,6 +214,34 @@ class ContinuousRelativeRefractoryConv2D(ContinuousConv2D):
         return s, pv, v
 
 
+class _ConvLIFStepFn(torch.autograd.Function):
+    """One Conv2dDCLLlayer step as an autograd node: forward = dcll_conv_lif_step, backward =
+    dcll_conv_lif_backward.  Gradients reach i2h.weight / i2h.bias (via pvoutput, pv, pvmem) and output_.weight /
+    output_.bias (via the output logits; output_ sees pv.detach(), reference :606); i2o is frozen, spikes and the
+    neuron state carry no gradient — exactly the graph the reference builds with eager ops."""
+
+    @staticmethod
+    def forward(ctx, layer, x, W, b, out_W, out_b):
+        i2h = layer.i2h
+        s, p, o, pv, v = i2h._step(x, layer.pooling, layer.i2o, layer.output_ if layer.output_layer else None)
+        ctx.layer = layer
+        ctx.desc = i2h.make_desc(x.shape[2:4], layer.pooling, layer.i2o.weight.shape[0], layer.output_layer)
+        # the state buffers are updated in place by the next step: keep this step's eps1
+        ctx.eps1 = i2h.state.eps1.clone()
+        ctx.v, ctx.pv = v, pv
+        ctx.mark_non_differentiable(s)
+        if o is None:
+            return s, p, pv, v
+        return s, p, pv, v, o
+
+    @staticmethod
+    def backward(ctx, gs, gp, gpv, gv, go=None):
+        layer = ctx.layer
+        dW, db, d_outW, d_outb = ops.conv_lif_backward(ctx.desc, ctx.eps1, ctx.v, ctx.pv, gp, go, gpv, gv,
+                                                       layer.i2o.weight, want_out=layer.output_layer and go is not None)
+        return None, None, dW, db, d_outW, d_outb
+
+
 class Conv2dDCLLlayer(nn.Module):
     """LIF conv + max-pool + frozen local readout (+ trainable output readout on the last layer), reference :512-612."""
 
@@ -277,6 +306,16 @@ class Conv2dDCLLlayer(nn.Module):
     def forward(self, input):
         """-> (output, pvoutput, pv, pvmem): next-layer spikes (or output_ logits on the last layer), local
         readout logits, pooled sigmoid, un-pooled membrane (reference :599-608) — one C-ABI call."""
+        if getattr(self, 'build_graph', False) and torch.is_grad_enabled():
+            # local-learning step: same kernels, wrapped in an autograd node (see _ConvLIFStepFn)
+            out = _ConvLIFStepFn.apply(self, input, self.i2h.weight, self.i2h.bias,
+                                       self.output_.weight if self.output_layer else None,
+                                       self.output_.bias if self.output_layer else None)
+            if self.output_layer:
+                s, p, pv, v, o = out
+                return o, p, pv, v
+            s, p, pv, v = out
+            return s, p, pv, v
         s, p, o, pv, v = self.i2h._step(input, self.pooling, self.i2o, self.output_ if self.output_layer else None)
         return (o if self.output_layer else s), p, pv, v
 
@@ -536,9 +575,38 @@ class DCLLBase(nn.Module):
             print(self.name + ' low:{0:1.3} high:{1:1.3}'.format(pd[0], pd[-1]))
 
     def train_dcll(self, input, target, do_train=True, regularize=0.05):
-        raise NotImplementedError(
-            'local learning (train_dcll, reference dcll/pytorch_libdcll.py:690-718) is not part of this build yet '
-            '(SURVEY.md 8(f)-2); the HIP path covers the forward / vote loop')
+        """One local-learning step (reference :690-718): forward; after burn-in the local loss on pvoutput (+ the loss
+        on the output_ logits for the output layer), backward through the HIP backward kernels, optimizer step(s).
+        With torch.distributed initialised the gradients are averaged over the ranks (RCCL) before the step."""
+        if not isinstance(self.dclllayer, Conv2dDCLLlayer):
+            raise NotImplementedError('local learning is implemented for Conv2dDCLLlayer slices')
+        learn_now = (self.iter + 1) >= self.burnin
+        self.dclllayer.build_graph = learn_now
+        try:
+            output, pvoutput, pv, pvmem = self.forward(input)
+        finally:
+            self.dclllayer.build_graph = False
+        if learn_now:
+            self.dclllayer.zero_grad()
+            tgt_loss = self.crit(pvoutput, target)
+            if self.dclllayer.output_layer:
+                tgt_loss = tgt_loss + self.output_crit(output, target)
+            if regularize > 0:
+                reg_loss = 20.0 * regularize * torch.mean(torch.relu(pvmem + 0.01))
+                reg2_loss = 0.1 * regularize * (torch.relu(0.1 - torch.mean(pv)))
+                loss = tgt_loss + reg_loss + reg2_loss
+            else:
+                loss = tgt_loss
+            loss.backward()
+            from .. import parallel
+            parallel.allreduce_mean_grads(p for p in self.dclllayer.parameters() if p.grad is not None)
+            if do_train:
+                self.optimizer.step()
+                if self.dclllayer.output_layer:
+                    self.optimizer2.step()
+        else:
+            tgt_loss = torch.Tensor([0])
+        return output, pvoutput, pv, pvmem, tgt_loss.detach()
 
 
 class DCLLClassification(DCLLBase):

@@ -60,6 +60,26 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     return s, p, o, pv, v
 
 
+def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want_out):
+    """Gradients of one layer step (dcll_conv_lif_backward) -> (dW, db, d_outW, d_outb)."""
+    B = eps1.shape[0]
+    dev = eps1.device
+    ch, cw, ph, pw = conv_out_shape(desc)
+    dW = torch.empty((desc.c_out, desc.c_in, desc.kh, desc.kw), device=dev, dtype=torch.float32)
+    db = torch.empty((desc.c_out,), device=dev, dtype=torch.float32)
+    K = desc.c_out * ph * pw
+    d_outW = torch.empty((desc.target, K), device=dev, dtype=torch.float32) if want_out else None
+    d_outb = torch.empty((desc.target,), device=dev, dtype=torch.float32) if want_out else None
+    scratch = torch.empty((B, desc.c_out, ch, cw), device=dev, dtype=torch.float32)
+    c = lambda t: None if t is None else _f32(t, "grad").contiguous()
+    rc = _lib.get().dcll_conv_lif_backward(
+        ctypes.byref(desc), ptr(eps1), ptr(v), ptr(pv_pooled), ptr(c(g_p)), ptr(c(g_o) if want_out else None),
+        ptr(c(g_pv)), ptr(c(g_v)), ptr(i2o_W), ptr(dW), ptr(db), ptr(d_outW), ptr(d_outb), ptr(scratch), B,
+        stream_ptr())
+    check(rc, "dcll_conv_lif_backward")
+    return dW, db, d_outW, d_outb
+
+
 def dense_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None):
     """One DenseDCLLlayer.forward step (dcll/pytorch_libdcll.py:250-255)."""
     B = x.shape[0]

@@ -332,3 +332,61 @@ def test_readout_gemm_fast_path(dev, rows, K, N):
     out = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev)).cpu().numpy()
     ref = (pv.astype(np.float64) @ Wt.astype(np.float64).T + b).astype(np.float32)
     np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("case", ["mnist_l0", "mnist_l2", "pool3", "scalar_tau", "radio_l2_out", "ref_tuple"])
+def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
+    """dcll_conv_lif_backward (all four incoming gradients, pooling incl. ties routing, output layer) against torch
+    autograd through the CPU oracle ops on the same step."""
+    from snn_modulation_classification_amd import ops
+    from oracle import torch_ref as R
+    g = golden("g1_layer_steps.npz")
+    m = golden_meta["g1"][case]
+    sd = {k: torch.from_numpy(v) for k, v in g.sub("g1/%s/sd/" % case).items()}
+    x = torch.from_numpy(g["g1/%s/x0" % case])
+    B = x.shape[0]
+    rng = np.random.RandomState(3)
+    # --- CPU: autograd through the reference op sequence
+    W = sd["i2h.weight"].clone().requires_grad_(True)
+    b = sd["i2h.bias"].clone().requires_grad_(True)
+    layer = R.RefConvLayer(dict(sd, **{"i2h.weight": W, "i2h.bias": b}), m["pad"], m["pool"], m["wrp"], m["alpharp"],
+                           m["output_layer"])
+    if m["output_layer"]:
+        layer.out_w = sd["output_.weight"].clone().requires_grad_(True)
+        layer.out_b = sd["output_.bias"].clone().requires_grad_(True)
+    layer.init_state(B, x.shape[2:4])
+    # emulate flatten.detach() of the reference for output_
+    s_, pv_, v_, st = R.conv_lif_step(x, W, b, layer.alpha, layer.tau_m, layer.alphas, layer.tau_s, layer.state,
+                                      layer.alpharp, layer.wrp, 1, layer.padding)
+    pvp = R.max_pool(pv_, layer.pooling)
+    flat = pvp.reshape(B, -1)
+    p_ = torch.nn.functional.linear(flat, sd["i2o.weight"], sd["i2o.bias"])
+    r_p = torch.from_numpy(rng.randn(*p_.shape).astype(np.float32))
+    r_pv = torch.from_numpy(rng.randn(*pvp.shape).astype(np.float32)) * 0.1
+    r_v = torch.from_numpy(rng.randn(*v_.shape).astype(np.float32)) * 0.01
+    loss = (p_ * r_p).sum() + (pvp * r_pv).sum() + (v_ * r_v).sum()
+    r_o = None
+    if m["output_layer"]:
+        o_ = torch.nn.functional.linear(flat.detach(), layer.out_w, layer.out_b)
+        r_o = torch.from_numpy(rng.randn(*o_.shape).astype(np.float32))
+        loss = loss + (o_ * r_o).sum()
+    loss.backward()
+    # --- GPU
+    t = {k: cu(v.numpy(), dev) for k, v in sd.items()}
+    d = ops.make_conv_desc(m["cin"], m["cout"], m["im"], m["k"], m["pad"], m["pool"], 24, m["output_layer"],
+                           sd["i2h.alpha"].numel() > 1, m["wrp"], m["alpharp"])
+    ch, cw, ph, pw = ops.conv_out_shape(d)
+    eps0 = torch.zeros((B, m["cin"]) + tuple(m["im"]), device=dev)
+    eps1 = torch.zeros_like(eps0)
+    arp = torch.zeros((B, m["cout"], ch, cw), device=dev)
+    s, p, o, pv, v = ops.conv_lif_step(d, x.to(dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
+                                       t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1, arp,
+                                       t["i2o.weight"], t["i2o.bias"], t.get("output_.weight"), t.get("output_.bias"))
+    dW, db, doW, dob = ops.conv_lif_backward(d, eps1, v, pv, r_p.to(dev), None if r_o is None else r_o.to(dev),
+                                             r_pv.to(dev), r_v.to(dev), t["i2o.weight"], want_out=m["output_layer"])
+    tol = lambda ref: dict(rtol=2e-3, atol=2e-5 * float(ref.abs().max()) + 1e-12)
+    np.testing.assert_allclose(dW.cpu().numpy(), W.grad.numpy(), **tol(W.grad))
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), **tol(b.grad))
+    if m["output_layer"]:
+        np.testing.assert_allclose(doW.cpu().numpy(), layer.out_w.grad.numpy(), **tol(layer.out_w.grad))
+        np.testing.assert_allclose(dob.cpu().numpy(), layer.out_b.grad.numpy(), **tol(layer.out_b.grad))

@@ -70,3 +70,32 @@ def test_two_rank_tally_allreduce_equals_single_process(tmp_path):
     assert int(cm[0].sum()) == n
     for i in range(3):
         assert abs(float(acc[i]) - float(np.mean(votes_np[i] == labels_np))) < 1e-12
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_process_group(backend="gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    parallel.allreduce_mean_grads(params)
+    np.save(os.path.join(out_dir, "g_%d.npy" % rank), np.concatenate([p.grad.reshape(-1).numpy() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gradient_mean(tmp_path):
+    """Local-learning gradients are averaged over the ranks before optimizer.step (training)."""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    expect = np.concatenate([np.full(12, 1.5), np.full(5, 3.0)])        # mean of (1,2) and of (2,4)
+    for rank in range(2):
+        assert np.allclose(np.load(os.path.join(str(tmp_path), "g_%d.npy" % rank)), expect)
+    # single process: no-op
+    p = torch.nn.Parameter(torch.zeros(2))
+    p.grad = torch.ones(2)
+    parallel.allreduce_mean_grads([p])
+    assert p.grad.tolist() == [1.0, 1.0]

@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Training entry point — flag surface of the reference's train.py (:19-94) on the MI355X build.
 
-What this build runs: the evaluation half of the reference's loop (train.py:263-294: every `n_test_interval` steps
-the test batches go through `net.test` / the fused sequence path, `acc_test.npy` and `parameters_{step}.pth` are
-written with the reference's state-dict keys).  What it does not run yet: the local-learning update
-(`net.learn` -> DCLLBase.train_dcll, reference dcll/pytorch_libdcll.py:690-718) and the non-spiking baseline CNN
-(ReferenceConvNetwork, networks/__init__.py:21-113, out of scope) — SURVEY.md 8(f)-2.  Asking for training steps
-therefore stops with a clear message instead of silently doing something else.
+Runs the DCLL half of the reference's loop on the HIP kernels: per training step a batch is encoded to spike planes,
+`net.learn(x[t], labels[t])` is called for every timestep (train.py:249-251: forward + local loss + backward + Adam
+step per layer per timestep after burn-in, dcll/pytorch_libdcll.py:690-718), learning rates are halved every 1000
+steps (:222-229), and every `n_test_interval` steps the test batches are evaluated and `acc_test.npy` /
+`parameters_{step}.pth` (reference state-dict keys) are written (:263-303).  Not run: the non-spiking baseline CNN
+(ReferenceConvNetwork, networks/__init__.py:21-113 — outside the DCLL path) and tensorboard dumps.
+Data: RadioML HDF5 needs h5py (absent here); `--synthetic N` uses the build's seeded constellation generator.
 """
 import argparse
 import datetime
@@ -111,25 +112,63 @@ def main(argv=None):
         with open(os.path.join(out_dir, 'args.pkl'), 'wb') as f:
             pickle.dump(vars(args), f)
 
-    if not args.eval_only:
-        sys.exit('The local-learning step (net.learn -> train_dcll, reference dcll/pytorch_libdcll.py:690-718) is not '
-                 'implemented on the HIP path yet (SURVEY.md 8(f)-2). Use --eval_only, or test_radio_ml.py.')
-
-    # the periodic evaluation block of the reference (train.py:263-303), once
-    n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
     if not args.synthetic:
         sys.exit('Reading RadioML HDF5 is not part of this build yet (SURVEY.md 8(f)-4); pass --synthetic N.')
-    batches = evaluation.synthetic_modulation_batches(args.synthetic, args.batch_size_test, args.max_snr,
-                                                      max(args.n_iters_test, 128), args.seed)[:n_test]
+    from snn_modulation_classification_amd.data.utils import IQEncoder, iq2spiketrain
+    n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
+    test_batches = evaluation.synthetic_modulation_batches(args.synthetic, args.batch_size_test, args.max_snr,
+                                                           max(args.n_iters_test, 128), args.seed)[:n_test]
     use_sequence = net.sequence_supported()
-    from snn_modulation_classification_amd.data.utils import IQEncoder
     encoder = IQEncoder(args.I_resolution, args.Q_resolution, args.I_bounds, args.Q_bounds,
                         device=pytorch_libdcll.device) if use_sequence else None
-    acc_test = np.empty([1, len(batches), len(net.dcll_slices)])
-    for i, (samples, labels) in enumerate(batches):
-        acc_test[0, i, :], _ = evaluation.evaluate_batch(net, args, samples, to_one_hot(labels, target_size), encoder,
-                                                         use_sequence)
-    print('[TEST]  Step {} \t Accuracy {} \t Ref {}'.format('00000', np.mean(acc_test[0], axis=0), 'N/A'))
+
+    def run_tests(step):
+        net.batch_size = args.batch_size_test
+        acc = np.empty([len(test_batches), len(net.dcll_slices)])
+        for i, (samples, labels) in enumerate(test_batches):
+            acc[i, :], _ = evaluation.evaluate_batch(net, args, samples, to_one_hot(labels, target_size), encoder,
+                                                     use_sequence)
+        net.batch_size = args.batch_size
+        print('[TEST]  Step {} \t Accuracy {} \t Ref {}'.format(str(step).zfill(5), np.mean(acc, axis=0), 'N/A'))
+        return acc
+
+    if args.eval_only:
+        acc_test = run_tests(0)[None]
+    else:
+        n_tests_total = int(np.ceil(float(args.n_steps) / args.n_test_interval))
+        acc_test = np.empty([n_tests_total, n_test, len(net.dcll_slices)])
+        st_kw = dict(out_w=args.I_resolution, out_h=args.Q_resolution, min_I=args.I_bounds[0], max_I=args.I_bounds[1],
+                     min_Q=args.Q_bounds[0], max_Q=args.Q_bounds[1], max_duration=args.n_iters, gs_stdev=0)
+        for step in range(args.n_steps):
+            if ((step + 1) % 1000) == 0:                      # reference :222-229
+                for sl in net.dcll_slices:
+                    sl.optimizer.param_groups[-1]['lr'] /= 2
+                net.dcll_slices[-1].optimizer2.param_groups[-1]['lr'] /= 2
+                print('Adjusting learning rates')
+            snr = int(np.random.randint(args.min_snr // 2, args.max_snr // 2 + 1) * 2)
+            samples, labels = evaluation.synthetic_modulation_batches(
+                args.batch_size, args.batch_size, snr, max(args.n_iters, 128), args.seed + 7919 * (step + 1))[0]
+            spikes, targets = iq2spiketrain(samples, to_one_hot(labels, target_size), **st_kw)
+            input_spikes = torch.Tensor(spikes).to(pytorch_libdcll.device)
+            labels_spikes = torch.as_tensor(np.asarray(targets), dtype=torch.float32).to(pytorch_libdcll.device)
+            net.reset()
+            net.train()
+            for t in range(args.n_iters):
+                net.learn(x=input_spikes[t], labels=labels_spikes[t])
+            print('[TRAIN] Step {} \t Accuracy {}'.format(str(step).zfill(5), net.accuracy(labels_spikes)))
+            if (step % args.n_test_interval) == 0:
+                acc_test[step // args.n_test_interval] = run_tests(step)
+                if not args.no_save:
+                    np.save(os.path.join(out_dir, 'acc_test.npy'), acc_test)
+                    save_path = os.path.join(out_dir, 'parameters_{}.pth'.format(step))
+                    torch.save(net.cpu().state_dict(), save_path)
+                    net.to(pytorch_libdcll.device)
+                    print('-' * 80)
+                    print('Saved network parameters to `%s`.' % save_path)
+                    print('-' * 80)
+        return out_dir
+
+    # --eval_only: the periodic evaluation block of the reference (train.py:263-303) once, then save
     if not args.no_save:
         np.save(os.path.join(out_dir, 'acc_test.npy'), acc_test)
         save_path = os.path.join(out_dir, 'parameters_{}.pth'.format(0))
