@@ -646,8 +646,9 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__
 //   VALU instruction of either wave of a SIMD adds its cycles to the MFMA time — nothing hides under the partner's
 //   MFMAs — and all waves meet at the stage barrier.  The non-MFMA work is therefore spread evenly over the four SIMDs
 //   (waves w and w+4 share a SIMD) in every stage:
-//   - trace update: wave w advances ONE of its 4 input channels per stage, for step t+1, in stages m = 2c + (w>>2)
-//     of step t (reads image[t&1], writes image[(t+1)&1]; eps0 lives in registers);
+//   - trace update: wave w advances ONE of its 4 input channels per stage, for step t+1, in every second stage of
+//     step t (reads image[t&1], writes image[(t+1)&1]; eps0 lives in registers) — the stages in which it also has an
+//     epilogue share, so that its SIMD partner has no extra work in that stage;
 //   - epilogue of the tile handed over by wave 7 (refractory trace, threshold, sigmoid, ballot-packed spikes): split
 //     by accumulator register quad over the 4 waves with (w>>2) == (m&1); wave w owns quad w&3 (channels
 //     rr + 8*(w&3) + 4*(lane>>5)) of the tiles of its parity and keeps their 16 arp values in registers.
@@ -679,7 +680,9 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 // NRO > 0 fuses the local readout(s) into the epilogue: logits[t][b][n] = sum_{co,pix} pv * Wro[n][co][pix] + b[n]
 // (i2o, and output_ stacked behind it on the last layer: dcll/pytorch_libdcll.py:602-606) with Wro pre-permuted to
 // the epilogue's register layout (dcll_permute_readout); pv then never travels through HBM.
-template <bool REFRACTORY, int OUT = 3, int NRO = 0, int ABLATE = 0>      // OUT bit0: write pv, bit1: write v
+// PRIO: s_setprio of the wave that carries the stage's non-MFMA work (bits 0-1: level, bit 2: keep it through the chain).
+// Measured (experiments/ablate_c32.hip, B=1024): 0 -> 25.56 ms, 1 -> 25.18 ms, 5 -> 25.13 ms.
+template <bool REFRACTORY, int OUT = 3, int NRO = 0, int ABLATE = 0, int PRIO = 5>  // OUT bit0: write pv, bit1: write v
 __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
@@ -700,6 +703,11 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, kept scalar
     const int wq = w & 3, wpar = w >> 2;                          // epilogue quad / tile parity owned by this wave
+    // my trace shares fall in the SAME stages as my epilogue shares (stage parity g&1 == wpar  <=>  tile parity
+    // m&1 == tpar): per SIMD and stage ONE wave carries all the non-MFMA work and its partner starts its MFMAs at
+    // once.  (Measured: with the two jobs on different waves of a SIMD both begin the stage waiting on LDS and that
+    // SIMD reaches the barrier last.)
+    const int tpar = wpar ^ (w & 1);
     const long b = blockIdx.x;
 
     for (int i = tid; i < 2 * IMG_FLOATS; i += 512) lds[i] = 0.0f;
@@ -784,9 +792,15 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
     __syncthreads();
 
     const int nstage = 8 * T + (NRO > 0 ? 17 : 9);
+    unsigned long long dbg_wait = 0, dbg_t0 = 0, dbg_epi = 0, dbg_tr = 0, dbg_mf = 0;   // ABLATE & 8 only
+    if (ABLATE & 8) dbg_t0 = __builtin_amdgcn_s_memtime();
     for (int g = 0; g < nstage; ++g) {
+        unsigned long long dbg_a = 0;
+        if (ABLATE & 8) dbg_a = __builtin_amdgcn_s_memtime();
         // ---- (1) epilogue share: quad wq of tile qe = g - 8 (finished by wave 7 in the previous stage) ----
         const int qe = g - 8;
+        const bool loaded = ((g & 1) == wpar);          // this wave carries the stage's non-MFMA work of its SIMD
+        if (loaded) __builtin_amdgcn_s_setprio(PRIO & 3);
         if (!(ABLATE & 1) && qe >= 0 && qe < 8 * T && ((qe & 1) == wpar)) {
             const int te = qe >> 3, me = qe & 7;
             const f32x4 v4 = *((const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + wq * 64 + lane);
@@ -859,12 +873,16 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                 ro_out[((long)tc * B + b) * NRO + lane] = tot;
             }
         }
+        if (ABLATE & 8) { unsigned long long x_ = __builtin_amdgcn_s_memtime(); dbg_epi += x_ - dbg_a; dbg_a = x_; }
         const int q = g - w;
-        if (q >= 0 && q < 8 * T) {
+        const bool active = q >= 0 && q < 8 * T;
+        const bool tracing = active && !(ABLATE & 2) && (((q & 7) & 1) == tpar) && (q >> 3) + 1 < T;
+        if (loaded && !tracing && !(PRIO & 4)) __builtin_amdgcn_s_setprio(0);
+        if (active) {
             const int m = q & 7, t = q >> 3;
             float *img = lds + (t & 1) * IMG_FLOATS;
             // ---- (2) trace share: channel c of step t+1 in stage m = 2c + wpar ----
-            if (!(ABLATE & 2) && ((m & 1) == wpar) && t + 1 < T) {
+            if (tracing) {
                 const int c = m >> 1;
                 const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
                 const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
@@ -894,6 +912,8 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
 #undef DCLL_TRACE_CASE
                 }
             }
+            if (ABLATE & 8) { unsigned long long x_ = __builtin_amdgcn_s_memtime(); dbg_tr += x_ - dbg_a; dbg_a = x_; }
+            if (loaded && tracing && !(PRIO & 4)) __builtin_amdgcn_s_setprio(0);
             // ---- (3) my K-slice of the chain ----
             f32x16 acc;
             if (w == 0 || (ABLATE & 4)) {
@@ -941,7 +961,21 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
                 }
             }
         }
-        __syncthreads();
+        if (loaded && (PRIO & 4)) __builtin_amdgcn_s_setprio(0);
+        if (ABLATE & 8) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            unsigned long long x_ = __builtin_amdgcn_s_memtime();
+            dbg_mf += x_ - dbg_a;
+            __syncthreads();
+            dbg_wait += __builtin_amdgcn_s_memtime() - x_;
+        } else {
+            __syncthreads();
+        }
+    }
+    if ((ABLATE & 8) && lane == 0 && b == 0) {
+        unsigned long long tot = __builtin_amdgcn_s_memtime() - dbg_t0;
+        unsigned long long *dp = (unsigned long long *)v_out + w * 8;       // v_out doubles as the debug buffer
+        dp[0] = tot; dp[1] = dbg_wait; dp[2] = dbg_epi; dp[3] = dbg_tr; dp[4] = dbg_mf;
     }
 
     // state back to HBM: eps1 of the last step lives in image[(T-1)&1]
