@@ -149,6 +149,16 @@ int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, 
                                  uint32_t *spk_out, float *pv_out, float *v_out, int32_t T, int32_t B, void *stream);
 
 /*
+ * Same kernel with iq2spiketrain's quantisation (data/utils.py:60-82) fused in: the input is the raw IQ window
+ * iq (B,2,L) fp32, samples t0..t0+T-1, quantised with the thresholds of dcll_iq_encode (thr_i, thr_q: 15 floats each
+ * for the 16x16 plane).  T <= 4096.
+ */
+int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
+                              int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
+                              float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
+                              int32_t T, int32_t B, void *stream);
+
+/*
  * Local readout for many rows at once: out[r, n] = sum_k pv[r,k]*Wt[n,k] + bias[n]   (i2o / output_, :602-606),
  * fp32 MFMA.  rows = T*B, K = c_out*ph*pw, N = rows of Wt (e.g. i2o and output_ stacked: 48).
  */

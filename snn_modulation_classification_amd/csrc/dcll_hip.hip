@@ -565,9 +565,15 @@ __global__ void k_pack(const float *__restrict__ dense, uint32_t *__restrict__ p
 //   chain (tap order = the pinned order for c_in == 1) for every output channel with wave-uniform weights.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PADW = 22;
+constexpr int C1_MAXT = 4096;       // longest window the fused IQ encoder of k_lif_seq_c1 keeps in LDS
 
+// Input either as cell indices (cells != NULL) or as raw IQ (iq != NULL): then the quantisation of iq2spiketrain
+// (data/utils.py:60-82, threshold form as in k_iq_encode) is fused here: thread t quantises sample t0+t (coalesced
+// loads of the I and the Q row of this window) and parks the cell index of step t in LDS.
 template <bool REFRACTORY>
 __global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
+                                                    const float *__restrict__ iq, const float *__restrict__ thr_i,
+                                                    const float *__restrict__ thr_q, int L, int t0,
                                                     const float *__restrict__ W, const float *__restrict__ bias,
                                                     const float *__restrict__ tau4, float *__restrict__ eps0_g,
                                                     float *__restrict__ eps1_g, float *__restrict__ arp_g,
@@ -575,16 +581,26 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__
                                                     float *__restrict__ v_out, int T, int B, float alpharp, float wrp)
 {
     __shared__ float plane[PADW * PADW];
+    __shared__ int scell[C1_MAXT];
     const int b = blockIdx.x, pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63, wave = pix >> 6;
     const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];
     for (int i = pix; i < PADW * PADW; i += 256) plane[i] = 0.0f;
+    if (iq) {
+        // fused encoder: thread t quantises sample t0+t of this window (coalesced loads of the I and the Q row)
+        for (int t = pix; t < T; t += 256) {
+            const float vi = iq[((long)b * 2 + 0) * L + t0 + t], vq = iq[((long)b * 2 + 1) * L + t0 + t];
+            int ci = 0, cq = 0;
+            for (int k = 0; k < 15; ++k) { ci += vi >= thr_i[k]; cq += vq >= thr_q[k]; }
+            scell[t] = cq * 16 + ci;
+        }
+    }
     float e0 = eps0_g[(long)b * 256 + pix], e1 = eps1_g[(long)b * 256 + pix];
     float arp[32];
 #pragma unroll
     for (int co = 0; co < 32; ++co) arp[co] = (REFRACTORY && co < c_out) ? arp_g[((long)b * c_out + co) * 256 + pix] : 0.0f;
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-        const int cell = cells[(long)t * B + b];
+        const int cell = iq ? scell[t] : cells[(long)t * B + b];
         trace_update(cell == pix ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0, e1);
         plane[(y + 3) * PADW + x + 3] = e1;
         __syncthreads();
@@ -1213,6 +1229,21 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
     return DCLL_OK;
 }
 
+static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
+                     const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4, float *eps0,
+                     float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, int T, int B,
+                     hipStream_t st)
+{
+    if (d->refractory)
+        hipLaunchKernelGGL(k_lif_seq_c1<true>, dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,
+                           tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
+    else
+        hipLaunchKernelGGL(k_lif_seq_c1<false>, dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,
+                           tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
+    HIP_CHECK_LAUNCH("k_lif_seq_c1");
+    return DCLL_OK;
+}
+
 extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *W, const float *b,
                                             const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
                                             float *pv_out, float *v_out, int32_t T, int32_t B, void *stream)
@@ -1223,15 +1254,24 @@ extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: refractory layer needs arp");
     if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: negative size");
     if (T == 0 || B == 0) return DCLL_OK;
-    hipStream_t st = (hipStream_t)stream;
-    if (d->refractory)
-        hipLaunchKernelGGL(k_lif_seq_c1<true>, dim3(B), dim3(256), 0, st, d->c_out, cells, W, b, tau4, eps0, eps1, arp,
-                           spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
-    else
-        hipLaunchKernelGGL(k_lif_seq_c1<false>, dim3(B), dim3(256), 0, st, d->c_out, cells, W, b, tau4, eps0, eps1, arp,
-                           spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
-    HIP_CHECK_LAUNCH("k_lif_seq_c1");
-    return DCLL_OK;
+    return launch_c1(d, cells, nullptr, nullptr, nullptr, 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B,
+                     (hipStream_t)stream);
+}
+
+extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
+                                         int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
+                                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
+                                         float *v_out, int32_t T, int32_t B, void *stream)
+{
+    int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_iq");
+    if (rc) return rc;
+    if (!iq || !thr_i || !thr_q || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: null pointer");
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: refractory layer needs arp");
+    if (T < 0 || B < 0 || t0 < 0 || t0 + T > L) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: window [t0, t0+T) outside the IQ row");
+    if (T > C1_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence_iq: at most 4096 timesteps per launch");
+    if (T == 0 || B == 0) return DCLL_OK;
+    return launch_c1(d, nullptr, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B,
+                     (hipStream_t)stream);
 }
 
 extern "C" int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t T, int32_t B, int32_t N,

@@ -384,6 +384,11 @@ class Conv2dDCLLlayer(nn.Module):
                 spk, pv, _ = ops.conv_lif_sequence_cells(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,
                                                          T, B, want_spikes=want_spikes, out=buffers)
                 return spk, pv, None
+            if kind == 'iq':        # inp = (iq (B,2,L), thr_i, thr_q, t0): encoder fused into the layer kernel
+                iq, thr_i, thr_q, t0 = inp
+                spk, pv, _ = ops.conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, i2h.weight, i2h.bias, tau4, st.eps0,
+                                                      st.eps1, arp, T, B, want_spikes=want_spikes, out=buffers)
+                return spk, pv, None
             if fuse_readout:
                 Wp, rb = self.fused_readout_weights()
                 spk, _, _, logits = ops.conv_lif_sequence(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,

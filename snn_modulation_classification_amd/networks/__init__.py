@@ -109,9 +109,12 @@ class ConvNetwork(torch.nn.Module):
                 t.zero_()
 
     @torch.no_grad()
-    def test_sequence(self, cells, collect=True, profile=None, fuse_readout=False):
+    def test_sequence(self, cells=None, collect=True, profile=None, fuse_readout=False, iq=None, encoder=None,
+                      T=None, t0=None):
         """Equivalent of `for t in range(T): net.test(x[t])` for input given as cell indices (T,B) int32 on device
-        (one input spike per sample per step, what iq2spiketrain produces).  Fills every slice's `clout`.
+        (one input spike per sample per step, what iq2spiketrain produces), or as the raw IQ batch `iq` (B,2,L) with an
+        `IQEncoder` — then the quantisation runs inside the first layer's kernel (T steps from sample t0; t0 drawn
+        like the host encoder when None).  Fills every slice's `clout`.
 
         `fuse_readout`: compute the readouts in the layer kernels' epilogue instead of materialising pv + a GEMM.
         Measured slower on MI355X (re-streaming the 786 KB readout matrix per sample-step through L2 costs more than
@@ -123,8 +126,16 @@ class ConvNetwork(torch.nn.Module):
         'clout' (per layer (T,B) int32) and 'vote' (per layer (B) int32)."""
         if not self.sequence_supported():
             raise ops._lib.DCLLUnsupported('no fused sequence kernel for this network geometry; use net.test(x[t])')
-        T, B = cells.shape
-        buf = self._sequence_buffers(T, B, cells.device)
+        if iq is not None:
+            iq = iq.reshape(iq.shape[0], 2, -1)
+            B = iq.shape[0]
+            if t0 is None:
+                t0 = np.random.randint(0, iq.shape[-1] - T + 1)       # same draw as iq2spiketrain
+            first_input, first_kind, dev = (iq, encoder.thr_i, encoder.thr_q, int(t0)), 'iq', iq.device
+        else:
+            T, B = cells.shape
+            first_input, first_kind, dev = cells.contiguous(), 'cells', cells.device
+        buf = self._sequence_buffers(T, B, dev)
 
         def timed(key, fn, *a, **kw):
             if profile is None:
@@ -136,14 +147,14 @@ class ConvNetwork(torch.nn.Module):
             profile.setdefault(key, []).append((e0, e1))
             return out
 
-        cur = cells.contiguous()
+        cur = first_input
         res = dict(logits=[], clout=[], vote=[])
         for i, s in enumerate(self.dcll_slices):
             L = s.dclllayer
             last = (i == self.num_layers - 1)
             fused = fuse_readout and i > 0
             spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B,
-                                'cells' if i == 0 else 'packed', want_spikes=not last,
+                                first_kind if i == 0 else 'packed', want_spikes=not last,
                                 buffers=dict(spk=buf['spk'][i & 1], pv=buf['pv'], ro=buf['ro'][i]),
                                 fuse_readout=fused)
             if fused:

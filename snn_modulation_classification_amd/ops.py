@@ -155,6 +155,28 @@ def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want
     return spk, pv, v
 
 
+def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True,
+                         want_pv=True, want_v=False, out=None):
+    """First layer from the raw IQ window (B,2,L): iq2spiketrain's quantisation fused into k_lif_seq_c1."""
+    dev = W.device
+    out = out or {}
+    iq = iq.reshape(B, 2, -1).contiguous()
+    L = iq.shape[-1]
+    words = desc.h * desc.w // 32
+    spk = out.get("spk") if want_spikes else None
+    if want_spikes and spk is None:
+        spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
+    pv = out.get("pv") if want_pv else None
+    if want_pv and pv is None:
+        pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
+    v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+    rc = _lib.get().dcll_conv_lif_sequence_iq(ctypes.byref(desc), ptr(iq), ptr(thr_i), ptr(thr_q), L, t0, ptr(W), ptr(b),
+                                              ptr(tau4), ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), T, B,
+                                              stream_ptr())
+    check(rc, "dcll_conv_lif_sequence_iq")
+    return spk, pv, v
+
+
 def readout(pv2d, Wt, bias, out=None):
     """out[r,n] = sum_k pv2d[r,k] Wt[n,k] + bias[n]  (i2o / output_), fp32 MFMA."""
     rows, K = pv2d.shape

@@ -101,11 +101,11 @@ def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
     """One batch through all timesteps; returns (per-layer accuracy list, confusion matrix of the last layer)."""
     T = args.n_iters_test
     if use_sequence:
-        cells = encoder(samples.to(pytorch_libdcll.device), T)         # IQ -> cells on the GPU
         targets = labels1h.unsqueeze(0).repeat(T, 1, 1)
         net.reset()
         net.eval()
-        net.test_sequence(cells)
+        # raw IQ to the GPU; quantisation to I/Q-plane cells happens inside the first layer's kernel
+        net.test_sequence(iq=samples.to(pytorch_libdcll.device), encoder=encoder, T=T)
     else:
         spikes, targets = iq2spiketrain(samples, labels1h, out_w=args.I_resolution, out_h=args.Q_resolution,
                                         min_I=args.I_bounds[0], max_I=args.I_bounds[1], min_Q=args.Q_bounds[0],
