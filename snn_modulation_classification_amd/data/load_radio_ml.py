@@ -1,0 +1,92 @@
+"""RadioML loaders for the DCLL entry points.
+
+`get_radio_ml_loader(batch_size, train, data_dir=..., min_snr=6, max_snr=30, per_h5_frac=0.5, train_frac=0.9)` keeps
+the call signature and the sample ordering of the reference's data/load_radio_ml.py (:10-132): per (class, SNR) block
+the first `per_h5_frac` of the examples is used, split into train / test at `train_frac`, and the blocks are
+INTERLEAVED (sample k of block j sits at index j + k * n_blocks), samples shaped (2, 1, L) float32, labels int64.
+
+Block sources, tried in this order inside `data_dir`:
+  class{c}_snr{s}.hdf5   the reference's per-(class, SNR) split of RadioML 2018.01A ('X': (n, 1024, 2)); needs h5py,
+                         which this image does not have — the import is attempted only when such files exist
+  class{c}_snr{s}.npy    the same blocks as plain numpy files (n, L, 2) — build-specific, h5py-free
+  RML2016.10a_dict.pkl   RadioML 2016.10a: pickled dict {(modulation, snr): (n, 2, 128)} (11 classes) — the dataset
+                         BASELINE.json names; the reference itself cannot read it
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+RML2016_FILES = ("RML2016.10a_dict.pkl", "RML2016.10a_dict.dat")
+
+
+def _block_2018(data_dir, class_idx, snr):
+    """One (class, SNR) block as (n, L, 2) float32, or None if the directory holds no such block."""
+    stem = os.path.join(data_dir, "class%d_snr%d" % (class_idx, snr))
+    if os.path.exists(stem + ".npy"):
+        return np.load(stem + ".npy").astype(np.float32, copy=False)
+    if os.path.exists(stem + ".hdf5"):
+        try:
+            import h5py
+        except ImportError:
+            raise RuntimeError("%s.hdf5 needs h5py, which is not installed; convert the blocks to .npy "
+                               "(same name, array (n, L, 2))" % stem)
+        with h5py.File(stem + ".hdf5", "r") as f:
+            return f["X"][:].astype(np.float32, copy=False)
+    return None
+
+
+def _blocks_2016(path, min_snr, max_snr):
+    """2016.10a pickle -> (class names sorted, {(class_idx, snr): (n, L, 2)})."""
+    with open(path, "rb") as f:
+        d = pickle.load(f, encoding="latin1")
+    mods = sorted({k[0] for k in d})
+    blocks = {}
+    for (mod, snr), x in d.items():
+        if min_snr <= snr <= max_snr:
+            blocks[(mods.index(mod), int(snr))] = np.transpose(np.asarray(x, dtype=np.float32), (0, 2, 1))
+    return mods, blocks
+
+
+def load_split(data_dir, train, min_snr=6, max_snr=30, per_h5_frac=0.5, train_frac=0.9, block_size=None):
+    """-> (X (N, 2, 1, L) float32, Y (N) int64, n_classes) in the reference's interleaved order."""
+    snrs = list(range(min_snr, max_snr + 2, 2))
+    pkl = next((os.path.join(data_dir, n) for n in RML2016_FILES if os.path.exists(os.path.join(data_dir, n))), None)
+    if pkl is not None:
+        mods, table = _blocks_2016(pkl, min_snr, max_snr)
+        n_classes = len(mods)
+        get = lambda c, s: table.get((c, s))
+    else:
+        n_classes = 24
+        get = lambda c, s: _block_2018(data_dir, c, s)
+    blocks = []
+    for c in range(n_classes):
+        for s in snrs:
+            x = get(c, s)
+            if x is None:
+                raise FileNotFoundError("no RadioML block for class %d, SNR %d under %s" % (c, s, data_dir))
+            blocks.append((c, x))
+    full = block_size if block_size is not None else min(len(x) for _, x in blocks)
+    use = int(per_h5_frac * full)
+    n_train = int(train_frac * use)
+    lo, hi = (0, n_train) if train else (n_train, use)
+    n_blocks, per = len(blocks), hi - lo
+    L = blocks[0][1].shape[1]
+    X = np.zeros((n_blocks * per, L, 2), dtype=np.float32)
+    Y = np.zeros(n_blocks * per, dtype=np.int64)
+    for j, (c, x) in enumerate(blocks):
+        X[j::n_blocks] = x[lo:hi]
+        Y[j::n_blocks] = c
+    return np.ascontiguousarray(X.transpose(0, 2, 1))[:, :, None, :], Y, n_classes
+
+
+def get_radio_ml_loader(batch_size, train, **kwargs):
+    X, Y, _ = load_split(kwargs['data_dir'], train, kwargs.get('min_snr', 6), kwargs.get('max_snr', 30),
+                         kwargs.get('per_h5_frac', 0.5), kwargs.get('train_frac', 0.9), kwargs.get('block_size'))
+    name = 'train' if train else 'test'
+    print('[%s] dataset size: %d' % (name, len(X)))
+    loader = DataLoader(TensorDataset(torch.from_numpy(X), torch.from_numpy(Y)), batch_size=batch_size, shuffle=train)
+    loader.name = 'RadioML_{}'.format(name)
+    return loader

@@ -6,9 +6,10 @@ snr_evaluation.txt, confusion_matrix_snr_%d.npy, snr_evaluation_accs.npy :71,156
 (:142-146) runs on the HIP kernels: the fused whole-sequence path when the network geometry has one
 (radio_ml_conv.yaml on a 16x16 I/Q plane), otherwise one C-ABI call per layer per step.
 
-Data: `--radio_ml_data_dir` must hold the per-(class, SNR) HDF5 split of RadioML 2018.01A that the reference's loader
-produces; reading it needs h5py (not in this image).  `--synthetic N` evaluates N seeded synthetic windows per SNR
-instead (the build's own generator: PSK/QAM constellations + AWGN), which is also what the tests use.
+Data: `--radio_ml_data_dir` holds the per-(class, SNR) blocks of RadioML 2018.01A (the reference's .hdf5 split — needs
+h5py — or the same blocks as .npy) or the RadioML 2016.10a pickle (data/load_radio_ml.py).  `--synthetic N` evaluates
+N seeded synthetic windows per SNR instead (the build's own generator: PSK/QAM constellations + AWGN), which is also
+what the tests use.
 """
 import argparse
 import os
@@ -89,12 +90,15 @@ def load_batches(args, snr, n_batches):
     if args.synthetic:
         return synthetic_modulation_batches(args.synthetic, args.batch_size_test, snr, max(args.n_iters_test, 128),
                                             args.seed)[:n_batches]
+    from snn_modulation_classification_amd.data.load_radio_ml import get_radio_ml_loader
     try:
-        import h5py  # noqa: F401
-    except ImportError:
-        sys.exit('Reading RadioML 2018.01A needs h5py, which is not installed here; pass --synthetic N to evaluate '
-                 'synthetic IQ windows (HDF5 reader: SURVEY.md 8(f)-4).')
-    sys.exit('The RadioML 2018.01A HDF5 reader is not part of this build yet (SURVEY.md 8(f)-4); use --synthetic N.')
+        loader = get_radio_ml_loader(args.batch_size_test, train=False, data_dir=args.radio_ml_data_dir, min_snr=snr,
+                                     max_snr=snr, per_h5_frac=args.per_h5_frac, train_frac=args.train_frac)
+    except (FileNotFoundError, RuntimeError) as e:
+        sys.exit('Cannot read RadioML data from `%s`: %s\nPass --synthetic N to evaluate synthetic IQ windows.'
+                 % (args.radio_ml_data_dir, e))
+    it = iter(loader)
+    return [next(it) for _ in range(n_batches)]
 
 
 def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):

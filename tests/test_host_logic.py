@@ -285,3 +285,48 @@ def test_entry_point_flag_surface():
     assert test_radio_ml.parse_args(['--random_tau', 'False']).random_tau is True
     s = test_radio_ml.parse_args(['--I_bounds', '-2', '1.5', '--arp', '1.0', '--burnin', '20'])
     assert s.I_bounds == [-2.0, 1.5] and s.arp == 1.0 and s.burnin == 20
+
+
+# ---------------------------------------------------------------------------------------------- dataset loaders
+def test_radio_ml_loader_interleaving_npy_blocks(tmp_path):
+    """Per-(class, SNR) blocks -> the reference's split + interleaved order (data/load_radio_ml.py:66-96)."""
+    from snn_modulation_classification_amd.data.load_radio_ml import load_split, get_radio_ml_loader
+    n, L = 20, 32
+    for c in range(24):
+        for s in (6, 8):
+            x = np.zeros((n, L, 2), np.float32)
+            x[:, 0, 0] = c
+            x[:, 0, 1] = s
+            x[:, 1, 0] = np.arange(n)
+            np.save(tmp_path / ("class%d_snr%d.npy" % (c, s)), x)
+    Xtr, Ytr, nc = load_split(str(tmp_path), True, 6, 8, per_h5_frac=0.5, train_frac=0.8)
+    Xte, Yte, _ = load_split(str(tmp_path), False, 6, 8, per_h5_frac=0.5, train_frac=0.8)
+    assert nc == 24 and Xtr.shape == (48 * 8, 2, 1, L) and Xte.shape == (48 * 2, 2, 1, L)
+    # sample k of block j (= class*2 + snr_idx) sits at j + k*48
+    for j in (0, 1, 5, 47):
+        for k in (0, 3, 7):
+            row = Xtr[j + k * 48]
+            assert Ytr[j + k * 48] == j // 2
+            assert row[0, 0, 0] == j // 2 and row[1, 0, 0] == (6, 8)[j % 2] and row[0, 0, 1] == k
+    assert Xte[3 + 48][0, 0, 1] == 9 and Yte[3 + 48] == 1          # test split = examples 8..9 of each block
+    loader = get_radio_ml_loader(16, False, data_dir=str(tmp_path), min_snr=6, max_snr=8, per_h5_frac=0.5,
+                                 train_frac=0.8)
+    xb, yb = next(iter(loader))
+    assert xb.shape == (16, 2, 1, L) and yb.dtype == torch.int64 and loader.name == 'RadioML_test'
+    with pytest.raises(FileNotFoundError):
+        load_split(str(tmp_path), True, 6, 10)
+
+
+def test_radio_ml_2016_pickle_adapter(tmp_path):
+    """RadioML 2016.10a (the dataset BASELINE.json names): dict {(mod, snr): (n, 2, 128)}, 11 classes."""
+    import pickle
+    from snn_modulation_classification_amd.data.load_radio_ml import load_split
+    mods = ['8PSK', 'AM-DSB', 'AM-SSB', 'BPSK', 'CPFSK', 'GFSK', 'PAM4', 'QAM16', 'QAM64', 'QPSK', 'WBFM']
+    rng = np.random.RandomState(0)
+    d = {(m, s): rng.randn(10, 2, 128).astype(np.float32) for m in mods for s in range(-4, 10, 2)}
+    with open(tmp_path / "RML2016.10a_dict.pkl", "wb") as f:
+        pickle.dump(d, f)
+    X, Y, nc = load_split(str(tmp_path), True, 0, 8, per_h5_frac=1.0, train_frac=0.5)
+    assert nc == 11 and X.shape == (11 * 5 * 5, 2, 1, 128)
+    assert np.array_equal(X[7, :, 0, :], d[(mods[1], 4)][0]) and Y[7] == 1      # block 7 = class 1, snr index 2
+    assert set(Y.tolist()) == set(range(11))

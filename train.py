@@ -113,7 +113,8 @@ def main(argv=None):
             pickle.dump(vars(args), f)
 
     if not args.synthetic:
-        sys.exit('Reading RadioML HDF5 is not part of this build yet (SURVEY.md 8(f)-4); pass --synthetic N.')
+        sys.exit('train.py of this build trains on the synthetic generator (--synthetic N); the RadioML readers '
+                 '(data/load_radio_ml.py) are wired into test_radio_ml.py.')
     from snn_modulation_classification_amd.data.utils import IQEncoder, iq2spiketrain
     n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
     test_batches = evaluation.synthetic_modulation_batches(args.synthetic, args.batch_size_test, args.max_snr,
