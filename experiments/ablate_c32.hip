@@ -1,7 +1,7 @@
 // Ablation timing of k_lif_seq_c32 (diagnostic, not product): which part of a stage costs what.
 #include "../snn_modulation_classification_amd/csrc/dcll_hip.hip"
 #include <vector>
-template <int AB, int PRIO = 0>
+template <int AB, int PRIO = 5, int BASES = 1>
 static float run(int B, int T, bool want_pv)
 {
     size_t nin = (size_t)T * B * 32 * 8;
@@ -21,8 +21,8 @@ static float run(int B, int T, bool want_pv)
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
-        if (want_pv) hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0, AB, PRIO>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
-        else hipLaunchKernelGGL((k_lif_seq_c32<true, 0, 0, AB, PRIO>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        if (want_pv) hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0, AB, PRIO, BASES>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        else hipLaunchKernelGGL((k_lif_seq_c32<true, 0, 0, AB, PRIO, BASES>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;
@@ -36,8 +36,8 @@ int main()
     double ideal = 2.0 * 32 * 1568 * 256 * (double)T * B / 157.3e12 * 1e3;
     printf("ideal at 157.3 TF: %.2f ms\n", ideal);
     printf("full                         %.2f ms\n", run<0>(B, T, true));
-    printf("full, loaded wave prio 1     %.2f ms\n", run<0, 1>(B, T, true));
-    printf("full, loaded wave prio 1 whole stage %.2f ms\n", run<0, 5>(B, T, true));
+    printf("full, 2 hidden bases         %.2f ms\n", run<0, 5, 2>(B, T, true));
+    printf("full, prio 0                 %.2f ms\n", run<0, 0>(B, T, true));
     printf("full (again)                 %.2f ms\n", run<0>(B, T, true));
     printf("full, no pv store            %.2f ms\n", run<0>(B, T, false));
     printf("no epilogue                  %.2f ms\n", run<1>(B, T, true));

@@ -698,7 +698,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 // the epilogue's register layout (dcll_permute_readout); pv then never travels through HBM.
 // PRIO: s_setprio of the wave that carries the stage's non-MFMA work (bits 0-1: level, bit 2: keep it through the chain).
 // Measured (experiments/ablate_c32.hip, B=1024): 0 -> 25.56 ms, 1 -> 25.18 ms, 5 -> 25.13 ms.
-template <bool REFRACTORY, int OUT = 3, int NRO = 0, int ABLATE = 0, int PRIO = 5>  // OUT bit0: write pv, bit1: write v
+template <bool REFRACTORY, int OUT = 3, int NRO = 0, int ABLATE = 0, int PRIO = 5, int BASES = 1>  // OUT bit0: pv, bit1: v
 __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
@@ -949,16 +949,22 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
             // row r are issued (explicit double buffer, order pinned with sched_barrier).
             // (Tried: four hand-made bases 256 dwords apart to spare the ~22 v_add per wave-stage that ds_read2_b32's
             //  8-bit offsets cost — measured 20 % slower, the compiler's own pairing is better.)
-            const float *bp = img + bbase + m * 2 * ROWF;
+            // LDS index of tap (cp,ky,kx) = i0 + cp*722 + ky*19 + kx.  ds_read2_b32 reaches 255 dwords from its base
+            // register; the second channel pair gets its own base (an integer hidden from the optimiser, so the
+            // accesses stay LDS-typed) instead of the ~22 per-row v_add the compiler would otherwise re-derive.
+            const int i0 = (t & 1) * IMG_FLOATS + bbase + m * 2 * ROWF;
+            int i1 = i0 + 2 * CHF;
+            if (BASES == 2) asm volatile("" : "+v"(i1));
+            auto tapval = [&](int cp, int off) -> float { return (BASES == 2 && cp) ? lds[i1 + off] : lds[i0 + cp * 2 * CHF + off]; };
             float bq[2][7];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = bp[kx];
+            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = tapval(0, kx);
 #pragma unroll
             for (int r = 0; r < 14; ++r) {
                 if (r + 1 < 14) {
                     const int cpn = (r + 1) / 7, kyn = (r + 1) % 7;
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = bp[cpn * 2 * CHF + kyn * ROWF + kx];
+                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = tapval(cpn, kyn * ROWF + kx);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
