@@ -19,7 +19,8 @@
 //                      accumulator of a 32-channel x 32-pixel tile is handed from wave w to wave w+1 through LDS,
 //                      so the result is ONE fmaf chain in the pinned order of include/dcll_hip.h; waves run
 //                      skewed by one tile (a systolic chain), one s_barrier per tile-stage.
-//   k_lif_seq_c1       first layer (c_in = 1, one input spike per step given as a cell index): VALU fmaf chain.
+//   k_lif_seq_c1       first layer (c_in = 1, one input spike per step as a cell index or raw IQ): fp32 MFMA with the
+//                      49 taps padded to 28 k-pairs by zero weights, weight-stationary, one sample per workgroup.
 //   k_trace / k_conv_lif / k_pool   generic per-step path (any geometry, state in HBM) — the exact drop-in for
 //                      `.forward`; same pinned order.
 //   k_dense_lif        DenseDCLLlayer step.
@@ -367,6 +368,7 @@ __global__ void k_bwd_outgrad(const float *__restrict__ g_o, const float *__rest
 // ------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int RO_ROWS = 128, RO_KC = 32, RO_LD = 33;
 
@@ -570,8 +572,14 @@ constexpr int C1_MAXT = 4096;       // longest window the fused IQ encoder of k_
 // Input either as cell indices (cells != NULL) or as raw IQ (iq != NULL): then the quantisation of iq2spiketrain
 // (data/utils.py:60-82, threshold form as in k_iq_encode) is fused here: thread t quantises sample t0+t (coalesced
 // loads of the I and the Q row of this window) and parks the cell index of step t in LDS.
+//
+// Conv as fp32 MFMA, weight-stationary: K = 49 taps, padded per kernel row to 8 = 4 MFMA k-pairs (kx 0|1, 2|3, 4|5,
+// 6|pad) with a ZERO weight on the pad tap: fmaf(x, 0, acc) == acc, so every channel still sees the pinned chain
+// bias, tap(0,0), tap(0,1), ... in order.  A = weights (lane: co = lane&31, kx parity = lane>>5; 28 VGPRs for the
+// whole sequence), B = eps1 from a zero-padded 22x24 LDS plane (per-lane base + immediate), D[co][pixel].
+// 4 waves = 8 pixel tiles of 32 (wave w: image rows 4w..4w+3); a thread also owns pixel `tid` of the traces.
 template <bool REFRACTORY>
-__global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
+__global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
                                                     const float *__restrict__ iq, const float *__restrict__ thr_i,
                                                     const float *__restrict__ thr_q, int L, int t0,
                                                     const float *__restrict__ W, const float *__restrict__ bias,
@@ -580,13 +588,16 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__
                                                     uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
                                                     float *__restrict__ v_out, int T, int B, float alpharp, float wrp)
 {
-    __shared__ float plane[PADW * PADW];
+    constexpr int PS = 24;                      // plane row stride: 16 + 2*3 padding + the pad tap's column
+    __shared__ float plane[22 * PS + 8];
+    __shared__ float sbias[32];
     __shared__ int scell[C1_MAXT];
-    const int b = blockIdx.x, pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63, wave = pix >> 6;
+    const int b = blockIdx.x, pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63;
+    const int w = __builtin_amdgcn_readfirstlane(pix >> 6);
+    const int h = lane >> 5, j = lane & 31;
     const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];
-    for (int i = pix; i < PADW * PADW; i += 256) plane[i] = 0.0f;
+    for (int i = pix; i < 22 * PS + 8; i += 256) plane[i] = 0.0f;
     if (iq) {
-        // fused encoder: thread t quantises sample t0+t of this window (coalesced loads of the I and the Q row)
         for (int t = pix; t < T; t += 256) {
             const float vi = iq[((long)b * 2 + 0) * L + t0 + t], vq = iq[((long)b * 2 + 1) * L + t0 + t];
             int ci = 0, cq = 0;
@@ -595,49 +606,75 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1(int c_out, const int32_t *__
         }
     }
     float e0 = eps0_g[(long)b * 256 + pix], e1 = eps1_g[(long)b * 256 + pix];
-    float arp[32];
+    // weight fragments: (ky, i): lane (co = j, kx = 2i + h); pad tap and channels >= c_out carry 0
+    float wf[7][4];
 #pragma unroll
-    for (int co = 0; co < 32; ++co) arp[co] = (REFRACTORY && co < c_out) ? arp_g[((long)b * c_out + co) * 256 + pix] : 0.0f;
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kx = 2 * i + h;
+            wf[ky][i] = (kx < 7 && j < c_out) ? W[j * 49 + ky * 7 + kx] : 0.0f;
+        }
+    // refractory trace of my two tiles: arp[tl][r] <-> channel (r&3)+8(r>>2)+4h, pixel 32*(2w+tl) + j
+    float arp[2][16];
+    if (pix < 32) sbias[pix] = pix < c_out ? bias[pix] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+            arp[tl][r] = (REFRACTORY && co < c_out) ? arp_g[((long)b * c_out + co) * 256 + 32 * (2 * w + tl) + j] : 0.0f;
+    }
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const int cell = iq ? scell[t] : cells[(long)t * B + b];
         trace_update(cell == pix ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0, e1);
-        plane[(y + 3) * PADW + x + 3] = e1;
-        __syncthreads();
-        float tap[49];
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) tap[ky * 7 + kx] = plane[(y + ky) * PADW + x + kx];
+        plane[(y + 3) * PS + x + 3] = e1;
         __syncthreads();
         const long obase = ((long)t * B + b) * c_out;
 #pragma unroll
-        for (int co = 0; co < 32; ++co) {
-            if (co < c_out) {       // wave-uniform
-                const float *w = W + co * 49;
-                float acc = bias[co];
+        for (int tl = 0; tl < 2; ++tl) {
+            const int m = 2 * w + tl;
+            const float *bp = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h;
+            f32x16 acc;
 #pragma unroll
-                for (int k = 0; k < 49; ++k) acc = __builtin_fmaf(tap[k], w[k], acc);
-                float v = acc;
+            for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ky][i], bp[ky * PS + 2 * i], acc, 0, 0, 0);
+            uint32_t myword = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[r];
                 bool s;
-                if (REFRACTORY) v = refractory(acc, arp[co], alpharp, wrp, s);
+                if (REFRACTORY) v = refractory(acc[r], arp[tl][r], alpharp, wrp, s);
                 else s = v > 0.0f;
-                unsigned long long m = __ballot(s);
-                if (spk_out) {
-                    if (lane == 0) spk_out[(obase + co) * 8 + wave * 2] = (uint32_t)m;
-                    if (lane == 32) spk_out[(obase + co) * 8 + wave * 2 + 1] = (uint32_t)(m >> 32);
+                unsigned long long mk = __ballot(s);
+                uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                myword = (j == r) ? mine : myword;
+                if (co < c_out) {
+                    if (pv_out) pv_out[(obase + co) * 256 + 32 * m + j] = sigmoidf_dev(v);
+                    if (v_out) v_out[(obase + co) * 256 + 32 * m + j] = v;
                 }
-                if (pv_out) pv_out[(obase + co) * 256 + pix] = sigmoidf_dev(v);
-                if (v_out) v_out[(obase + co) * 256 + pix] = v;
             }
+            const int cow = (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (spk_out && j < 16 && cow < c_out) spk_out[(obase + cow) * 8 + m] = myword;
         }
+        __syncthreads();
     }
     eps0_g[(long)b * 256 + pix] = e0;
     eps1_g[(long)b * 256 + pix] = e1;
     if (REFRACTORY) {
 #pragma unroll
-        for (int co = 0; co < 32; ++co)
-            if (co < c_out) arp_g[((long)b * c_out + co) * 256 + pix] = arp[co];
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+                if (co < c_out) arp_g[((long)b * c_out + co) * 256 + 32 * (2 * w + tl) + j] = arp[tl][r];
+        }
     }
 }
 
