@@ -486,6 +486,40 @@ __global__ __launch_bounds__(256) void k_readout_v4(const float *__restrict__ pv
     }
 }
 
+// Few rows (per-step calls: rows = batch): the 128-row tiles above would leave most CUs idle, so here one workgroup
+// takes ONE row, its 256 threads split K, and a fixed-order LDS tree combines them (deterministic, no atomics).
+constexpr int RS_MAXN = 64;
+__global__ __launch_bounds__(256) void k_readout_rows(const float *__restrict__ pv, const float *__restrict__ Wt,
+                                                       const float *__restrict__ bias, float *__restrict__ out, int K,
+                                                       int N)
+{
+    __shared__ float red[256];
+    const long row = blockIdx.x;
+    const float *p = pv + row * K;
+    float acc[RS_MAXN];
+#pragma unroll
+    for (int n = 0; n < RS_MAXN; ++n) acc[n] = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float a = p[k];
+#pragma unroll
+        for (int n = 0; n < RS_MAXN; ++n)
+            if (n < N) acc[n] = __builtin_fmaf(a, Wt[(long)n * K + k], acc[n]);
+    }
+    for (int n = 0; n < N; ++n) {
+        float val = 0.0f;
+#pragma unroll
+        for (int u = 0; u < RS_MAXN; ++u) val = (u == n) ? acc[u] : val;
+        __syncthreads();
+        red[threadIdx.x] = val;
+        __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) {
+            if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[row * N + n] = red[0] + (bias ? bias[n] : 0.0f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // argmax per (t,b) (first maximum, like torch.argmax) and vote per b (Counter.most_common(1): ties -> first seen)
 // ------------------------------------------------------------------------------------------------------------
@@ -1079,7 +1113,9 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
 {
     if (rows == 0 || N == 0) return DCLL_OK;
     const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0;
-    if (fast && N <= 32) {
+    if (rows <= 2048 && N <= RS_MAXN) {
+        hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)rows), dim3(256), 0, st, pv, Wt, bias, out, K, N);
+    } else if (fast && N <= 32) {
         hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast) {
         hipLaunchKernelGGL(k_readout_v4<2>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);

@@ -40,9 +40,16 @@ def _mode_first_seen(row):
     return Counter(row).most_common(1)[0][0]
 
 
+def _clout_to_numpy(pvoutput):
+    """clout as a (T,B) integer array; entries may be numpy arrays or (device) tensors appended without a sync."""
+    if len(pvoutput) and isinstance(pvoutput[0], torch.Tensor):
+        return torch.stack(list(pvoutput)).cpu().numpy()
+    return np.asarray(pvoutput)
+
+
 def get_predictions_by_vote(pvoutput, labels):
     """pvoutput: T arrays of per-sample argmax; labels: (T,B,C) one-hot tensor.  -> (pred (B), label (B))."""
-    votes = np.asarray(pvoutput).T
+    votes = _clout_to_numpy(pvoutput).T
     lab = labels.detach().cpu().numpy().argmax(axis=2).T
     pred = np.array([_mode_first_seen(r) for r in votes], dtype=np.float64)
     labv = np.array([_mode_first_seen(r) for r in lab], dtype=np.float64)
@@ -148,7 +155,18 @@ class ContinuousConv2D(nn.Module):
                                   self.stride, self.dilation, self.groups)
 
     def tau_per_channel(self):
-        """(4, C_in) tensor [alpha, tau_m, alphas, tau_s] if the time constants do not vary over (H,W), else None."""
+        """(4, C_in) tensor [alpha, tau_m, alphas, tau_s] if the time constants do not vary over (H,W), else None.
+        Cached until one of the four tensors is replaced or modified (the check costs a device sync)."""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self.alpha, self.tau_m__dt, self.alphas,
+                                                                        self.tau_s__dt))
+        cache = getattr(self, '_tau4_cache', None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        tau4 = self._tau_per_channel_uncached()
+        self._tau4_cache = (key, tau4)
+        return tau4
+
+    def _tau_per_channel_uncached(self):
         rows = []
         for t in (self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt):
             if t.numel() == 1:
@@ -169,12 +187,37 @@ class ContinuousConv2D(nn.Module):
                               output_ is not None)
         st = self.state
         arp = st.arp if len(st) > 2 else None
+        if getattr(self, 'binary_input', False) and self._fast_step_ok(input, pooling):
+            return self._step_packed(desc, input, st, arp, i2o, output_)
         with torch.no_grad():
             return ops.conv_lif_step(
                 desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt,
                 st.eps0, st.eps1, arp,
                 None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
                 None if output_ is None else output_.weight, None if output_ is None else output_.bias)
+
+    def _fast_step_ok(self, input, pooling):
+        """32->32, 7x7 pad 3, 16x16, pool 1, per-channel time constants: the MFMA sequence kernel serves one step."""
+        return (self.in_channels == 32 and self.out_channels == 32 and self.kernel_size == (7, 7) and
+                self.padding == (3, 3) and tuple(input.shape[2:4]) == (16, 16) and tuple(pooling) == (1, 1) and
+                self.stride == 1 and self.dilation == 1 and self.groups == 1 and self.bias is not None and
+                self.tau_per_channel() is not None)
+
+    def _step_packed(self, desc, input, st, arp, i2o, output_):
+        """One step through the weight-stationary MFMA kernel (T = 1, state in HBM) for layers whose input is known
+        to be a binary spike map (`binary_input`, set by ConvNetwork for every layer fed by another layer): bit-pack ->
+        k_lif_seq_c32 -> unpack; 20x faster than the generic per-step kernels and bit-identical to them."""
+        B = input.shape[0]
+        with torch.no_grad():
+            spk_in = ops.pack_spikes(input.reshape(B, 32, 256)).reshape(1, B, 32, 8)
+            spk, pv, v = ops.conv_lif_sequence(desc, spk_in, self.weight, self.bias, self.tau_per_channel(), st.eps0,
+                                               st.eps1, arp, 1, B, want_v=True)
+            s = ops.unpack_spikes(spk.reshape(B, 32, 8)).reshape(B, 32, 16, 16)
+            pv, v = pv[0], v[0]
+            flat = pv.reshape(B, -1)
+            p = ops.readout(flat, i2o.weight, i2o.bias) if i2o is not None else None
+            o = ops.readout(flat, output_.weight, output_.bias) if output_ is not None else None
+        return s, p, o, pv, v
 
     def forward(self, input):
         """-> (output spikes, pv, pvmem), un-pooled (reference :407-426)."""
@@ -554,6 +597,18 @@ class DCLLBase(nn.Module):
         self.slice_id = DCLLBase.num_instances
         DCLLBase.num_instances += 1
 
+    @property
+    def clout(self):
+        """Per-step argmax of the slice as the reference keeps it: a list of T numpy arrays (B,).  Internally the
+        entries stay on the device until somebody looks (one transfer instead of one sync per timestep)."""
+        if self._clout and isinstance(self._clout[0], torch.Tensor):
+            self._clout = list(torch.stack(self._clout).cpu().numpy())
+        return self._clout
+
+    @clout.setter
+    def clout(self, value):
+        self._clout = value
+
     def init(self, batch_size, init_states=True):
         self.clout = []
         self.activity_hist = []
@@ -565,15 +620,16 @@ class DCLLBase(nn.Module):
         self.iter += 1
         o, p, pv, pvmem = self.dclllayer.forward(input)
         if self.collect_stats and (self.iter % 20) == 0:
-            # the reference histograms pv on the host (19 bins) and later keeps only the first and last bin
-            self.activity_hist.append(np.histogram(pv.detach().cpu().numpy(), bins=self.stats_bins)[0])
+            # the reference histograms pv on the host (np.histogram, 19 bins over [0,1]); same bins on the device,
+            # only the 19 counts cross PCIe (and only when write_stats asks for them)
+            self.activity_hist.append(torch.histc(pv.detach().float(), bins=19, min=0.0, max=1.0))
         return o, p, pv, pvmem
 
     def write_stats(self, writer, label, epoch):
         writer.add_histogram(self.name + '/weight', self.dclllayer.i2h.weight.flatten(), epoch)
         writer.add_histogram(self.name + '/bias', self.dclllayer.i2h.bias.flatten(), epoch)
         if self.collect_stats and len(self.activity_hist):
-            pd = np.mean(self.activity_hist, axis=0)
+            pd = np.mean([h.cpu().numpy() if isinstance(h, torch.Tensor) else h for h in self.activity_hist], axis=0)
             pd = pd / pd.sum()
             writer.add_scalar(self.name + '/low_pv/' + label, pd[0], epoch)
             writer.add_scalar(self.name + '/high_pv/' + label, pd[-1], epoch)
@@ -619,13 +675,14 @@ class DCLLClassification(DCLLBase):
         o, p, pv, pvmem = super().forward(input)
         if ignore_burnin or self.iter >= self.burnin:
             logits = o if self.dclllayer.output_layer else p
-            self.clout.append(logits.argmax(1).detach().cpu().numpy())
+            # kept on the device (no sync per step, unlike the reference's .cpu() at :726-728); converted on demand
+            self._clout.append(logits.argmax(1).detach())
         return o, p, pv, pvmem
 
     def set_sequence_result(self, clout_dev, n_steps):
         """Install the per-step argmax of a whole-sequence run ((T,B) int32 on device) as `clout`."""
         self.iter += n_steps
-        self.clout = list(clout_dev.cpu().numpy().astype(np.int64))
+        self._clout = list(clout_dev.to(torch.int64))
 
     def write_stats(self, writer, label, epoch):
         super().write_stats(writer, label, epoch)
