@@ -101,12 +101,14 @@ int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, 
  *   incoming gradients (each may be NULL): g_p (B,target) of pvoutput, g_o (B,target) of the output_ logits,
  *   g_pv (B,c_out,ph,pw) of pv, g_v (B,c_out,ch,cw) of pvmem
  *   results: dW (c_out,c_in,kh,kw), db (c_out) [may be NULL]; d_outW (target, c_out*ph*pw), d_outb (target) iff g_o
- *   scratch: B*c_out*ch*cw floats.  i2o is frozen, neuron state detached, output_ sees pv.detach() (:570,:504,:606).
+ *   scratch: scratch_floats >= B*c_out*ch*cw + k*c_out*(c_in*kh*kw + 1) floats with k >= 1 batch chunks for the weight
+ *   gradient's partial sums (more chunks = more parallelism; up to 256 are used).
+ *   i2o is frozen, neuron state detached, output_ sees pv.detach() (:570,:504,:606).
  */
 int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
                            const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
                            const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
-                           float *scratch, int32_t B, void *stream);
+                           float *scratch, int64_t scratch_floats, int32_t B, void *stream);
 
 /* One timestep of DenseDCLLlayer.forward — drop-in for dcll/pytorch_libdcll.py:250-255 (dropout = identity). */
 int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W, const float *b,

@@ -49,7 +49,7 @@ SIGNATURES = {
     "dcll_last_error": (ctypes.c_char_p, []),
     "dcll_conv_out_shape": (_I32, [_DP, _IP, _IP, _IP, _IP]),
     "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_I32, _P]),
-    "dcll_conv_lif_backward": (_I32, [_DP] + [_P] * 13 + [_I32, _P]),
+    "dcll_conv_lif_backward": (_I32, [_DP] + [_P] * 13 + [_I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
     "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _I32, _I32, _P]),
     "dcll_permute_readout": (_I32, [_P, _P, _I32, _P]),

@@ -34,6 +34,15 @@
 
 #include "../../include/dcll_hip.h"
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// geometry of the LDS-resident 32-channel 16x16 eps1 image shared by k_lif_seq_c32 and k_bwd_wgrad_c32
+constexpr int NWAVE = 8, CPW = 4, ROWF = 19, CHF = 361;
+constexpr int IMG_FLOATS = ((32 * CHF + 3 * ROWF + 3 + 61) + 3) & ~3;     // 11676 >= offset of (ci=31, y=18, x=18) + 1
+constexpr int SLOT_FLOATS = 16 * 64;
+
 // ------------------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------------------
@@ -294,11 +303,12 @@ __global__ void k_bwd_dv(dcll_conv_desc d, int ch, int cw, int ph, int pw, const
 }
 
 // dW[co,ci,ky,kx] = sum_{b,y,x} gvf[b,co,y,x] * eps1[b,ci,y+ky-pad,x+kx-pad];  db[co] = sum gvf[b,co,:,:]
-// one workgroup per (co, ci); thread = conv output position (strided), per-thread tap accumulators, LDS tree at the end.
+// Generic kernel: workgroup (co*ci, chunk) sums the samples b = chunk, chunk + nchunk, ... into the partial row
+// part[chunk][co][ci*ntap + tap] (row length c_in*ntap + 1, the last entry = bias gradient); k_bwd_reduce adds the
+// chunks in a fixed order.  thread = conv output position (strided), per-thread tap accumulators, LDS tree at the end.
 constexpr int WG_MAXTAPS = 64;
 __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int cw, const float *__restrict__ gvf,
-                                                    const float *__restrict__ eps1, float *__restrict__ dW,
-                                                    float *__restrict__ db, int B)
+                                                    const float *__restrict__ eps1, float *__restrict__ part, int B)
 {
     extern __shared__ float sm[];
     const int co = blockIdx.x / d.c_in, ci = blockIdx.x % d.c_in;
@@ -310,7 +320,9 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
     for (int t = 0; t < WG_MAXTAPS; ++t) acc[t] = 0.0f;
     float accb = 0.0f;
     for (int i = threadIdx.x; i < HP * WP; i += 256) e[i] = 0.0f;
-    for (int b = 0; b < B; ++b) {
+    const long rowlen = (long)d.c_in * ntap + 1;
+    float *prow = part + ((long)blockIdx.y * d.c_out + co) * rowlen;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
         const float *ep = eps1 + ((long)b * d.c_in + ci) * d.h * d.w;
         for (int i = threadIdx.x; i < d.h * d.w; i += 256) e[(i / d.w + d.pad_h) * WP + (i % d.w) + d.pad_w] = ep[i];
@@ -338,10 +350,91 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            if (t < ntap) dW[((long)co * d.c_in + ci) * ntap + t] = red[0];
-            else if (ci == 0 && db) db[co] = red[0];
+            if (t < ntap) prow[(long)ci * ntap + t] = red[0];
+            else if (ci == 0) prow[rowlen - 1] = red[0];
         }
     }
+}
+
+// Weight gradient of the 32 -> 32, 7x7, 16x16 layers as fp32 MFMA: dW[co][n] = sum_{b,pix} g[b,co,pix] * E[b][n][pix],
+// n = ci*49 + tap (1568 columns = 49 tiles of 32), E = zero-padded eps1 (same compact LDS image as k_lif_seq_c32).
+// One workgroup takes samples b = blockIdx.x, + gridDim.x, ...; per sample g (32 x 256, row stride 257 against bank
+// conflicts) and the image are staged in LDS; wave w accumulates column tiles w, w+8, ... (7 x 16 accumulator
+// registers) over the 128 pixel pairs: A[co][pixel pair], B[pixel pair][column] = one ds_read at an immediate offset
+// from the column's lane base.  Partial sums go to part[workgroup][co][1568 + 1] (k_bwd_reduce adds them in order).
+constexpr int WG32_GLD = 257;
+__global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__ gvf, const float *__restrict__ eps1,
+                                                        float *__restrict__ part, int B)
+{
+    __shared__ __attribute__((aligned(16))) float lds[IMG_FLOATS + 32 * WG32_GLD];
+    float *img = lds, *gl = lds + IMG_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = (w == 0) ? 7 : 6;
+    for (int i = tid; i < IMG_FLOATS; i += 512) img[i] = 0.0f;
+    int bbase[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int n = (w + 8 * q) * 32 + j;                  // my column in tile q (n < 1568 for q < ntile)
+        const int nn = n < 1568 ? n : 0;
+        const int ci = nn / 49, tap = nn % 49;
+        bbase[q] = ci * CHF + (tap / 7) * ROWF + (tap % 7) + h;
+    }
+    f32x16 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    float bsum = 0.0f;                                        // wave w, lanes: co = 4w + (lane>>4), 16 pixels per pass
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < 32 * 256; i += 512) {
+            const int c = i >> 8, p = i & 255;
+            gl[c * WG32_GLD + p] = gvf[(long)b * 8192 + i];
+            img[c * CHF + ((p >> 4) + 3) * ROWF + (p & 15) + 3] = eps1[(long)b * 8192 + i];
+        }
+        __syncthreads();
+        {   // bias gradient: co = 4w + lane/16, pixels lane%16 + 16*k
+            const float *gr = gl + (4 * w + (lane >> 4)) * WG32_GLD + (lane & 15);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) bsum += gr[16 * k];
+        }
+        const float *ga = gl + j * WG32_GLD + h;              // A: co = j, pixel p + h
+#pragma unroll 4
+        for (int pp = 0; pp < 128; ++pp) {
+            const int p = 2 * pp;
+            const float a = ga[p];
+            const int poff = (p >> 4) * ROWF + (p & 15);
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+                if (q < ntile) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
+        }
+    }
+    float *pw = part + (long)blockIdx.x * 32 * 1569;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+        if (q < ntile) {
+            const int n = (w + 8 * q) * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * 1569 + n] = acc[q][r];
+        }
+    // bias partial: reduce the 16 lanes of each co group
+    bsum += __shfl_xor(bsum, 1); bsum += __shfl_xor(bsum, 2); bsum += __shfl_xor(bsum, 4); bsum += __shfl_xor(bsum, 8);
+    if ((lane & 15) == 0) pw[(long)(4 * w + (lane >> 4)) * 1569 + 1568] = bsum;
+}
+
+// dW / db = fixed-order sum of the partial rows part[chunk][co][rowlen] (rowlen = c_in*ntap + 1, last = bias gradient)
+__global__ void k_bwd_reduce(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int nchunk,
+                             int c_out, long rowlen)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c_out * rowlen) return;
+    const int co = (int)(i / rowlen);
+    const long n = i % rowlen;
+    float acc = 0.0f;
+    for (int c = 0; c < nchunk; ++c) acc += part[((long)c * c_out + co) * rowlen + n];
+    if (n < rowlen - 1) dW[(long)co * (rowlen - 1) + n] = acc;
+    else if (db) db[co] = acc;
 }
 
 // d_outW[n,k] = sum_b g_o[b,n] * pvp[b,k];  d_outb[n] = sum_b g_o[b,n]      (output_ sees pv.detach())
@@ -366,9 +459,6 @@ __global__ void k_bwd_outgrad(const float *__restrict__ g_o, const float *__rest
 //   workgroup = 4 waves = 128 rows x 32 columns; K in chunks of 32 staged through LDS (row stride 33: conflict-free
 //   column reads of the v_mfma_f32_32x32x2_f32 fragments).
 // ------------------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int RO_ROWS = 128, RO_KC = 32, RO_LD = 33;
 
@@ -740,9 +830,6 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
 //     by accumulator register quad over the 4 waves with (w>>2) == (m&1); wave w owns quad w&3 (channels
 //     rr + 8*(w&3) + 4*(lane>>5)) of the tiles of its parity and keeps their 16 arp values in registers.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int NWAVE = 8, CPW = 4, ROWF = 19, CHF = 361;
-constexpr int IMG_FLOATS = ((32 * CHF + 3 * ROWF + 3 + 61) + 3) & ~3;     // 11676 >= offset of (ci=31, y=18, x=18) + 1
-constexpr int SLOT_FLOATS = 16 * 64;
 
 // ABLATE is a diagnostic knob for experiments/ablate_c32.hip only (bit0: no epilogue, bit1: no trace update,
 // bit2: no accumulator hand-off); every product launch uses ABLATE = 0.
@@ -1211,7 +1298,7 @@ extern "C" int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, con
 extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
                                       const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
                                       const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
-                                      float *scratch, int32_t B, void *stream)
+                                      float *scratch, int64_t scratch_floats, int32_t B, void *stream)
 {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -1227,10 +1314,30 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
     hipLaunchKernelGGL(k_bwd_dv, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, v, g_p, g_pv, g_v, i2o_W,
                        scratch, nconv);
     HIP_CHECK_LAUNCH("k_bwd_dv");
-    const size_t lds = ((size_t)(d->h + 2 * d->pad_h) * (d->w + 2 * d->pad_w) + 256) * sizeof(float);
-    if (lds > 60 * 1024) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: input plane too large for the LDS-resident weight-gradient kernel");
-    hipLaunchKernelGGL(k_bwd_wgrad, dim3(d->c_out * d->c_in), dim3(256), lds, st, *d, ch, cw, scratch, eps1, dW, db, B);
-    HIP_CHECK_LAUNCH("k_bwd_wgrad");
+    // weight gradient: partial sums over batch chunks (after the g_v_full plane in scratch), then a fixed-order reduce
+    const long rowlen = (long)d->c_in * d->kh * d->kw + 1;
+    const long per_chunk = (long)d->c_out * rowlen;
+    float *part = scratch + nconv;
+    long nchunk = (scratch_floats - nconv) / per_chunk;
+    if (nchunk < 1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: scratch too small (need B*c_out*ch*cw + k*(c_out*(c_in*kh*kw+1)), k >= 1)");
+    const bool c32 = d->c_in == 32 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 &&
+                     d->h == 16 && d->w == 16;
+    if (c32) {
+        if (nchunk > 256) nchunk = 256;
+        if (nchunk > B) nchunk = B;
+        hipLaunchKernelGGL(k_bwd_wgrad_c32, dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1, part, B);
+        HIP_CHECK_LAUNCH("k_bwd_wgrad_c32");
+    } else {
+        const size_t lds = ((size_t)(d->h + 2 * d->pad_h) * (d->w + 2 * d->pad_w) + 256) * sizeof(float);
+        if (lds > 60 * 1024) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: input plane too large for the LDS-resident weight-gradient kernel");
+        if (nchunk > 64) nchunk = 64;
+        if (nchunk > B) nchunk = B;
+        hipLaunchKernelGGL(k_bwd_wgrad, dim3(d->c_out * d->c_in, (unsigned)nchunk), dim3(256), lds, st, *d, ch, cw, scratch,
+                           eps1, part, B);
+        HIP_CHECK_LAUNCH("k_bwd_wgrad");
+    }
+    hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+    HIP_CHECK_LAUNCH("k_bwd_reduce");
     if (g_o) {
         const int K = d->c_out * ph * pw;
         hipLaunchKernelGGL(k_bwd_outgrad, dim3(nblk((long)d->target * (K + 1), 256)), dim3(256), 0, st, g_o, pv_pooled,

@@ -70,11 +70,13 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
     K = desc.c_out * ph * pw
     d_outW = torch.empty((desc.target, K), device=dev, dtype=torch.float32) if want_out else None
     d_outb = torch.empty((desc.target,), device=dev, dtype=torch.float32) if want_out else None
-    scratch = torch.empty((B, desc.c_out, ch, cw), device=dev, dtype=torch.float32)
+    nchunk = min(B, 256)
+    n_scratch = B * desc.c_out * ch * cw + nchunk * desc.c_out * (desc.c_in * desc.kh * desc.kw + 1)
+    scratch = torch.empty((n_scratch,), device=dev, dtype=torch.float32)
     c = lambda t: None if t is None else _f32(t, "grad").contiguous()
     rc = _lib.get().dcll_conv_lif_backward(
         ctypes.byref(desc), ptr(eps1), ptr(v), ptr(pv_pooled), ptr(c(g_p)), ptr(c(g_o) if want_out else None),
-        ptr(c(g_pv)), ptr(c(g_v)), ptr(i2o_W), ptr(dW), ptr(db), ptr(d_outW), ptr(d_outb), ptr(scratch), B,
+        ptr(c(g_pv)), ptr(c(g_v)), ptr(i2o_W), ptr(dW), ptr(db), ptr(d_outW), ptr(d_outb), ptr(scratch), n_scratch, B,
         stream_ptr())
     check(rc, "dcll_conv_lif_backward")
     return dW, db, d_outW, d_outb
