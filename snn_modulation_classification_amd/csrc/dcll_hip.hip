@@ -1217,6 +1217,7 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
 extern "C" int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out, int64_t rows, int32_t K,
                             int32_t N, void *stream)
 {
+    if (rows == 0) return DCLL_OK;
     if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1) return fail(DCLL_ERR_INVALID, "dcll_readout: bad argument");
     return launch_readout(pv, Wt, bias, out, rows, K, N, (hipStream_t)stream);
 }
@@ -1229,6 +1230,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
 {
     int rc = check_desc(d);
     if (rc) return rc;
+    if (B == 0) return DCLL_OK;
     if (!x || !W || !alpha || !tau_m || !alphas || !tau_s || !eps0 || !eps1 || !out_s || !out_pv)
         return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: refractory layer needs arp");
@@ -1278,6 +1280,7 @@ extern "C" int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, con
                                    float *out_s, float *out_p, float *out_pv, float *out_v, int32_t B, void *stream)
 {
     if (!d || d->in_features < 1 || d->out_features < 1) return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: bad descriptor");
+    if (B == 0) return DCLL_OK;
     if (!x || !W || !alpha || !tau_m || !alphas || !tau_s || !eps0 || !eps1 || !out_pv)
         return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: refractory layer needs arp");
@@ -1391,13 +1394,13 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
 {
     int rc = check_seq_geometry(d, 32, "dcll_conv_lif_sequence");
     if (rc) return rc;
+    if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
     if (!spk_in || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: refractory layer needs arp");
     if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: negative size");
     if (n_ro != 0 && n_ro != 24 && n_ro != 48)
         return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout supports 24 or 48 rows (target 24)");
     if (n_ro && (!ro_Wp || !ro_b || !ro_out)) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: fused readout needs ro_Wp, ro_b, ro_out");
-    if (T == 0 || B == 0) return DCLL_OK;
     hipStream_t st = (hipStream_t)stream;
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
 #define DCLL_ARGS out, B, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out, T, d->alpharp, d->wrp
@@ -1436,10 +1439,10 @@ extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32
 {
     int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_cells");
     if (rc) return rc;
+    if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
     if (!cells || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: refractory layer needs arp");
     if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: negative size");
-    if (T == 0 || B == 0) return DCLL_OK;
     return launch_c1(d, cells, nullptr, nullptr, nullptr, 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B,
                      (hipStream_t)stream);
 }
@@ -1451,11 +1454,11 @@ extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *i
 {
     int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_iq");
     if (rc) return rc;
+    if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
     if (!iq || !thr_i || !thr_q || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: refractory layer needs arp");
     if (T < 0 || B < 0 || t0 < 0 || t0 + T > L) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: window [t0, t0+T) outside the IQ row");
     if (T > C1_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence_iq: at most 4096 timesteps per launch");
-    if (T == 0 || B == 0) return DCLL_OK;
     return launch_c1(d, nullptr, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B,
                      (hipStream_t)stream);
 }
@@ -1463,6 +1466,7 @@ extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *i
 extern "C" int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t T, int32_t B, int32_t N,
                                 int32_t t_begin, void *stream)
 {
+    if (T == 0 || B == 0) return DCLL_OK;
     if (!logits || !clout || T < 0 || B < 0 || N < 1) return fail(DCLL_ERR_INVALID, "dcll_argmax_vote: bad argument");
     if (vote && N > VOTE_MAXN) return fail(DCLL_ERR_UNSUPPORTED, "dcll_argmax_vote: vote supports at most 64 classes");
     if (T == 0 || B == 0) return DCLL_OK;
@@ -1491,6 +1495,7 @@ extern "C" int dcll_iq_encode(const float *iq, const float *thr_i, const float *
 
 extern "C" int dcll_unpack_spikes(const uint32_t *packed, float *dense, int64_t nwords, void *stream)
 {
+    if (nwords == 0) return DCLL_OK;
     if (!packed || !dense || nwords < 0) return fail(DCLL_ERR_INVALID, "dcll_unpack_spikes: bad argument");
     if (nwords == 0) return DCLL_OK;
     hipLaunchKernelGGL(k_unpack, dim3(nblk(nwords * 32, 256)), dim3(256), 0, (hipStream_t)stream, packed, dense, (long)nwords);
@@ -1500,6 +1505,7 @@ extern "C" int dcll_unpack_spikes(const uint32_t *packed, float *dense, int64_t 
 
 extern "C" int dcll_pack_spikes(const float *dense, uint32_t *packed, int64_t nwords, void *stream)
 {
+    if (nwords == 0) return DCLL_OK;
     if (!packed || !dense || nwords < 0) return fail(DCLL_ERR_INVALID, "dcll_pack_spikes: bad argument");
     if (nwords == 0) return DCLL_OK;
     hipLaunchKernelGGL(k_pack, dim3(nblk(nwords * 32, 256)), dim3(256), 0, (hipStream_t)stream, dense, packed, (long)nwords);

@@ -390,3 +390,41 @@ def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
     if m["output_layer"]:
         np.testing.assert_allclose(doW.cpu().numpy(), layer.out_w.grad.numpy(), **tol(layer.out_w.grad))
         np.testing.assert_allclose(dob.cpu().numpy(), layer.out_b.grad.numpy(), **tol(layer.out_b.grad))
+
+
+def test_edge_cases_empty_and_single(dev):
+    """Empty batch / zero timesteps are no-ops, B = 1 and T = 1 work (the reference itself breaks at B = 1 in
+    iq2spiketrain's squeeze), invalid windows are rejected with ValueError."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(2)
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
+    d = ops.make_conv_desc(32, 32, (16, 16), 7, 3, 1, 24, False, True, 1.0)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    z = lambda B: [torch.zeros((B, 32, 16, 16), device=dev) for _ in range(3)]
+    # T = 0 and B = 0: nothing happens, nothing crashes
+    st = z(2)
+    spk, pv, _ = ops.conv_lif_sequence(d, torch.zeros((0, 2, 32, 8), device=dev, dtype=torch.int32), cu(W, dev), cu(b, dev),
+                                       tau4, *st, 0, 2)
+    assert spk.shape == (0, 2, 32, 8) and all(float(s.abs().sum()) == 0 for s in st)
+    spk, pv, _ = ops.conv_lif_sequence(d, torch.zeros((3, 0, 32, 8), device=dev, dtype=torch.int32), cu(W, dev), cu(b, dev),
+                                       tau4, *z(0), 3, 0)
+    assert spk.shape == (3, 0, 32, 8)
+    assert ops.readout(torch.zeros((0, 64), device=dev), torch.zeros((5, 64), device=dev), None).shape == (0, 5)
+    assert ops.pack_spikes(torch.zeros((0, 32), device=dev)).shape == (0, 1)
+    # B = 1, T = 1 against the oracle
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, (16, 16), rng=rng)
+    orc = C.OracleConvLayer(sd, (16, 16), 3, 1, 1.0)
+    x = (rng.uniform(size=(1, 1, 32, 256)) < 0.3).astype(np.float32)
+    st = z(1)
+    spk, pv, v = ops.conv_lif_sequence(d, ops.pack_spikes(cu(x, dev)), cu(W, dev), cu(b, dev), tau4, *st, 1, 1, want_v=True)
+    oo, op, opv, ov, os_ = orc.forward(x[0].reshape(1, 32, 16, 16))
+    assert bits_equal(v[0].cpu().numpy(), ov)
+    assert np.array_equal(ops.unpack_spikes(spk).cpu().numpy().reshape(1, 32, 16, 16), os_)
+    # invalid IQ window
+    with pytest.raises(ValueError):
+        ops.iq_encode(torch.zeros((2, 2, 16), device=dev), torch.zeros(15, device=dev), torch.zeros(15, device=dev),
+                      10, 8, 16, 16)
+    # vote over an empty window (t_begin == T): no class has a vote -> -1
+    c, vt = ops.argmax_vote(torch.zeros((4, 3, 5), device=dev), t_begin=4)
+    assert vt.cpu().tolist() == [-1, -1, -1] and c.shape == (4, 3)
