@@ -197,6 +197,85 @@ __global__ void k_conv_lif(dcll_conv_desc d, int ch, int cw, const float *__rest
     pv_full[i] = sigmoidf_dev(v);
 }
 
+// Tiled version of k_conv_lif for the common kernel sizes: a workgroup computes a 16x16 tile of output pixels for COG
+// output channels.  Per input-channel pair the (16+KH-1)x(16+KW-1) input tiles and the COG x KH*KW x 2 weights are
+// staged in LDS; a thread keeps the two KH x KW windows of its pixel in registers and runs COG independent fmaf
+// chains in the pinned order (cp, ky, kx, h) — bit-identical to k_conv_lif, ~100x faster (weights come as LDS
+// broadcasts, inputs from registers).  Out-of-image taps and channels beyond c_in contribute fmaf(0, w, acc).
+template <int KH, int KW, int COG>
+__global__ __launch_bounds__(256) void k_conv_lif_tiled(dcll_conv_desc d, int ch, int cw, const float *__restrict__ eps1,
+                                                         const float *__restrict__ W, const float *__restrict__ bias,
+                                                         float *__restrict__ arp, float *__restrict__ s_full,
+                                                         float *__restrict__ pv_full, float *__restrict__ v_out)
+{
+    constexpr int IH = 16 + KH - 1, IW = 16 + KW - 1, KK = KH * KW;
+    __shared__ float in[2][IH * IW];
+    __shared__ __attribute__((aligned(16))) float wl[COG * KK * 2];
+    const int ntx = (cw + 15) >> 4;
+    const int tx0 = (blockIdx.x % ntx) * 16, ty0 = (blockIdx.x / ntx) * 16;
+    const int co0 = blockIdx.y * COG;
+    const long b = blockIdx.z;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    float acc[COG];
+#pragma unroll
+    for (int c = 0; c < COG; ++c) acc[c] = (bias && co0 + c < d.c_out) ? bias[co0 + c] : 0.0f;
+    const float *eb = eps1 + b * d.c_in * d.h * d.w;
+    const int npair = (d.c_in + 1) >> 1;
+    for (int cp = 0; cp < npair; ++cp) {
+        __syncthreads();
+        for (int i = tid; i < 2 * IH * IW; i += 256) {
+            const int hh = i / (IH * IW), r = i % (IH * IW);
+            const int yy = ty0 + r / IW - d.pad_h, xx = tx0 + r % IW - d.pad_w, ci = 2 * cp + hh;
+            const bool ok = ci < d.c_in && yy >= 0 && yy < d.h && xx >= 0 && xx < d.w;
+            in[hh][r] = ok ? eb[((long)ci * d.h + yy) * d.w + xx] : 0.0f;
+        }
+        for (int i = tid; i < COG * KK * 2; i += 256) {
+            const int hh = i & 1, tap = (i >> 1) % KK, c = (i >> 1) / KK, ci = 2 * cp + hh;
+            wl[i] = (co0 + c < d.c_out && ci < d.c_in) ? W[((long)(co0 + c) * d.c_in + ci) * KK + tap] : 0.0f;
+        }
+        __syncthreads();
+        float win[2][KK];
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                win[0][ky * KW + kx] = in[0][(ly + ky) * IW + lx + kx];
+                win[1][ky * KW + kx] = in[1][(ly + ky) * IW + lx + kx];
+            }
+#pragma unroll
+        for (int c = 0; c < COG; ++c) {
+            const f32x2 *wp = (const f32x2 *)(wl + c * KK * 2);
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const f32x2 w2 = wp[tap];
+                acc[c] = __builtin_fmaf(win[0][tap], w2[0], acc[c]);
+                acc[c] = __builtin_fmaf(win[1][tap], w2[1], acc[c]);
+            }
+        }
+    }
+    if (oy < ch && ox < cw) {
+#pragma unroll
+        for (int c = 0; c < COG; ++c) {
+            if (co0 + c < d.c_out) {
+                const long i = ((b * d.c_out + co0 + c) * ch + oy) * cw + ox;
+                float v = acc[c];
+                bool s;
+                if (d.refractory) {
+                    float a = arp[i];
+                    v = refractory(acc[c], a, d.alpharp, d.wrp, s);
+                    arp[i] = a;
+                } else {
+                    s = v > 0.0f;
+                }
+                if (v_out) v_out[i] = v;
+                s_full[i] = s ? 1.0f : 0.0f;
+                pv_full[i] = sigmoidf_dev(v);
+            }
+        }
+    }
+}
+
 // MaxPool2d(kernel=stride=pool, padding=(pool-1)/2), one thread per pooled element.
 __global__ void k_pool(dcll_conv_desc d, int ch, int cw, int ph, int pw, const float *__restrict__ s_full,
                        const float *__restrict__ pv_full, float *__restrict__ s_out, float *__restrict__ pv_out, long n)
@@ -577,37 +656,39 @@ __global__ __launch_bounds__(256) void k_readout_v4(const float *__restrict__ pv
 }
 
 // Few rows (per-step calls: rows = batch): the 128-row tiles above would leave most CUs idle, so here one workgroup
-// takes ONE row, its 256 threads split K, and a fixed-order LDS tree combines them (deterministic, no atomics).
-constexpr int RS_MAXN = 64;
+// takes ONE row and RS_NG readout rows of Wt (grid = rows x ceil(N / RS_NG): also enough workgroups when K is huge,
+// e.g. 32*128*128 on the 128x128 plane), its 256 threads stride over K, and a fixed-order LDS tree combines them
+// (deterministic, no atomics).
+constexpr int RS_NG = 4;
 __global__ __launch_bounds__(256) void k_readout_rows(const float *__restrict__ pv, const float *__restrict__ Wt,
                                                        const float *__restrict__ bias, float *__restrict__ out, int K,
                                                        int N)
 {
-    __shared__ float red[256];
+    __shared__ float red[RS_NG][256];
     const long row = blockIdx.x;
+    const int n0 = blockIdx.y * RS_NG;
     const float *p = pv + row * K;
-    float acc[RS_MAXN];
+    float acc[RS_NG];
 #pragma unroll
-    for (int n = 0; n < RS_MAXN; ++n) acc[n] = 0.0f;
+    for (int u = 0; u < RS_NG; ++u) acc[u] = 0.0f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float a = p[k];
 #pragma unroll
-        for (int n = 0; n < RS_MAXN; ++n)
-            if (n < N) acc[n] = __builtin_fmaf(a, Wt[(long)n * K + k], acc[n]);
+        for (int u = 0; u < RS_NG; ++u)
+            if (n0 + u < N) acc[u] = __builtin_fmaf(a, Wt[(long)(n0 + u) * K + k], acc[u]);
     }
-    for (int n = 0; n < N; ++n) {
-        float val = 0.0f;
 #pragma unroll
-        for (int u = 0; u < RS_MAXN; ++u) val = (u == n) ? acc[u] : val;
-        __syncthreads();
-        red[threadIdx.x] = val;
-        __syncthreads();
-        for (int sft = 128; sft > 0; sft >>= 1) {
-            if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
-            __syncthreads();
+    for (int u = 0; u < RS_NG; ++u) red[u][threadIdx.x] = acc[u];
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (threadIdx.x < sft) {
+#pragma unroll
+            for (int u = 0; u < RS_NG; ++u) red[u][threadIdx.x] += red[u][threadIdx.x + sft];
         }
-        if (threadIdx.x == 0) out[row * N + n] = red[0] + (bias ? bias[n] : 0.0f);
+        __syncthreads();
     }
+    if (threadIdx.x < RS_NG && n0 + threadIdx.x < N)
+        out[row * N + n0 + threadIdx.x] = red[threadIdx.x][0] + (bias ? bias[n0 + threadIdx.x] : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1200,8 +1281,9 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
 {
     if (rows == 0 || N == 0) return DCLL_OK;
     const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0;
-    if (rows <= 2048 && N <= RS_MAXN) {
-        hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)rows), dim3(256), 0, st, pv, Wt, bias, out, K, N);
+    if (rows <= 2048) {
+        hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)rows, (N + RS_NG - 1) / RS_NG), dim3(256), 0, st, pv, Wt, bias, out,
+                           K, N);
     } else if (fast && N <= 32) {
         hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast) {
@@ -1253,8 +1335,21 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
         s_full = scratch;
         pv_full = scratch + nconv;
     }
-    hipLaunchKernelGGL(k_conv_lif, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, eps1, W, b, arp, s_full,
-                       pv_full, out_v, nconv);
+    {
+        constexpr int COG = 8;
+        const dim3 tg(((cw + 15) / 16) * ((ch + 15) / 16), (d->c_out + COG - 1) / COG, B);
+        const bool tile_ok = ch >= 8 && cw >= 8 && B <= 65535;
+#define DCLL_TILED(KH_, KW_)                                                                                          \
+    hipLaunchKernelGGL((k_conv_lif_tiled<KH_, KW_, COG>), tg, dim3(256), 0, st, *d, ch, cw, eps1, W, b, arp, s_full,    \
+                       pv_full, out_v)
+        if (tile_ok && d->kh == 7 && d->kw == 7) DCLL_TILED(7, 7);
+        else if (tile_ok && d->kh == 5 && d->kw == 5) DCLL_TILED(5, 5);
+        else if (tile_ok && d->kh == 3 && d->kw == 3) DCLL_TILED(3, 3);
+        else
+            hipLaunchKernelGGL(k_conv_lif, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, eps1, W, b, arp, s_full,
+                               pv_full, out_v, nconv);
+#undef DCLL_TILED
+    }
     HIP_CHECK_LAUNCH("k_conv_lif");
     if (pooled) {
         hipLaunchKernelGGL(k_pool, dim3(nblk(npool, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, s_full, pv_full, out_s,
