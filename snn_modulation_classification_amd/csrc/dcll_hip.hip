@@ -656,39 +656,49 @@ __global__ __launch_bounds__(256) void k_readout_v4(const float *__restrict__ pv
 }
 
 // Few rows (per-step calls: rows = batch): the 128-row tiles above would leave most CUs idle, so here one workgroup
-// takes ONE row and RS_NG readout rows of Wt (grid = rows x ceil(N / RS_NG): also enough workgroups when K is huge,
+// takes RS_RB rows and RS_NG readout rows of Wt (grid = rows/RS_RB x ceil(N / RS_NG): enough workgroups even when K is huge,
 // e.g. 32*128*128 on the 128x128 plane), its 256 threads stride over K, and a fixed-order LDS tree combines them
 // (deterministic, no atomics).
-constexpr int RS_NG = 4;
+constexpr int RS_NG = 4, RS_RB = 4;
 __global__ __launch_bounds__(256) void k_readout_rows(const float *__restrict__ pv, const float *__restrict__ Wt,
-                                                       const float *__restrict__ bias, float *__restrict__ out, int K,
-                                                       int N)
+                                                       const float *__restrict__ bias, float *__restrict__ out,
+                                                       long rows, int K, int N)
 {
-    __shared__ float red[RS_NG][256];
-    const long row = blockIdx.x;
+    __shared__ float red[RS_RB * RS_NG][256];
+    const long row0 = (long)blockIdx.x * RS_RB;
     const int n0 = blockIdx.y * RS_NG;
-    const float *p = pv + row * K;
-    float acc[RS_NG];
+    float acc[RS_RB][RS_NG];
 #pragma unroll
-    for (int u = 0; u < RS_NG; ++u) acc[u] = 0.0f;
+    for (int r = 0; r < RS_RB; ++r)
+#pragma unroll
+        for (int u = 0; u < RS_NG; ++u) acc[r][u] = 0.0f;
     for (int k = threadIdx.x; k < K; k += 256) {
-        const float a = p[k];
+        float a[RS_RB], w[RS_NG];
 #pragma unroll
-        for (int u = 0; u < RS_NG; ++u)
-            if (n0 + u < N) acc[u] = __builtin_fmaf(a, Wt[(long)(n0 + u) * K + k], acc[u]);
+        for (int r = 0; r < RS_RB; ++r) a[r] = row0 + r < rows ? pv[(row0 + r) * K + k] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < RS_NG; ++u) w[u] = n0 + u < N ? Wt[(long)(n0 + u) * K + k] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < RS_RB; ++r)
+#pragma unroll
+            for (int u = 0; u < RS_NG; ++u) acc[r][u] = __builtin_fmaf(a[r], w[u], acc[r][u]);
     }
 #pragma unroll
-    for (int u = 0; u < RS_NG; ++u) red[u][threadIdx.x] = acc[u];
+    for (int r = 0; r < RS_RB; ++r)
+#pragma unroll
+        for (int u = 0; u < RS_NG; ++u) red[r * RS_NG + u][threadIdx.x] = acc[r][u];
     __syncthreads();
     for (int sft = 128; sft > 0; sft >>= 1) {
         if (threadIdx.x < sft) {
 #pragma unroll
-            for (int u = 0; u < RS_NG; ++u) red[u][threadIdx.x] += red[u][threadIdx.x + sft];
+            for (int q = 0; q < RS_RB * RS_NG; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + sft];
         }
         __syncthreads();
     }
-    if (threadIdx.x < RS_NG && n0 + threadIdx.x < N)
-        out[row * N + n0 + threadIdx.x] = red[threadIdx.x][0] + (bias ? bias[n0 + threadIdx.x] : 0.0f);
+    if (threadIdx.x < RS_RB * RS_NG) {
+        const int r = threadIdx.x / RS_NG, u = threadIdx.x % RS_NG;
+        if (row0 + r < rows && n0 + u < N) out[(row0 + r) * N + n0 + u] = red[threadIdx.x][0] + (bias ? bias[n0 + u] : 0.0f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1282,8 +1292,8 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
     if (rows == 0 || N == 0) return DCLL_OK;
     const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0;
     if (rows <= 2048) {
-        hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)rows, (N + RS_NG - 1) / RS_NG), dim3(256), 0, st, pv, Wt, bias, out,
-                           K, N);
+        hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)((rows + RS_RB - 1) / RS_RB), (N + RS_NG - 1) / RS_NG), dim3(256),
+                           0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast && N <= 32) {
         hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast) {
