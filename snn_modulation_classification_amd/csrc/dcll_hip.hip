@@ -1355,6 +1355,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
         if (tile_ok && d->kh == 7 && d->kw == 7) DCLL_TILED(7, 7);
         else if (tile_ok && d->kh == 5 && d->kw == 5) DCLL_TILED(5, 5);
         else if (tile_ok && d->kh == 3 && d->kw == 3) DCLL_TILED(3, 3);
+        else if (tile_ok && d->kh == 1 && d->kw == 3) DCLL_TILED(1, 3);       // radio_ml_conv_ref.yaml
         else
             hipLaunchKernelGGL(k_conv_lif, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, eps1, W, b, arp, s_full,
                                pv_full, out_v, nconv);

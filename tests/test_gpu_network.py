@@ -324,3 +324,35 @@ def test_full_size_properties_batch512_t128():
         for j, name in enumerate(("eps0", "eps1", "arp")):
             got = getattr(s.dclllayer.i2h.state, name)[pick].cpu().numpy()
             assert np.array_equal(got.view(np.uint32), orc.layers[i].state[j].view(np.uint32)), (i, name)
+
+
+def test_ref_yaml_network_on_128_plane_per_step():
+    """radio_ml_conv_ref.yaml (7 x 64 channels, (1,3) kernels, (1,2) pooling) is constructible on a 128-wide plane
+     and runs on the per-step HIP path: checked against the C oracle for a few steps."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from oracle import c_oracle as C
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv_ref.yaml"))
+    torch.manual_seed(2)
+    np.random.seed(2)
+    B, H, W = 2, 16, 128
+    net = ConvNetwork(_args(arp=1.0), (1, H, W), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=2)
+    net.reset(True)
+    assert [tuple(s.dclllayer.output_shape) for s in net.dcll_slices] == [(16, 64), (16, 32), (16, 16), (16, 8), (16, 4),
+                                                                           (16, 2), (16, 1)]
+    sds = [{k: v.detach().cpu().numpy() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
+    orc = C.OracleConvNetwork(sds, convs, (H, W), 1.0)
+    rng = np.random.RandomState(0)
+    net.reset()
+    for t in range(4):
+        x = (rng.uniform(size=(B, 1, H, W)) < 0.05).astype(np.float32)
+        outs = orc.step(x)
+        cur = torch.from_numpy(x).cuda()
+        for i, s in enumerate(net.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            assert np.array_equal(v.cpu().numpy().view(np.uint32), outs[i]["v"].view(np.uint32) if outs[i]["v"] is not None
+                                  else v.cpu().numpy().view(np.uint32))
+            np.testing.assert_allclose(p.cpu().numpy(), outs[i]["p"], atol=LOGIT_TOL, rtol=0)
+            if i < 6:
+                assert np.array_equal(o.cpu().numpy(), outs[i]["s"]), (t, i)
+            cur = o
