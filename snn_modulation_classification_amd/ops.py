@@ -35,6 +35,36 @@ def _f32(t, name):
     return t
 
 
+def _expect(t, name, dtype, shape=None, numel=None):
+    """Host-side operand check before a raw pointer crosses the ABI: a kernel indexes exactly the extents its
+    descriptor implies, so a wrong dtype / shape here would be an out-of-bounds access on the GPU."""
+    if t is None:
+        return
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    if numel is not None and t.numel() != numel:
+        raise ValueError("%s must have %d elements, got %d" % (name, numel, t.numel()))
+
+
+def _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=None, tau4=None):
+    ch, cw, _, _ = conv_out_shape(desc)
+    _expect(W, "W", torch.float32, (desc.c_out, desc.c_in, desc.kh, desc.kw))
+    _expect(b, "b", torch.float32, (desc.c_out,))
+    _expect(eps0, "eps0", torch.float32, (B, desc.c_in, desc.h, desc.w))
+    _expect(eps1, "eps1", torch.float32, (B, desc.c_in, desc.h, desc.w))
+    _expect(arp, "arp", torch.float32, (B, desc.c_out, ch, cw))
+    if desc.refractory and arp is None:
+        raise ValueError("refractory layer needs an arp state tensor")
+    if tau is not None:
+        n = desc.c_in * desc.h * desc.w if desc.tau_is_tensor else 1
+        for k, t in enumerate(tau):
+            _expect(t, "time constant %d" % k, torch.float32, numel=n)
+    if tau4 is not None:
+        _expect(tau4, "tau4", torch.float32, (4, desc.c_in))
+
+
 def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None,
                   out_W=None, out_b=None, want_v=True):
     """One Conv2dDCLLlayer.forward step (dcll/pytorch_libdcll.py:599-608); state tensors are updated in place.
@@ -45,6 +75,15 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     ch, cw, ph, pw = conv_out_shape(desc)
     dev = x.device
     x = _f32(x, "x").contiguous()
+    _expect(x, "x", torch.float32, (B, desc.c_in, desc.h, desc.w))
+    _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=(alpha, tau_m, alphas, tau_s))
+    K_ro = desc.c_out * ph * pw
+    if i2o_W is not None:
+        _expect(i2o_W, "i2o_W", torch.float32, (desc.target, K_ro))
+        _expect(i2o_b, "i2o_b", torch.float32, (desc.target,))
+    if desc.output_layer:
+        _expect(out_W, "out_W", torch.float32, (desc.target, K_ro))
+        _expect(out_b, "out_b", torch.float32, (desc.target,))
     s = torch.empty((B, desc.c_out, ph, pw), device=dev, dtype=torch.float32)
     pv = torch.empty_like(s)
     v = torch.empty((B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if want_v else None
@@ -115,19 +154,25 @@ def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spik
     dev = W.device
     out = out or {}
     words = desc.h * desc.w // 32
+    _expect(spk_in, "spk_in", torch.int32, (T, B, desc.c_in, words))
+    _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau4=tau4)
     spk = out.get("spk") if want_spikes else None
     if want_spikes and spk is None:
         spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
     pv = out.get("pv") if want_pv else None
     if want_pv and pv is None:
         pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
+    _expect(spk, "spk_out", torch.int32, (T, B, desc.c_out, words))
+    _expect(pv, "pv_out", torch.float32, (T, B, desc.c_out, desc.h, desc.w))
     v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
     n_ro, logits = 0, None
     if ro_Wp is not None:
         n_ro = ro_b.numel()
+        _expect(ro_Wp, "ro_Wp", torch.float32, numel=n_ro * desc.c_out * desc.h * desc.w)
         logits = out.get("ro")
         if logits is None:
             logits = torch.empty((T, B, n_ro), device=dev, dtype=torch.float32)
+        _expect(logits, "ro_out", torch.float32, (T, B, n_ro))
     rc = _lib.get().dcll_conv_lif_sequence(ctypes.byref(desc), ptr(spk_in), ptr(W), ptr(b), ptr(tau4), ptr(eps0),
                                            ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), ptr(ro_Wp), ptr(ro_b),
                                            ptr(logits), n_ro, T, B, stream_ptr())
@@ -143,6 +188,8 @@ def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want
     dev = W.device
     out = out or {}
     words = desc.h * desc.w // 32
+    _expect(cells, "cells", torch.int32, (T, B))
+    _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau4=tau4)
     spk = out.get("spk") if want_spikes else None
     if want_spikes and spk is None:
         spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
@@ -165,6 +212,10 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
     iq = iq.reshape(B, 2, -1).contiguous()
     L = iq.shape[-1]
     words = desc.h * desc.w // 32
+    _expect(iq, "iq", torch.float32)
+    _expect(thr_i, "thr_i", torch.float32, (desc.w - 1,))
+    _expect(thr_q, "thr_q", torch.float32, (desc.h - 1,))
+    _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau4=tau4)
     spk = out.get("spk") if want_spikes else None
     if want_spikes and spk is None:
         spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
@@ -185,8 +236,12 @@ def readout(pv2d, Wt, bias, out=None):
     N = Wt.shape[0]
     if Wt.shape[1] != K:
         raise ValueError("readout: K mismatch %d vs %d" % (Wt.shape[1], K))
+    _expect(pv2d, "pv", torch.float32)
+    _expect(Wt, "Wt", torch.float32)
+    _expect(bias, "bias", torch.float32, (N,))
     if out is None:
         out = torch.empty((rows, N), device=pv2d.device, dtype=torch.float32)
+    _expect(out, "out", torch.float32, (rows, N))
     check(_lib.get().dcll_readout(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), rows, K, N, stream_ptr()), "dcll_readout")
     return out
 
@@ -194,6 +249,7 @@ def readout(pv2d, Wt, bias, out=None):
 def argmax_vote(logits, t_begin=0, want_vote=True):
     """logits (T,B,N) -> clout (T,B) int32, vote (B) int32."""
     T, B, N = logits.shape
+    _expect(logits, "logits", torch.float32)
     clout = torch.empty((T, B), device=logits.device, dtype=torch.int32)
     vote = torch.empty((B,), device=logits.device, dtype=torch.int32) if want_vote else None
     check(_lib.get().dcll_argmax_vote(ptr(logits), ptr(clout), ptr(vote), T, B, N, t_begin, stream_ptr()),
@@ -205,6 +261,9 @@ def iq_encode(iq, thr_i, thr_q, t0, T, w, h):
     """iq (B,2,L) fp32 -> cells (T,B) int32 = q*w + i."""
     B, two, L = iq.shape
     assert two == 2
+    _expect(iq, "iq", torch.float32)
+    _expect(thr_i, "thr_i", torch.float32, (w - 1,))
+    _expect(thr_q, "thr_q", torch.float32, (h - 1,))
     cells = torch.empty((T, B), device=iq.device, dtype=torch.int32)
     check(_lib.get().dcll_iq_encode(ptr(iq), ptr(thr_i), ptr(thr_q), ptr(cells), B, L, t0, T, w, h, stream_ptr()),
           "dcll_iq_encode")

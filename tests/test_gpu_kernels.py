@@ -281,9 +281,11 @@ def test_error_conventions(dev):
     """Bad geometry -> DCLLUnsupported (NotImplementedError); nulls -> ValueError; never a crash."""
     from snn_modulation_classification_amd import ops, _lib
     d = ops.make_conv_desc(32, 32, (20, 20), 7, 3, 1, 24, False, True, 1.0)
-    z = torch.zeros(4, device=dev)
-    with pytest.raises(NotImplementedError):
-        ops.conv_lif_sequence(d, z.int(), z, z, z, z, z, z, 1, 1)
+    st = lambda: torch.zeros((1, 32, 20, 20), device=dev)
+    with pytest.raises(NotImplementedError):      # well-formed operands, but a plane the fused kernel does not cover
+        ops.conv_lif_sequence(d, torch.zeros((1, 1, 32, 400 // 32), device=dev, dtype=torch.int32),
+                              torch.zeros((32, 32, 7, 7), device=dev), torch.zeros(32, device=dev),
+                              torch.ones((4, 32), device=dev), st(), st(), st(), 1, 1)
     d2 = ops.make_conv_desc(1, 4, (8, 8), 3, 1, 1, 10, False, False, 0.0, stride=2)
     with pytest.raises(NotImplementedError):
         ops.conv_out_shape(d2)
@@ -428,3 +430,28 @@ def test_edge_cases_empty_and_single(dev):
     # vote over an empty window (t_begin == T): no class has a vote -> -1
     c, vt = ops.argmax_vote(torch.zeros((4, 3, 5), device=dev), t_begin=4)
     assert vt.cpu().tolist() == [-1, -1, -1] and c.shape == (4, 3)
+
+
+def test_operand_validation_before_the_abi(dev):
+    """Wrong dtype / shape is rejected on the host (TypeError / ValueError) instead of becoming an OOB access."""
+    from snn_modulation_classification_amd import ops
+    d = ops.make_conv_desc(1, 32, (16, 16), 7, 3, 1, 24, False, True, 1.0)
+    W, b = torch.zeros((32, 1, 7, 7), device=dev), torch.zeros(32, device=dev)
+    tau4 = torch.ones((4, 1), device=dev)
+    st = lambda B, c: torch.zeros((B, c, 16, 16), device=dev)
+    with pytest.raises(TypeError):        # int64 cells
+        ops.conv_lif_sequence_cells(d, torch.zeros((3, 2), device=dev, dtype=torch.int64), W, b, tau4, st(2, 1), st(2, 1),
+                                    st(2, 32), 3, 2)
+    with pytest.raises(ValueError):       # state for a different batch size
+        ops.conv_lif_sequence_cells(d, torch.zeros((3, 2), device=dev, dtype=torch.int32), W, b, tau4, st(5, 1), st(2, 1),
+                                    st(2, 32), 3, 2)
+    with pytest.raises(ValueError):       # weights of another geometry
+        ops.conv_lif_sequence_cells(d, torch.zeros((3, 2), device=dev, dtype=torch.int32), torch.zeros((32, 1, 5, 5), device=dev),
+                                    b, tau4, st(2, 1), st(2, 1), st(2, 32), 3, 2)
+    d32 = ops.make_conv_desc(32, 32, (16, 16), 7, 3, 1, 24, False, True, 1.0)
+    with pytest.raises(ValueError):       # packed input with the wrong word count
+        ops.conv_lif_sequence(d32, torch.zeros((3, 2, 32, 4), device=dev, dtype=torch.int32),
+                              torch.zeros((32, 32, 7, 7), device=dev), b, torch.ones((4, 32), device=dev), st(2, 32),
+                              st(2, 32), st(2, 32), 3, 2)
+    with pytest.raises(ValueError):       # readout bias of the wrong length
+        ops.readout(torch.zeros((4, 64), device=dev), torch.zeros((5, 64), device=dev), torch.zeros(4, device=dev))
