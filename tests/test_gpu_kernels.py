@@ -133,6 +133,50 @@ def test_sequence_c32_vs_oracle(dev, wrp, T, B, zero_state):
     assert 0.01 < spk_d[1:].mean() < 0.9, "degenerate test: spikes all equal"
 
 
+@pytest.mark.parametrize("hw,wrp,T,B,zero_state", [((32, 32), 1.0, 11, 2, True), ((16, 64), 0.0, 10, 3, False),
+                                                    ((24, 96), 1.0, 9, 2, False), ((128, 128), 1.0, 3, 1, True)])
+def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
+    """k_lif_seq_c32t (large planes: one workgroup per 8 x 32 tile with a recomputed 3-pixel trace halo) == C oracle
+    stepping, bit for bit, incl. the final state; planes with 1, 2, 3 and 4 tiles per row / column exercise every
+    border combination (tile touching both, one or no plane edge)."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(13)
+    H, Wd = hw
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    orc = C.OracleConvLayer(sd, hw, 3, 1, wrp)
+    orc.init_state(B)
+    if not zero_state:
+        orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape)
+        orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape)
+        if wrp > 0:
+            orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+    state = [cu(s.copy(), dev) for s in orc.state]
+    eps0, eps1 = state[0], state[1]
+    arp = state[2] if wrp > 0 else None
+    x = (rng.uniform(size=(T, B, 32, H * Wd)) < 0.08).astype(np.float32)
+    x[0] = (rng.uniform(size=(B, 32, H * Wd)) < 0.5)
+    d = ops.make_conv_desc(32, 32, hw, 7, 3, 1, 24, False, wrp > 0, wrp)
+    spk_in = ops.pack_spikes(cu(x, dev))
+    assert spk_in.shape == (T, B, 32, H * Wd // 32)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    spk, pv, v = ops.conv_lif_sequence(d, spk_in, cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp, T, B, want_v=True)
+    torch.cuda.synchronize()
+    spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T, B, 32, H, Wd)
+    v, pv = v.cpu().numpy(), pv.cpu().numpy()
+    for t in range(T):
+        oo, op, opv, ov, os_ = orc.forward(x[t].reshape(B, 32, H, Wd))
+        assert bits_equal(v[t], ov), (t, np.abs(v[t] - ov).max(), np.argwhere(v[t] != ov)[:5])
+        assert np.array_equal(spk_d[t], os_), t
+        np.testing.assert_allclose(pv[t], opv, atol=PV_TOL, rtol=0)
+    assert bits_equal(eps0.cpu().numpy(), orc.state[0])
+    assert bits_equal(eps1.cpu().numpy(), orc.state[1])
+    if wrp > 0:
+        assert bits_equal(arp.cpu().numpy(), orc.state[2])
+    assert 0.01 < spk_d[1:].mean() < 0.9, "degenerate test: spikes all equal"
+
+
 @pytest.mark.parametrize("wrp,cout", [(1.0, 32), (0.0, 32), (1.0, 8)])
 def test_sequence_c1_vs_oracle(dev, wrp, cout):
     from snn_modulation_classification_amd import ops
