@@ -27,43 +27,10 @@
 //   k_readout          fp32-MFMA GEMM for i2o / output_ over many rows.
 //   k_argmax, k_vote   per-step argmax and vote.
 //   k_iq_encode, k_pack, k_unpack     glue.
-#include <hip/hip_runtime.h>
-#include <type_traits>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
+#include "dcll_internal.h"
 
-#include "../../include/dcll_hip.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// geometry of the LDS-resident 32-channel 16x16 eps1 image shared by k_lif_seq_c32 and k_bwd_wgrad_c32
-constexpr int NWAVE = 8, CPW = 4, ROWF = 19, CHF = 361;
-constexpr int IMG_FLOATS = ((32 * CHF + 3 * ROWF + 3 + 61) + 3) & ~3;     // 11676 >= offset of (ci=31, y=18, x=18) + 1
-constexpr int SLOT_FLOATS = 16 * 64;
-
-// ------------------------------------------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char *msg, const char *who = nullptr)
-{
-    if (who) snprintf(g_err, sizeof(g_err), "%s: %s", who, msg);
-    else snprintf(g_err, sizeof(g_err), "%s", msg);
-    return code;
-}
-
-#define HIP_CHECK_LAUNCH(name)                                                              \
-    do {                                                                                    \
-        hipError_t e_ = hipGetLastError();                                                  \
-        if (e_ != hipSuccess) {                                                             \
-            snprintf(g_err, sizeof(g_err), "%s: %s", name, hipGetErrorString(e_));          \
-            return DCLL_ERR_LAUNCH;                                                         \
-        }                                                                                   \
-    } while (0)
+static thread_local char g_err[DCLL_ERR_LEN] = "";
+char *dcll_err_buf(void) { return g_err; }
 
 extern "C" int dcll_version(void) { return DCLL_ABI_VERSION; }
 extern "C" const char *dcll_last_error(void) { return g_err; }
@@ -101,35 +68,6 @@ extern "C" int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *ch, int32_t
     if (ph) *ph = c;
     if (pw) *pw = e;
     return DCLL_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// shared device helpers
-// ------------------------------------------------------------------------------------------------------------
-// pv = 1/(1+exp(-v)): v_exp_f32 + v_rcp_f32 (each ~1 ulp); pv is not bit-pinned (include/dcll_hip.h), |err| ~1e-7.
-__device__ __forceinline__ float sigmoidf_dev(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-
-// dcll/pytorch_libdcll.py:493-494 — (x*tau_s) + (alphas*eps0) ; (alpha*eps1) + (eps0'*tau_m); every op rounded.
-__device__ __forceinline__ void trace_update(float x, float alpha, float tau_m, float alphas, float tau_s,
-                                             float &e0, float &e1)
-{
-    float a = x * tau_s;
-    float b = alphas * e0;
-    e0 = a + b;
-    float c = alpha * e1;
-    float d = e0 * tau_m;
-    e1 = c + d;
-}
-
-// :497-503 — returns v, updates arp, sets s.
-__device__ __forceinline__ float refractory(float pvmem, float &arp, float alpharp, float wrp, bool &s)
-{
-    float a = alpharp * arp;
-    float v = pvmem + a;
-    s = v > 0.0f;
-    float sw = s ? wrp : 0.0f;      // s*wrp, exact
-    arp = a - sw;
-    return v;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -782,7 +720,6 @@ __global__ void k_pack(const float *__restrict__ dense, uint32_t *__restrict__ p
 //   mirrored into a zero-padded 22x22 LDS plane; each thread gathers its 49 taps once per step and runs the fmaf
 //   chain (tap order = the pinned order for c_in == 1) for every output channel with wave-uniform weights.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int PADW = 22;
 constexpr int C1_MAXT = 4096;       // longest window the fused IQ encoder of k_lif_seq_c1 keeps in LDS
 
 // Input either as cell indices (cells != NULL) or as raw IQ (iq != NULL): then the quantisation of iq2spiketrain
@@ -1267,276 +1204,6 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// k_lif_seq_c32t — the same 32 -> 32 channel 7x7 layer over all T steps on a LARGE plane (H % 8 == 0, W % 32 == 0;
-// the reference's default 128x128 I/Q plane, test_radio_ml.py:52): one workgroup per (sample, 8 x 32 pixel tile).
-// Same machine as k_lif_seq_c32 (8 waves x 4 input channels, weights in registers, systolic accumulator hand-off,
-// one barrier per stage, epilogue split by register quad), with these differences:
-//   - an MFMA tile is ONE image row of 32 pixels (lane&31 = column), so every spike word is still one ballot half
-//     and the B-fragment reads of a half-wave are 32 consecutive floats (conflict free);
-//   - the workgroup keeps the eps1 traces of its tile PLUS the 3-pixel halo (14 rows x 38 columns per channel,
-//     row stride TRW, channel stride TCH = 32 mod 64 banks) and recomputes the halo redundantly (2.08x trace work,
-//     <2 % of the stage; the halo values are the same fp32 ops on the same inputs as the owning tile computes, so the
-//     result stays bit-exact).  Pixels outside the plane stay 0 = the convolution's zero padding;
-//   - only wave w ever reads its 4 channels of the image, so ONE image suffices: region rows are advanced to the next
-//     step in place as soon as the wave's own chain no longer needs them (row r is last read by tile r):
-//       end of stage m=2: rows 0-2 -> step t+1      end of stage m=0: rows 9-11  -> step t  (first read by tile 3)
-//       end of stage m=5: rows 3-5 -> step t+1      end of stage m=1: rows 12-13 -> step t  (first read by tile 6)
-//       end of stage m=7: rows 6-8 -> step t+1
-//     with the input spike words fetched at the start of the stage and consumed after the MFMA chain.
-// eps0 of the region lives in registers (5 row groups x 2 slots x 4 channels).
-// ------------------------------------------------------------------------------------------------------------
-constexpr int TRW = 38, TROWS = 14, TCH = 544, TIMG = 32 * TCH;
-constexpr int TGROUP = 3 * TRW;         // floats per row group (3 rows; the 5th group has 2)
-
-template <bool REFRACTORY, int OUT>     // OUT bit0: pv, bit1: v
-__global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
-                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
-                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
-                                                       float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
-                                                       float *__restrict__ pv_out, float *__restrict__ v_out, int T,
-                                                       int B, int H, int Wd, float alpharp, float wrp)
-{
-    __shared__ __attribute__((aligned(16))) float lds[TIMG + NWAVE * 2 * SLOT_FLOATS + 32];
-    float *slots = lds + TIMG;
-    float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wq = w & 3, wpar = w >> 2;
-    const int wpr = Wd >> 5;                                  // spike words per image row = tiles per row
-    const int ntile = (H >> 3) * wpr;
-    const long b = blockIdx.x / ntile;
-    const int tile = blockIdx.x % ntile;
-    const int y0 = (tile / wpr) * 8, tx = tile % wpr, x0 = tx * 32;
-    const long HW = (long)H * Wd;
-    const long words = HW >> 5;
-
-    for (int i = tid; i < TIMG; i += 512) lds[i] = 0.0f;
-    if (tid < 32) sbias[tid] = bias[tid];
-
-    float wf[2][49];
-#pragma unroll
-    for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-        for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
-
-    // trace element (group k, slot s) of a lane: region element idx = lane + 64 s of the group's 3 (2) rows, i.e.
-    // row 3k + idx / 38, column idx % 38; its LDS offset inside a channel image is simply 114 k + idx.
-    int erow[2], egx[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int idx = lane + 64 * s;
-        erow[s] = idx / TRW;
-        egx[s] = x0 - 3 + (idx % TRW);
-    }
-    // global position of element (k, s): row gy = y0 - 3 + 3k + erow[s], column egx[s]; valid if inside the plane and
-    // inside the group (idx < 114, or < 76 for the last group)
-    auto elem_ok = [&](int k, int s) -> bool {
-        const int idx = lane + 64 * s;
-        const int gy = y0 - 3 + 3 * k + erow[s];
-        return idx < (k < 4 ? TGROUP : 2 * TRW) && (unsigned)gy < (unsigned)H && (unsigned)egx[s] < (unsigned)Wd;
-    };
-    auto in_group = [&](int k, int s) -> bool { return lane + 64 * s < (k < 4 ? TGROUP : 2 * TRW); };
-    const uint32_t *in_b = spk_in + (b * 32 + 4 * w) * words;
-    const long in_step = (long)B * 32 * words;
-    // spike words of (step ts, group k): xw[s][c]
-    auto fetch = [&](int k, int ts, uint32_t (&xw)[2][4]) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bool ok = elem_ok(k, s);
-            const long off = (long)(y0 - 3 + 3 * k + erow[s]) * wpr + (egx[s] >> 5);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xw[s][c] = ok ? in_b[(long)ts * in_step + c * words + off] : 0u;
-        }
-    };
-    float e0[5][2][4];
-    __syncthreads();        // image zeroed
-
-    // prologue: state of the region from HBM (0 outside the plane), advanced to step 0 -> image
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        uint32_t xw[2][4];
-        fetch(k, 0, xw);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bool ok = elem_ok(k, s);
-            const long goff = (long)(y0 - 3 + 3 * k + erow[s]) * Wd + egx[s];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
-                const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
-                const long gidx = (b * 32 + 4 * w + c) * HW + goff;
-                float e0v = ok ? eps0_g[gidx] : 0.0f, e1 = ok ? eps1_g[gidx] : 0.0f;
-                const float xin = (float)((xw[s][c] >> (egx[s] & 31)) & 1u);
-                trace_update(xin, ta, tm, tas, ts, e0v, e1);
-                e0[k][s][c] = e0v;
-                if (in_group(k, s)) lds[(4 * w + c) * TCH + k * TGROUP + lane + 64 * s] = e1;
-            }
-        }
-    }
-    // refractory trace of my epilogue share: tiles (rows) m = 2k + wpar, quad wq: channel rr + 8 wq + 4h, column j
-    float arp[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            arp[k][rr] = REFRACTORY ? arp_g[(b * 32 + rr + 8 * wq + 4 * h) * HW + (long)(y0 + 2 * k + wpar) * Wd + x0 + j]
-                                    : 0.0f;
-    const int bbase = (4 * w + h) * TCH + j;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) asm volatile("" ::"v"(arp[k][rr]));
-#pragma unroll
-    for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-        for (int k = 0; k < 49; ++k) asm volatile("" ::"v"(wf[cp][k]));
-    __syncthreads();
-
-    // advance group K of my 4 channels by one step with the fetched spike words
-    auto advance = [&](auto KC, const uint32_t (&xw)[2][4]) {
-        constexpr int K = decltype(KC)::value;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
-            const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (in_group(K, s)) {
-                    float *p = lds + (4 * w + c) * TCH + K * TGROUP + lane + 64 * s;
-                    float e1 = *p;
-                    const float xin = (float)((xw[s][c] >> (egx[s] & 31)) & 1u);
-                    trace_update(xin, ta, tm, tas, ts, e0[K][s][c], e1);
-                    *p = e1;
-                }
-            }
-        }
-    };
-
-    const int nstage = 8 * T + 9;
-    for (int g = 0; g < nstage; ++g) {
-        // ---- (1) epilogue share: quad wq of tile qe = g - 8 ----
-        const int qe = g - 8;
-        if (qe >= 0 && qe < 8 * T && ((qe & 1) == wpar)) {
-            __builtin_amdgcn_s_setprio(1);
-            const int te = qe >> 3, me = qe & 7;
-            const f32x4 v4 = *((const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + wq * 64 + lane);
-            const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
-            const long oelem = obase * HW + (long)(y0 + me) * Wd + x0 + j;    // + rr*HW
-            float *pvp = pv_out + oelem, *vp = v_out + oelem;
-            auto quad = [&](float (&ar)[4]) {
-                uint32_t myword = 0;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    float v = v4[rr];
-                    bool s;
-                    if (REFRACTORY) v = refractory(v4[rr], ar[rr], alpharp, wrp, s);
-                    else s = v > 0.0f;
-                    unsigned long long mk = __ballot(s);
-                    uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-                    myword = (j == rr) ? mine : myword;
-                    if (OUT & 1) pvp[rr * HW] = sigmoidf_dev(v);
-                    if (OUT & 2) vp[rr * HW] = v;
-                }
-                if (spk_out && j < 4) spk_out[(obase + j) * words + (long)(y0 + me) * wpr + tx] = myword;
-            };
-            switch (me >> 1) {
-            case 0: quad(arp[0]); break;
-            case 1: quad(arp[1]); break;
-            case 2: quad(arp[2]); break;
-            default: quad(arp[3]); break;
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        const int q = g - w;
-        if (q >= 0 && q < 8 * T) {
-            const int m = q & 7, t = q >> 3;
-            // ---- (2a) spike words of the row group this stage advances (consumed after the chain) ----
-            //   m = 2, 5, 7 -> groups 0, 1, 2 to step t+1;   m = 0, 1 -> groups 3, 4 to step t (t >= 1)
-            int tg = -1, tstep = 0;
-            if (m == 2) { tg = 0; tstep = t + 1; }
-            else if (m == 5) { tg = 1; tstep = t + 1; }
-            else if (m == 7) { tg = 2; tstep = t + 1; }
-            else if (m == 0) { tg = 3; tstep = t; }
-            else if (m == 1) { tg = 4; tstep = t; }
-            if (tstep >= T || tstep < 1) tg = -1;
-            uint32_t xw[2][4];
-            if (tg >= 0) fetch(tg, tstep, xw);
-            // ---- (3) my K-slice of the chain ----
-            f32x16 acc;
-            if (w == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
-            } else {
-                const f32x4 *sp = (const f32x4 *)(slots + ((w - 1) * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + lane;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x4 v4 = sp[c * 64];
-                    acc[4 * c + 0] = v4[0]; acc[4 * c + 1] = v4[1]; acc[4 * c + 2] = v4[2]; acc[4 * c + 3] = v4[3];
-                }
-            }
-            const int i0 = bbase + m * TRW;
-            auto tapval = [&](int cp, int off) -> float { return lds[i0 + cp * 2 * TCH + off]; };
-            float bq[2][7];
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = tapval(0, kx);
-#pragma unroll
-            for (int r = 0; r < 14; ++r) {
-                if (r + 1 < 14) {
-                    const int cpn = (r + 1) / 7, kyn = (r + 1) % 7;
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = tapval(cpn, kyn * TRW + kx);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kx = 0; kx < 7; ++kx)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r / 7][(r % 7) * 7 + kx], bq[r & 1][kx], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            f32x4 *dp = (f32x4 *)(slots + (w * 2 + (g & 1)) * SLOT_FLOATS) + lane;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 v4 = {acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
-                dp[c * 64] = v4;
-            }
-            // ---- (2b) advance the row group (its rows are no longer read by this step's remaining tiles) ----
-            switch (tg) {       // wave-uniform: keeps e0[][][] statically indexed (registers)
-            case 0: advance(std::integral_constant<int, 0>{}, xw); break;
-            case 1: advance(std::integral_constant<int, 1>{}, xw); break;
-            case 2: advance(std::integral_constant<int, 2>{}, xw); break;
-            case 3: advance(std::integral_constant<int, 3>{}, xw); break;
-            case 4: advance(std::integral_constant<int, 4>{}, xw); break;
-            default: break;
-            }
-        }
-        __syncthreads();
-    }
-
-    // state back to HBM: the interior of the region (rows 3..10, columns 3..34)
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int idx = lane + 64 * s, rr = 3 * k + erow[s], cc = idx % TRW;
-            if (in_group(k, s) && rr >= 3 && rr < 11 && cc >= 3 && cc < 35) {
-                const long goff = (long)(y0 - 3 + rr) * Wd + egx[s];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const long gidx = (b * 32 + 4 * w + c) * HW + goff;
-                    eps0_g[gidx] = e0[k][s][c];
-                    eps1_g[gidx] = lds[(4 * w + c) * TCH + k * TGROUP + idx];
-                }
-            }
-        }
-    if (REFRACTORY) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                arp_g[(b * 32 + rr + 8 * wq + 4 * h) * HW + (long)(y0 + 2 * k + wpar) * Wd + x0 + j] = arp[k][rr];
-    }
-}
-
 // readout weights (N, 32*256) [n][co][pix]  ->  epilogue layout [me][wq][n][lane][rr]:
 //   co = rr + 8*wq + 4*(lane>>5), pix = 32*me + (lane&31)
 __global__ void k_permute_readout(const float *__restrict__ Wt, float *__restrict__ Wp, int N)
@@ -1783,31 +1450,9 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
     if (n_ro && (!ro_Wp || !ro_b || !ro_out)) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: fused readout needs ro_Wp, ro_b, ro_out");
     hipStream_t st = (hipStream_t)stream;
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
-    if (d->h != 16 || d->w != 16) {         // large plane: one workgroup per (sample, 8 x 32 tile)
+    if (d->h != 16 || d->w != 16) {         // large plane: k_lif_seq_c32t, one workgroup per (sample, 8 x 32 tile)
         if (n_ro) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout only on the 16x16 plane");
-        const long nwg = (long)B * (d->h / 8) * (d->w / 32);
-        if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: batch x tiles exceeds the grid limit");
-#define DCLL_LAUNCH_C32T(R, O)                                                                                          \
-    hipLaunchKernelGGL((k_lif_seq_c32t<R, O>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1,   \
-                       arp, spk_out, pv_out, v_out, T, B, d->h, d->w, d->alpharp, d->wrp)
-        if (d->refractory) {
-            switch (out) {
-            case 0: DCLL_LAUNCH_C32T(true, 0); break;
-            case 1: DCLL_LAUNCH_C32T(true, 1); break;
-            case 2: DCLL_LAUNCH_C32T(true, 2); break;
-            default: DCLL_LAUNCH_C32T(true, 3); break;
-            }
-        } else {
-            switch (out) {
-            case 0: DCLL_LAUNCH_C32T(false, 0); break;
-            case 1: DCLL_LAUNCH_C32T(false, 1); break;
-            case 2: DCLL_LAUNCH_C32T(false, 2); break;
-            default: DCLL_LAUNCH_C32T(false, 3); break;
-            }
-        }
-#undef DCLL_LAUNCH_C32T
-        HIP_CHECK_LAUNCH("k_lif_seq_c32t");
-        return DCLL_OK;
+        return dcll_launch_seq_c32t(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, st);
     }
 #define DCLL_ARGS out, B, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out, T, d->alpharp, d->wrp
     if (d->refractory) {

@@ -1,0 +1,78 @@
+// dcll_internal.h — what the translation units of libdcll_hip.so share: vector typedefs, the geometry constants of
+// the LDS-resident layouts, the error plumbing of the C ABI and the device helpers that define the pinned arithmetic
+// (include/dcll_hip.h).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dcll_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// geometry of the LDS-resident 32-channel 16x16 eps1 image shared by k_lif_seq_c32 and k_bwd_wgrad_c32
+constexpr int NWAVE = 8, CPW = 4, ROWF = 19, CHF = 361;
+constexpr int IMG_FLOATS = ((32 * CHF + 3 * ROWF + 3 + 61) + 3) & ~3;     // 11676 >= offset of (ci=31, y=18, x=18) + 1
+constexpr int SLOT_FLOATS = 16 * 64;
+
+// ------------------------------------------------------------------------------------------------------------
+// error plumbing (the message buffer lives in dcll_hip.hip; one per thread)
+// ------------------------------------------------------------------------------------------------------------
+__attribute__((visibility("hidden"))) char *dcll_err_buf(void);
+constexpr size_t DCLL_ERR_LEN = 512;
+
+static inline int fail(int code, const char *msg, const char *who = nullptr)
+{
+    if (who) snprintf(dcll_err_buf(), DCLL_ERR_LEN, "%s: %s", who, msg);
+    else snprintf(dcll_err_buf(), DCLL_ERR_LEN, "%s", msg);
+    return code;
+}
+
+#define HIP_CHECK_LAUNCH(name)                                                              \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) {                                                             \
+            snprintf(dcll_err_buf(), DCLL_ERR_LEN, "%s: %s", name, hipGetErrorString(e_));  \
+            return DCLL_ERR_LAUNCH;                                                         \
+        }                                                                                   \
+    } while (0)
+
+// k_lif_seq_c32t (dcll_seq_tiled.hip): the 32 -> 32 channel sequence layer on planes with h % 8 == 0, w % 32 == 0
+__attribute__((visibility("hidden")))
+int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+                         const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
+                         float *v_out, int32_t T, int32_t B, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------------------------
+// pv = 1/(1+exp(-v)): v_exp_f32 + v_rcp_f32 (each ~1 ulp); pv is not bit-pinned (include/dcll_hip.h), |err| ~1e-7.
+__device__ __forceinline__ float sigmoidf_dev(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// dcll/pytorch_libdcll.py:493-494 — (x*tau_s) + (alphas*eps0) ; (alpha*eps1) + (eps0'*tau_m); every op rounded.
+__device__ __forceinline__ void trace_update(float x, float alpha, float tau_m, float alphas, float tau_s,
+                                             float &e0, float &e1)
+{
+    float a = x * tau_s;
+    float b = alphas * e0;
+    e0 = a + b;
+    float c = alpha * e1;
+    float d = e0 * tau_m;
+    e1 = c + d;
+}
+
+// :497-503 — returns v, updates arp, sets s.
+__device__ __forceinline__ float refractory(float pvmem, float &arp, float alpharp, float wrp, bool &s)
+{
+    float a = alpharp * arp;
+    float v = pvmem + a;
+    s = v > 0.0f;
+    float sw = s ? wrp : 0.0f;      // s*wrp, exact
+    arp = a - sw;
+    return v;
+}
+
