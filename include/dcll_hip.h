@@ -119,8 +119,10 @@ int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W
 /*
  * Whole-sequence fast path behind ConvNetwork.test (networks/__init__.py:182-185) for one layer: all T timesteps
  * of dcll/pytorch_libdcll.py:485-509 / :407-426 in ONE launch with the neuron state held on-chip.
- * Supported geometry (else DCLL_ERR_UNSUPPORTED): c_in==32, c_out==32, 7x7, pad 3, 16x16, pool 1, time constants
- * constant over (h,w) per input channel (what randomize_tau produces, :391-405).
+ * Supported geometry (else DCLL_ERR_UNSUPPORTED): c_in==32, c_out==32, 7x7, pad 3, pool 1, time constants constant
+ * over (h,w) per input channel (what randomize_tau produces, :391-405), on the 16x16 plane of the reference's scripts
+ * (one sample per workgroup) or on any plane with h % 8 == 0 and w % 32 == 0 — e.g. the 128x128 default of
+ * test_radio_ml.py:52 — (one workgroup per 8x32 tile; no fused readout there).
  *   spk_in   (T,B,c_in,h*w/32) uint32   packed input spikes: bit (y*w+x)%32 of word (y*w+x)/32
  *   tau4     (4,c_in) fp32              rows: alpha, tau_m, alphas, tau_s per input channel
  *   eps0,eps1,arp                       neuron state in/out as in dcll_conv_lif_step (read at t=0, written after t=T-1)
@@ -143,7 +145,8 @@ int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void *stream);
 
 /*
  * First-layer sequence kernel (c_in==1): the input is exactly one spike per sample per step (iq2spiketrain,
- * data/utils.py:43-87), given as its cell index q*w+i.  Geometry: c_in==1, c_out<=32, 7x7, pad 3, 16x16, pool 1.
+ * data/utils.py:43-87), given as its cell index q*w+i.  Geometry: c_in==1, c_out<=32, 7x7, pad 3, pool 1, plane 16x16
+ * or h % 8 == 0 and w % 32 == 0.
  *   cells (T,B) int32 ; tau4 (4,1) ; other arguments as dcll_conv_lif_sequence.
  */
 int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *W, const float *b,
@@ -152,8 +155,8 @@ int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, 
 
 /*
  * Same kernel with iq2spiketrain's quantisation (data/utils.py:60-82) fused in: the input is the raw IQ window
- * iq (B,2,L) fp32, samples t0..t0+T-1, quantised with the thresholds of dcll_iq_encode (thr_i, thr_q: 15 floats each
- * for the 16x16 plane).  T <= 4096.
+ * iq (B,2,L) fp32, samples t0..t0+T-1, quantised with the thresholds of dcll_iq_encode (thr_i: w-1 floats, thr_q:
+ * h-1 floats).  T <= 4096.
  */
 int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
                               int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,

@@ -1399,12 +1399,12 @@ static int check_seq_geometry(const dcll_conv_desc *d, int c_in, const char *who
     int rc = check_desc(d);
     if (rc) return rc;
     const bool small = d->h == 16 && d->w == 16;
-    const bool tiled = c_in == 32 && d->h >= 8 && d->h % 8 == 0 && d->w >= 32 && d->w % 32 == 0;   // k_lif_seq_c32t
+    const bool tiled = d->h >= 8 && d->h % 8 == 0 && d->w >= 32 && d->w % 32 == 0;   // k_lif_seq_c1t / k_lif_seq_c32t
     if (d->c_in != c_in || d->c_out > 32 || (c_in == 32 && d->c_out != 32) || !(small || tiled) || d->kh != 7 ||
         d->kw != 7 || d->pad_h != 3 || d->pad_w != 3 || d->pool_h != 1 || d->pool_w != 1)
         return fail(DCLL_ERR_UNSUPPORTED,
-                    "sequence kernel supports 7x7 pad 3, pool 1, c_out<=32 (==32 for c_in 32) on a 16x16 plane, and for "
-                    "c_in 32 also planes with h % 8 == 0, w % 32 == 0", who);
+                    "sequence kernel supports 7x7 pad 3, pool 1, c_out<=32 (==32 for c_in 32) on a 16x16 plane or a plane "
+                    "with h % 8 == 0, w % 32 == 0", who);
     return DCLL_OK;
 }
 
@@ -1474,6 +1474,9 @@ static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float 
                      float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, int T, int B,
                      hipStream_t st)
 {
+    if (d->h != 16 || d->w != 16)       // large plane: k_lif_seq_c1t, one workgroup per (sample, 8 x 32 tile)
+        return dcll_launch_seq_c1t(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
+                                   T, B, st);
     if (d->refractory)
         hipLaunchKernelGGL(k_lif_seq_c1<true>, dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,
                            tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);

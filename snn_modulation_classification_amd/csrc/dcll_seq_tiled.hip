@@ -281,6 +281,167 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_lif_seq_c1t — the first layer (c_in = 1, one input spike per step as a cell index or raw IQ) on a large plane:
+// one 256-thread workgroup per (sample, 8 x 32 pixel tile), all T steps.  Same MFMA form as k_lif_seq_c1 (49 taps
+// padded per kernel row to 4 k-pairs with a ZERO weight on the pad tap, weight-stationary in 28 VGPRs); the tile's
+// trace region (14 x 38 with the 3-pixel halo, recomputed redundantly like in k_lif_seq_c32t) lives in registers
+// (eps0, eps1: 3 elements per thread) with eps1 mirrored into an LDS plane for the B fragments.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int C1T_MAXT = 4096;
+constexpr int C1T_REGION = 14 * TRW;        // 532
+
+template <bool REFRACTORY>
+__global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *__restrict__ cells,
+                                                      const float *__restrict__ iq, const float *__restrict__ thr_i,
+                                                      const float *__restrict__ thr_q, int L, int t0,
+                                                      const float *__restrict__ W, const float *__restrict__ bias,
+                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
+                                                      float *__restrict__ eps1_g, float *__restrict__ arp_g,
+                                                      uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
+                                                      float *__restrict__ v_out, int T, int B, int H, int Wd,
+                                                      float alpharp, float wrp)
+{
+    __shared__ float plane[C1T_REGION + 8];     // + the pad tap's read past the last row (zero weight, finite data)
+    __shared__ float sbias[32];
+    __shared__ int scell[C1T_MAXT];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wpr = Wd >> 5;
+    const int ntile = (H >> 3) * wpr;
+    const long b = blockIdx.x / ntile;
+    const int tile = blockIdx.x % ntile;
+    const int y0 = (tile / wpr) * 8, tx = tile % wpr, x0 = tx * 32;
+    const long HW = (long)H * Wd;
+    const long words = HW >> 5;
+    const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];
+    for (int i = tid; i < C1T_REGION + 8; i += 256) plane[i] = 0.0f;
+    if (iq) {
+        // quantisation of iq2spiketrain (data/utils.py:60-82) in threshold form, as k_iq_encode: cell = row * W + col
+        for (int t = tid; t < T; t += 256) {
+            const float vi = iq[(b * 2 + 0) * L + t0 + t], vq = iq[(b * 2 + 1) * L + t0 + t];
+            int ci = 0, cq = 0;
+            for (int k = 0; k < Wd - 1; ++k) ci += vi >= thr_i[k];
+            for (int k = 0; k < H - 1; ++k) cq += vq >= thr_q[k];
+            scell[t] = cq * Wd + ci;
+        }
+    }
+    // my (up to) 3 region elements: idx = tid + 256 s -> region row idx / 38, column idx % 38; gpix = its pixel
+    // index in the plane, or -1 outside the plane / region (then it stays 0 = zero padding)
+    int gpix[3];
+    float e0[3], e1[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int idx = tid + 256 * s, rr = idx / TRW, cc = idx % TRW;
+        const int gy = y0 - 3 + rr, gx = x0 - 3 + cc;
+        const bool ok = idx < C1T_REGION && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
+        gpix[s] = ok ? gy * Wd + gx : -1;
+        e0[s] = ok ? eps0_g[b * HW + gpix[s]] : 0.0f;
+        e1[s] = ok ? eps1_g[b * HW + gpix[s]] : 0.0f;
+    }
+    float wf[7][4];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kx = 2 * i + h;
+            wf[ky][i] = (kx < 7 && j < c_out) ? W[j * 49 + ky * 7 + kx] : 0.0f;
+        }
+    // refractory trace of my two tiles (rows y0 + 2w + tl): arp[tl][r] <-> channel (r&3)+8(r>>2)+4h, column x0 + j
+    float arp[2][16];
+    if (tid < 32) sbias[tid] = tid < c_out ? bias[tid] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+            arp[tl][r] = (REFRACTORY && co < c_out)
+                             ? arp_g[(b * c_out + co) * HW + (long)(y0 + 2 * w + tl) * Wd + x0 + j] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int cell = iq ? scell[t] : cells[(long)t * B + b];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            trace_update(cell == gpix[s] ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0[s], e1[s]);
+            if (tid + 256 * s < C1T_REGION) plane[tid + 256 * s] = e1[s];
+        }
+        __syncthreads();
+        const long obase = ((long)t * B + b) * c_out;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int m = 2 * w + tl;
+            const float *bp = plane + m * TRW + j + h;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ky][i], bp[ky * TRW + 2 * i], acc, 0, 0, 0);
+            uint32_t myword = 0;
+            const long opix = (long)(y0 + m) * Wd + x0 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[r];
+                bool s;
+                if (REFRACTORY) v = refractory(acc[r], arp[tl][r], alpharp, wrp, s);
+                else s = v > 0.0f;
+                unsigned long long mk = __ballot(s);
+                uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                myword = (j == r) ? mine : myword;
+                if (co < c_out) {
+                    if (pv_out) pv_out[(obase + co) * HW + opix] = sigmoidf_dev(v);
+                    if (v_out) v_out[(obase + co) * HW + opix] = v;
+                }
+            }
+            const int cow = (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (spk_out && j < 16 && cow < c_out) spk_out[(obase + cow) * words + (long)(y0 + m) * wpr + tx] = myword;
+        }
+        __syncthreads();
+    }
+    // state back: the interior of the region
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int idx = tid + 256 * s, rr = idx / TRW, cc = idx % TRW;
+        if (gpix[s] >= 0 && rr >= 3 && rr < 11 && cc >= 3 && cc < 35) {
+            eps0_g[b * HW + gpix[s]] = e0[s];
+            eps1_g[b * HW + gpix[s]] = e1[s];
+        }
+    }
+    if (REFRACTORY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+                if (co < c_out) arp_g[(b * c_out + co) * HW + (long)(y0 + 2 * w + tl) * Wd + x0 + j] = arp[tl][r];
+        }
+    }
+}
+
+int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
+                        const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4,
+                        float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, int T,
+                        int B, hipStream_t st)
+{
+    if (iq && T > C1T_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "fused IQ encoder: T exceeds 4096 steps");
+    const long nwg = (long)B * (d->h / 8) * (d->w / 32);
+    if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel: batch x tiles exceeds the grid limit");
+    if (d->refractory)
+        hipLaunchKernelGGL(k_lif_seq_c1t<true>, dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i,
+                           thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,
+                           d->alpharp, d->wrp);
+    else
+        hipLaunchKernelGGL(k_lif_seq_c1t<false>, dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i,
+                           thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,
+                           d->alpharp, d->wrp);
+    HIP_CHECK_LAUNCH("k_lif_seq_c1t");
+    return DCLL_OK;
+}
+
 int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                          const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
                          float *v_out, int32_t T, int32_t B, hipStream_t st)

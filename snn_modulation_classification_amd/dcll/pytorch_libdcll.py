@@ -370,7 +370,9 @@ class Conv2dDCLLlayer(nn.Module):
     def sequence_kind(self):
         """'cells' / 'packed' if a fused all-T kernel exists for this geometry (include/dcll_hip.h), else None."""
         i = self.i2h
-        ok = (self.im_dims == (16, 16) and i.kernel_size == (7, 7) and i.padding == (3, 3) and
+        H, W = self.im_dims
+        plane_ok = (H, W) == (16, 16) or (H % 8 == 0 and W % 32 == 0)      # k_lif_seq_c1/c32 or the tiled c1t/c32t
+        ok = (plane_ok and i.kernel_size == (7, 7) and i.padding == (3, 3) and
               self.pooling == (1, 1) and i.stride == 1 and i.dilation == 1 and i.groups == 1 and
               i.out_channels <= 32 and i.bias is not None and i.spiking)
         if not ok or i.tau_per_channel() is None:
@@ -411,7 +413,7 @@ class Conv2dDCLLlayer(nn.Module):
         return cache[1], cache[2]
 
     def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False):
-        """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,8) int32 ('packed').
+        """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,H*W/32) int32 ('packed').
         Neuron state is read from / written back to self.i2h.state.
         -> (packed spikes, pv (T,B,C,H,W) or None, logits (T,B,24|48) or None).  With fuse_readout ('packed' only)
         the readout(s) are computed in the kernel's epilogue and pv is not materialised."""

@@ -88,7 +88,9 @@ class ConvNetwork(torch.nn.Module):
 
     # -- whole-sequence fast path -----------------------------------------------------------------------------------
     def sequence_supported(self):
-        """True if every layer has a fused all-T kernel (radio_ml_conv.yaml on a 16x16 I/Q plane)."""
+        """True if every layer has a fused all-T kernel: radio_ml_conv.yaml on the 16x16 I/Q plane of the reference's
+        scripts, or on a plane with H % 8 == 0 and W % 32 == 0 (the 128x128 argparse default; there the pv buffer of one
+        layer is T*B*32*H*W*4 bytes — 17 GB at T=128, B=64 — so size the batch for it)."""
         kinds = [s.dclllayer.sequence_kind() for s in self.dcll_slices]
         return kinds[0] == 'cells' and all(k == 'packed' for k in kinds[1:])
 

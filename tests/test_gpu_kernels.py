@@ -177,29 +177,38 @@ def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
     assert 0.01 < spk_d[1:].mean() < 0.9, "degenerate test: spikes all equal"
 
 
-@pytest.mark.parametrize("wrp,cout", [(1.0, 32), (0.0, 32), (1.0, 8)])
-def test_sequence_c1_vs_oracle(dev, wrp, cout):
+@pytest.mark.parametrize("wrp,cout,hw", [(1.0, 32, (16, 16)), (0.0, 32, (16, 16)), (1.0, 8, (16, 16)),
+                                         (1.0, 32, (32, 32)), (0.0, 8, (24, 64)), (1.0, 32, (128, 128))])
+def test_sequence_c1_vs_oracle(dev, wrp, cout, hw):
+    """First-layer sequence kernels (k_lif_seq_c1 on 16x16, the tiled k_lif_seq_c1t on larger planes) == C oracle
+    stepping, bit for bit, from a non-zero initial state, incl. the final state."""
     from snn_modulation_classification_amd import ops
     from oracle import c_oracle as C
     rng = np.random.RandomState(5)
-    T, B = 17, 4
+    H, Wd = hw
+    T, B = (17, 4) if H * Wd <= 4096 else (5, 2)
     W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 1, cout, gain=3.0)
-    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, (16, 16), rng=rng)
-    orc = C.OracleConvLayer(sd, (16, 16), 3, 1, wrp)
-    cells = rng.randint(0, 256, size=(T, B)).astype(np.int32)
-    d = ops.make_conv_desc(1, cout, (16, 16), 7, 3, 1, 24, False, True, wrp)
-    eps0 = torch.zeros((B, 1, 16, 16), device=dev)
-    eps1 = torch.zeros_like(eps0)
-    arp = torch.zeros((B, cout, 16, 16), device=dev)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    orc = C.OracleConvLayer(sd, hw, 3, 1, wrp)
+    orc.init_state(B)
+    orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape) * (rng.uniform(size=orc.state[0].shape) < 0.3)
+    orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape) * (rng.uniform(size=orc.state[1].shape) < 0.3)
+    if wrp > 0:
+        orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+    cells = rng.randint(0, H * Wd, size=(T, B)).astype(np.int32)
+    cells[0, 0], cells[1, 0] = 0, H * Wd - 1                    # plane corners
+    d = ops.make_conv_desc(1, cout, hw, 7, 3, 1, 24, False, True, wrp)
+    eps0, eps1 = cu(orc.state[0].copy(), dev), cu(orc.state[1].copy(), dev)
+    arp = cu(orc.state[2].copy(), dev) if wrp > 0 else torch.zeros((B, cout, H, Wd), device=dev)
     tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
     spk, pv, v = ops.conv_lif_sequence_cells(d, cu(cells, dev), cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp, T, B,
                                              want_v=True)
-    spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T, B, cout, 16, 16)
+    spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T, B, cout, H, Wd)
     v, pv = v.cpu().numpy(), pv.cpu().numpy()
     for t in range(T):
-        x = np.zeros((B, 1, 256), np.float32)
+        x = np.zeros((B, 1, H * Wd), np.float32)
         x[np.arange(B), 0, cells[t]] = 1
-        oo, op, opv, ov, os_ = orc.forward(x.reshape(B, 1, 16, 16))
+        oo, op, opv, ov, os_ = orc.forward(x.reshape(B, 1, H, Wd))
         assert bits_equal(v[t], ov), (t, np.abs(v[t] - ov).max())
         assert np.array_equal(spk_d[t], os_)
         np.testing.assert_allclose(pv[t], opv, atol=PV_TOL, rtol=0)

@@ -104,6 +104,45 @@ def test_sequence_equals_per_step_with_state_carry_over():
     assert all(float(t.abs().sum()) == 0 for s in a.dcll_slices for t in s.dclllayer.i2h.state)
 
 
+@pytest.mark.parametrize("R_,T,B", [(32, 14, 3), (128, 5, 2)])
+def test_sequence_path_on_large_planes(R_, T, B):
+    """radio_ml_conv.yaml on planes larger than the scripts' 16x16 (128x128 = the argparse default,
+    test_radio_ml.py:52): the tiled all-T kernels (one workgroup per 8x32 tile, halo recomputed) must equal the
+    per-step path — state, per-step argmax, logits — over two batches with state carry-over, from cells and from raw IQ."""
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    torch.manual_seed(6)
+    a, b, c = _radio_net(B, R_), _radio_net(B, R_), _radio_net(B, R_)
+    assert a.sequence_supported()
+    enc = IQEncoder(R_, R_, device='cuda')
+    for k in range(2):
+        iq = (0.45 * torch.randn(B, 2, 128)).cuda()
+        cells = enc(iq, T, t0=3)
+        for n in (a, b, c):
+            n.reset()
+        ra = a.test_sequence(cells)
+        rc = c.test_sequence(iq=iq, encoder=enc, T=T, t0=3)
+        per_step_logits = [[] for _ in range(3)]
+        for t in range(T):
+            x = torch.zeros(B, R_ * R_, device='cuda')
+            x[torch.arange(B), cells[t].long()] = 1
+            cur = x.reshape(B, 1, R_, R_)
+            for i, s in enumerate(b.dcll_slices):
+                o, p, pv, v = s.forward(cur, ignore_burnin=True)
+                per_step_logits[i].append(p)
+                cur = o
+        for i in range(3):
+            for name in ("eps0", "eps1", "arp"):
+                sa = getattr(a.dcll_slices[i].dclllayer.i2h.state, name)
+                sb = getattr(b.dcll_slices[i].dclllayer.i2h.state, name)
+                sc = getattr(c.dcll_slices[i].dclllayer.i2h.state, name)
+                assert torch.equal(sa, sb), (k, i, name)
+                assert torch.equal(sa, sc), (k, i, name)
+            assert torch.equal(ra["clout"][i], rc["clout"][i])
+            ref = torch.stack(per_step_logits[i])
+            np.testing.assert_allclose(ra["logits"][i].cpu().numpy(), ref.cpu().numpy(), atol=LOGIT_TOL, rtol=0)
+            assert np.array_equal(np.array(a.dcll_slices[i].clout), np.array(b.dcll_slices[i].clout))
+
+
 def test_mnist_config1_per_step(golden):
     """BASELINE config 1 geometry on the GPU per-step path (28x28, pool 2/1/2, no refractory) vs the C oracle
     (bit-exact spikes) and the reference (logits)."""
