@@ -22,3 +22,18 @@ for t in range(2, T):
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (T - 2)
 flop = 2 * 32 * 49 * R * R * (1 + 32 + 32) * B
 print("128x128 plane, B=%d: %.1f ms per timestep (%.2f TFLOP/s) -> %.2f windows/s at T=128" % (B, dt * 1e3, flop / dt / 1e12, B / (dt * 128)))
+
+# fused all-T path (k_lif_seq_c1t / k_lif_seq_c32t): python experiments/plane128_timing.py B seq [T]
+if len(sys.argv) > 2 and sys.argv[2] == "seq":
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    Ts = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    enc = IQEncoder(R, R, device='cuda')
+    iq = (0.4 * torch.randn(B, 2, 128)).cuda()
+    for rep in range(3):
+        prof = {}
+        net.zero_states(); net.reset()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        net.test_sequence(iq=iq, encoder=enc, T=Ts, t0=0, profile=prof)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        parts = {k: [round(a.elapsed_time(b), 2) for a, b in v] for k, v in prof.items()}
+        print("fused, B=%d T=%d: %.1f ms -> %.1f windows/s  %s" % (B, Ts, dt * 1e3, B / dt, parts))

@@ -594,6 +594,82 @@ __global__ __launch_bounds__(256) void k_readout_v4(const float *__restrict__ pv
     }
 }
 
+// Long rows, moderately many of them (rows = T*B of a 128x128 plane: 8192 rows of K = 524288): 128-row tiles would be
+// only 64 workgroups, so here a workgroup takes 32 rows and its 4 waves split every 128-float K-chunk between them
+// (wave w: floats 32w..32w+31); the four partial tiles are combined in LDS in fixed order (deterministic).
+constexpr int RK_ROWS = 32, RK_KC = 128, RK_LD = 129;
+template <int NT>
+__global__ __launch_bounds__(256) void k_readout_ks(const float *__restrict__ pv, const float *__restrict__ Wt,
+                                                     const float *__restrict__ bias, float *__restrict__ out,
+                                                     long rows, int K, int N)
+{
+    __shared__ float sm[(RK_ROWS + NT * 32) * RK_LD];
+    float *sA = sm, *sB = sm + RK_ROWS * RK_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long row0 = (long)blockIdx.x * RK_ROWS;
+    const int kq = (tid & 31) * 4, rsub = tid >> 5;         // 32 threads x float4 = one 128-float K-chunk of a row
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    f32x4 ra[4], rb[NT * 4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long gr = row0 + rsub + 8 * i;
+            ra[i] = gr < rows ? *(const f32x4 *)(pv + gr * K + k0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) {
+            int nn = rsub + 8 * i;
+            rb[i] = nn < N ? *(const f32x4 *)(Wt + (long)nn * K + k0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += RK_KC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sA[(rsub + 8 * i) * RK_LD + kq + e] = ra[i][e];
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sB[(rsub + 8 * i) * RK_LD + kq + e] = rb[i][e];
+        __syncthreads();
+        if (k0 + RK_KC < K) fetch(k0 + RK_KC);
+        const float *a = sA + (lane & 31) * RK_LD + 32 * wave + (lane >> 5);
+        const float *bb = sB + (lane & 31) * RK_LD + 32 * wave + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float av = a[2 * kk];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[t * 32 * RK_LD + 2 * kk], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // partial tiles -> LDS [wave][t][r][lane], then 256 threads add the four in wave order
+    float *red = sm;
+    static_assert(4 * NT * 1024 <= (RK_ROWS + NT * 32) * RK_LD, "reduction buffer must fit the tile buffers");
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    for (int e = tid; e < NT * 1024; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
+        const int n = t * 32 + (l & 31);
+        const long gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (n < N && gr < rows) {
+            float tot = red[e];
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) tot += red[wv * NT * 1024 + e];
+            out[gr * N + n] = tot + (bias ? bias[n] : 0.0f);
+        }
+    }
+}
+
 // Few rows (per-step calls: rows = batch): the 128-row tiles above would leave most CUs idle, so here one workgroup
 // takes RS_RB rows and RS_NG readout rows of Wt (grid = rows/RS_RB x ceil(N / RS_NG): enough workgroups even when K is huge,
 // e.g. 32*128*128 on the 128x128 plane), its 256 threads stride over K, and a fixed-order LDS tree combines them
@@ -1232,6 +1308,12 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
     if (rows <= 2048) {
         hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)((rows + RS_RB - 1) / RS_RB), (N + RS_NG - 1) / RS_NG), dim3(256),
                            0, st, pv, Wt, bias, out, rows, K, N);
+    } else if (fast && K % RK_KC == 0 && K >= 8 * RK_KC && rows < 256L * RO_ROWS) {
+        // fewer 128-row tiles than CUs: 32-row tiles with the K-chunk split over the waves
+        if (N <= 32)
+            hipLaunchKernelGGL(k_readout_ks<1>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+        else
+            hipLaunchKernelGGL(k_readout_ks<2>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast && N <= 32) {
         hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast) {

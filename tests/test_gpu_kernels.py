@@ -389,6 +389,22 @@ def test_readout_gemm_fast_path(dev, rows, K, N):
     np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("rows,K,N", [(2100, 4096, 24), (2049, 1024, 48), (4000, 2048, 33), (2500, 8192, 10)])
+def test_readout_gemm_long_rows(dev, rows, K, N):
+    """k_readout_ks: more than 2048 rows but fewer 128-row tiles than CUs (T*B rows of a large plane) — 32-row tiles,
+    the K-chunk split over the 4 waves, partials combined in fixed order (run-to-run identical)."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(2)
+    pv = rng.uniform(0, 1, size=(rows, K)).astype(np.float32)
+    Wt = rng.uniform(-.01, .01, size=(N, K)).astype(np.float32)
+    b = rng.uniform(-.01, .01, size=(N,)).astype(np.float32)
+    a1 = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev))
+    a2 = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev))
+    assert torch.equal(a1, a2)
+    ref = (pv.astype(np.float64) @ Wt.astype(np.float64).T + b).astype(np.float32)
+    np.testing.assert_allclose(a1.cpu().numpy(), ref, atol=2e-5, rtol=0)
+
+
 @pytest.mark.parametrize("case", ["mnist_l0", "mnist_l2", "pool3", "scalar_tau", "radio_l2_out", "ref_tuple"])
 def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
     """dcll_conv_lif_backward (all four incoming gradients, pooling incl. ties routing, output layer) against torch
