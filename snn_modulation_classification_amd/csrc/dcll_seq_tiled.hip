@@ -12,21 +12,30 @@
 //   - an MFMA tile is ONE image row of 32 pixels (lane&31 = column), so every spike word is still one ballot half
 //     and the B-fragment reads of a half-wave are 32 consecutive floats (conflict free);
 //   - the workgroup keeps the eps1 traces of its tile PLUS the 3-pixel halo (14 rows x 38 columns per channel,
-//     row stride TRW, channel stride TCH = 32 mod 64 banks) and recomputes the halo redundantly (2.08x trace work,
-//     <2 % of the stage; the halo values are the same fp32 ops on the same inputs as the owning tile computes, so the
-//     result stays bit-exact).  Pixels outside the plane stay 0 = the convolution's zero padding;
-//   - only wave w ever reads its 4 channels of the image, so ONE image suffices: region rows are advanced to the next
-//     step in place as soon as the wave's own chain no longer needs them (row r is last read by tile r):
-//       end of stage m=2: rows 0-2 -> step t+1      end of stage m=0: rows 9-11  -> step t  (first read by tile 3)
-//       end of stage m=5: rows 3-5 -> step t+1      end of stage m=1: rows 12-13 -> step t  (first read by tile 6)
-//       end of stage m=7: rows 6-8 -> step t+1
-//     with the input spike words fetched at the start of the stage and consumed after the MFMA chain.
-// eps0 of the region lives in registers (5 row groups x 2 slots x 4 channels).
+//     row stride TRW, channel stride TCH = 32 mod 64 banks) and recomputes the halo redundantly (2.08x trace work;
+//     the halo values are the same fp32 ops on the same inputs as the owning tile computes, so the result stays
+//     bit-exact).  Pixels outside the plane stay 0 = the convolution's zero padding;
+//   - only the wave that owns 4 input channels ever reads them, so ONE image suffices: region row r (last read by
+//     tile min(r,7), first needed again by tile max(0,r-6)) is advanced in place between those two reads;
+//   - chain position p (channels 4p..4p+3) sits on hardware wave 4*(p&1) + (p>>1): the two waves of a SIMD are
+//     neighbours in the chain, so their tile indices m = (g - p) & 7 always differ in parity, and every wave carries
+//     its non-MFMA work — its epilogue share AND its trace rows — in its EVEN-m stages while its SIMD partner starts
+//     its MFMAs at once (the arrangement that k_lif_seq_c32 measured best):
+//       m = 0: rows 6-8  -> step t      m = 4: rows 12-13 -> step t, rows 0-1 -> step t+1
+//       m = 2: rows 9-11 -> step t      m = 6: rows 2-5   -> step t+1
+//   - input spikes: one global load per lane fetches the (row, channel, word) triples of a row group one stage ahead;
+//     the lanes of a trace element pick their word with ds_bpermute (one VGPR held across the chain, not 8).
+// eps0 of the region lives in registers (11 element slots x 4 channels).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TRW = 38, TCH = 544, TIMG = 32 * TCH;
-constexpr int TGROUP = 3 * TRW;         // floats per row group (3 rows; the 5th group has 2)
 
-template <bool REFRACTORY, int OUT>     // OUT bit0: pv, bit1: v
+// row groups of the trace schedule: first region row, number of rows
+struct tgroup { int row0, nrows; };
+__device__ constexpr tgroup TG[5] = {{6, 3}, {9, 3}, {12, 2}, {0, 2}, {2, 4}};
+
+// ABLATE is a diagnostic knob for experiments/ablate_c32t.hip only (bit0: no epilogue, bit1: no trace advance,
+// bit2: no accumulator hand-off); every product launch uses ABLATE = 0.
+template <bool REFRACTORY, int OUT, int ABLATE = 0>     // OUT bit0: pv, bit1: v
 __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                        const float *__restrict__ bias, const float *__restrict__ tau4,
                                                        float *__restrict__ eps0_g, float *__restrict__ eps1_g,
@@ -38,8 +47,9 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
     float *slots = lds + TIMG;
     float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wq = w & 3, wpar = w >> 2;
+    const int hwv = __builtin_amdgcn_readfirstlane(tid >> 6);   // hardware wave; SIMD = hwv & 3
+    const int wq = hwv & 3, wpar = hwv >> 2;                     // epilogue quad / tile parity owned by this wave
+    const int w = 2 * wq + wpar;                                 // position in the chain: channels 4w..4w+3
     const int wpr = Wd >> 5;                                  // spike words per image row = tiles per row
     const int ntile = (H >> 3) * wpr;
     const long b = blockIdx.x / ntile;
@@ -51,58 +61,70 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
     for (int i = tid; i < TIMG; i += 512) lds[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
 
-    // trace element (group k, slot s) of a lane: region element idx = lane + 64 s of the group's 3 (2) rows, i.e.
-    // row 3k + idx / 38, column idx % 38; its LDS offset inside a channel image is simply 114 k + idx.
-    int erow[2], egx[2], eoff[2];
-    bool colok[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int idx = lane + 64 * s;
-        erow[s] = idx / TRW;
-        egx[s] = x0 - 3 + (idx % TRW);
-        colok[s] = (unsigned)egx[s] < (unsigned)Wd;
-        eoff[s] = colok[s] ? erow[s] * wpr + (egx[s] >> 5) : 0;      // word offset inside the group's rows
-    }
-    // global position of element (k, s): row gy = y0 - 3 + 3k + erow[s], column egx[s]; valid if inside the plane and
-    // inside the group (idx < 114, or < 76 for the last group)
-    auto in_group = [&](int k, int s) -> bool { return lane + 64 * s < (k < 4 ? TGROUP : 2 * TRW); };
-    auto elem_ok = [&](int k, int s) -> bool {
-        return in_group(k, s) && colok[s] && (unsigned)(y0 - 3 + 3 * k + erow[s]) < (unsigned)H;
-    };
+    // trace element slot s of a lane inside a row group: element idx = lane + 64 s of the group's rows, i.e. group row
+    // idx / 38, column idx % 38; its LDS offset inside a channel image is row0 * 38 + idx.
+    auto erow = [&](int s) -> int { return (lane + 64 * s) / TRW; };
+    auto ecol = [&](int s) -> int { return (lane + 64 * s) % TRW; };
+    // spike-word fetch role of a lane: (group row fr, channel fc, word fw - 1 relative to the tile's own word tx)
+    const int fr = lane / 12, fc = (lane % 12) / 3, fw = lane % 3;
+    const bool fwok = (unsigned)(tx - 1 + fw) < (unsigned)wpr;
+    const int foff = fwok ? fr * wpr + fc * (int)words + fw : 0;        // < 2^31: 32 channels of the plane fit an int
     const uint32_t *in_b = spk_in + (b * 32 + 4 * w) * words;
     const long in_step = (long)B * 32 * words;
-    // spike words of (step ts, group k): xw[s][c]; wave-uniform base + one 32-bit lane offset per slot
-    auto fetch = [&](int k, int ts, uint32_t (&xw)[2][4]) {
-        const uint32_t *base = in_b + (long)ts * in_step + (long)(y0 - 3 + 3 * k) * wpr;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bool ok = elem_ok(k, s);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xw[s][c] = ok ? (base + c * words)[eoff[s]] : 0u;
-        }
+    auto fetch = [&](int gi, int ts) -> uint32_t {       // gi, ts wave-uniform
+        const int gy = y0 - 3 + TG[gi].row0 + fr;
+        const bool ok = fr < TG[gi].nrows && fwok && (unsigned)gy < (unsigned)H;
+        const uint32_t *base = in_b + (long)ts * in_step + (long)(y0 - 3 + TG[gi].row0) * wpr + (tx - 1);
+        return ok ? base[foff] : 0u;
     };
-    float e0[5][2][4];
+    // input bit of element (slot s, channel c) out of the fetched words: source lane erow*12 + 3c + word select.
+    // pb / sh: per-slot byte address of the source lane for c = 0 and the bit position; kept to 6 registers (the
+    // asm keeps the compiler from hoisting all 12 (s, c) addresses out of the stage loop).
+    int pb[3], sh[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        pb[s] = (erow(s) * 12 + (((ecol(s) - 3) >> 5) + 1)) * 4;
+        sh[s] = (ecol(s) - 3) & 31;
+    }
+    auto spike_bit = [&](uint32_t word, int s, int c) -> float {
+        int a = pb[s];
+        asm volatile("" : "+v"(a));
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_ds_bpermute(a + 12 * c, (int)word);
+        return (float)((wv >> sh[s]) & 1u);
+    };
+    // x * tau_s for x in {0, 1} without the int->float conversion: sign-extend the spike bit to a 0 / ~0 mask and AND
+    // it onto tau_s (exact: the product is tau_s or +0.0)
+    auto spike_times = [&](uint32_t word, int s, int c, float ts) -> float {
+        int a = pb[s];
+        asm volatile("" : "+v"(a));
+        const int wv = __builtin_amdgcn_ds_bpermute(a + 12 * c, (int)word);
+        const int mask = __builtin_amdgcn_sbfe(wv, sh[s], 1);
+        return __int_as_float(mask & __float_as_int(ts));
+    };
+    float e0[5][3][4];
     __syncthreads();        // image zeroed
 
     // prologue: state of the region from HBM (0 outside the plane), advanced to step 0 -> image
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        uint32_t xw[2][4];
-        fetch(k, 0, xw);
+    for (int gi = 0; gi < 5; ++gi) {
+        const uint32_t word = fetch(gi, 0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bool ok = elem_ok(k, s);
-            const long goff = (long)(y0 - 3 + 3 * k + erow[s]) * Wd + egx[s];
+        for (int s = 0; s < 3; ++s) {
+            if (64 * s >= TG[gi].nrows * TRW) continue;
+            const int idx = lane + 64 * s;
+            const int gy = y0 - 3 + TG[gi].row0 + erow(s), gx = x0 - 3 + ecol(s);
+            const bool ing = idx < TG[gi].nrows * TRW;
+            const bool ok = ing && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
                 const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
-                const long gidx = (b * 32 + 4 * w + c) * HW + goff;
+                const long gidx = (b * 32 + 4 * w + c) * HW + (long)gy * Wd + gx;
                 float e0v = ok ? eps0_g[gidx] : 0.0f, e1 = ok ? eps1_g[gidx] : 0.0f;
-                const float xin = (float)((xw[s][c] >> (egx[s] & 31)) & 1u);
+                const float xin = spike_bit(word, s, c);
                 trace_update(xin, ta, tm, tas, ts, e0v, e1);
-                e0[k][s][c] = e0v;
-                if (in_group(k, s)) lds[(4 * w + c) * TCH + k * TGROUP + lane + 64 * s] = e1;
+                e0[gi][s][c] = e0v;
+                if (ing) lds[(4 * w + c) * TCH + TG[gi].row0 * TRW + idx] = e1;
             }
         }
         __builtin_amdgcn_sched_barrier(0);      // one group at a time: keeps the prologue's register peak low
@@ -133,36 +155,70 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
         for (int k = 0; k < 49; ++k) asm volatile("" ::"v"(wf[cp][k]));
     __syncthreads();
 
-    // advance group K of my 4 channels by one step with the fetched spike words
-    auto advance = [&](auto KC, const uint32_t (&xw)[2][4]) {
-        constexpr int K = decltype(KC)::value;
+    // advance row group GI of my 4 channels by one step with the fetched spike words.  Branch-free and batched: all
+    // ds_bpermutes and image reads go out first, then the arithmetic, then the writes — one LDS round trip per phase
+    // instead of one per element (per-element exec-mask branches made this 8.5k cycles per stage).  Lanes past the
+    // end of the group are pointed at the 12 pad floats behind their channel's 14 x 38 image (never read).
+    auto advance = [&](auto GC, uint32_t word) {
+        constexpr int GI = decltype(GC)::value;
+        constexpr int NS = (TG[GI].nrows * TRW + 63) / 64;
+        float xts[NS][4], e1[NS][4];        // x * tau_s, eps1
+        int off[NS];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
-            const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
+        for (int s = 0; s < NS; ++s) {
+            off[s] = (lane + 64 * s < TG[GI].nrows * TRW) ? TG[GI].row0 * TRW + lane + 64 * s : 14 * TRW;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (in_group(K, s)) {
-                    float *p = lds + (4 * w + c) * TCH + K * TGROUP + lane + 64 * s;
-                    float e1 = *p, e0v = e0[K][s][c];
-                    // (opaque to the SLP vectoriser: paired v_pk_* forms of these updates cost ~70 spilled registers)
-                    asm volatile("" : "+v"(e1), "+v"(e0v));
-                    const float xin = (float)((xw[s][c] >> (egx[s] & 31)) & 1u);
-                    trace_update(xin, ta, tm, tas, ts, e0v, e1);
-                    asm volatile("" : "+v"(e1), "+v"(e0v));
-                    e0[K][s][c] = e0v;
-                    *p = e1;
-                }
+            for (int c = 0; c < 4; ++c) {
+                xts[s][c] = (ABLATE & 8) ? 0.0f : spike_times(word, s, c, tau4[3 * 32 + 4 * w + c]);
+                e1[s][c] = lds[(4 * w + c) * TCH + off[s]];
             }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c], tas = tau4[2 * 32 + 4 * w + c];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {      // dcll/pytorch_libdcll.py:493-494, every op rounded separately
+                const float bb = tas * e0[GI][s][c];
+                e0[GI][s][c] = xts[s][c] + bb;
+                const float cc = ta * e1[s][c];
+                const float dd = e0[GI][s][c] * tm;
+                e1[s][c] = cc + dd;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds[(4 * w + c) * TCH + off[s]] = e1[s][c];
     };
 
     const int nstage = 8 * T + 9;
+    uint32_t fw0 = 0, fw1 = 0;          // spike words of the row group(s) my next even-m stage advances
+    unsigned long long dbg_wait = 0, dbg_t0 = 0, dbg_epi = 0, dbg_tr = 0, dbg_mf = 0;   // ABLATE & 64 only
+    if (ABLATE & 64) dbg_t0 = __builtin_amdgcn_s_memtime();
     for (int g = 0; g < nstage; ++g) {
+        unsigned long long dbg_a = 0;
+        if (ABLATE & 64) dbg_a = __builtin_amdgcn_s_memtime();
+        const int q = g - w;
+        const bool active = q >= 0 && q < 8 * T;
+        const int m = q & 7, t = q >> 3;
+        // ---- (0) odd m: fetch the spike words for the groups of my next stage (m+1, even; step tn) ----
+        if (!(ABLATE & (2 | 8)) && q >= 0 && q + 1 < 8 * T && (m & 1)) {
+            const int tn = (q + 1) >> 3;
+            switch (m) {
+            case 7: if (tn >= 1) fw0 = fetch(0, tn); break;                  // m' = 0: rows 6-8 -> tn
+            case 1: if (tn >= 1) fw0 = fetch(1, tn); break;                  // m' = 2: rows 9-11 -> tn
+            case 3:                                                          // m' = 4: rows 12-13 -> tn, rows 0-1 -> tn+1
+                if (tn >= 1) fw0 = fetch(2, tn);
+                if (tn + 1 < T) fw1 = fetch(3, tn + 1);
+                break;
+            default: if (tn + 1 < T) fw0 = fetch(4, tn + 1); break;          // m' = 6: rows 2-5 -> tn+1
+            }
+        }
         // ---- (1) epilogue share: quad wq of tile qe = g - 8 ----
         const int qe = g - 8;
-        if (qe >= 0 && qe < 8 * T && ((qe & 1) == wpar)) {
-            __builtin_amdgcn_s_setprio(1);
+        const bool loaded = ((g & 1) == wpar);          // <=> my m is even: this stage carries my non-MFMA work
+        if (loaded) __builtin_amdgcn_s_setprio(1);
+        if (!(ABLATE & 1) && qe >= 0 && qe < 8 * T && loaded) {
             const int te = qe >> 3, me = qe & 7;
             const f32x4 v4 = *((const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + wq * 64 + lane);
             const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
@@ -190,25 +246,29 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
             case 2: quad(arp[2]); break;
             default: quad(arp[3]); break;
             }
-            __builtin_amdgcn_s_setprio(0);
         }
-        const int q = g - w;
-        if (q >= 0 && q < 8 * T) {
-            const int m = q & 7, t = q >> 3;
-            // ---- (2a) spike words of the row group this stage advances (consumed after the chain) ----
-            //   m = 2, 5, 7 -> groups 0, 1, 2 to step t+1;   m = 0, 1 -> groups 3, 4 to step t (t >= 1)
-            int tg = -1, tstep = 0;
-            if (m == 2) { tg = 0; tstep = t + 1; }
-            else if (m == 5) { tg = 1; tstep = t + 1; }
-            else if (m == 7) { tg = 2; tstep = t + 1; }
-            else if (m == 0) { tg = 3; tstep = t; }
-            else if (m == 1) { tg = 4; tstep = t; }
-            if (tstep >= T || tstep < 1) tg = -1;
-            uint32_t xw[2][4];
-            if (tg >= 0) fetch(tg, tstep, xw);
+        if (ABLATE & 64) { unsigned long long x_ = __builtin_amdgcn_s_memtime(); dbg_epi += x_ - dbg_a; dbg_a = x_; }
+        if (active) {
+            // ---- (2) even m: advance my row group(s) (their rows are not read between tile m-1 and tile m) ----
+            if (!(ABLATE & 2) && !(m & 1)) {
+                switch (m) {        // wave-uniform: keeps e0[][][] statically indexed (registers)
+                case 0: if (t >= 1) advance(std::integral_constant<int, 0>{}, fw0); break;
+                case 2: if (t >= 1) advance(std::integral_constant<int, 1>{}, fw0); break;
+                case 4:
+                    if (t >= 1) advance(std::integral_constant<int, 2>{}, fw0);
+                    if (t + 1 < T) advance(std::integral_constant<int, 3>{}, fw1);
+                    break;
+                default: if (t + 1 < T) advance(std::integral_constant<int, 4>{}, fw0); break;
+                }
+            }
+            if (loaded) __builtin_amdgcn_s_setprio(0);
+            if (ABLATE & 64) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned long long x_ = __builtin_amdgcn_s_memtime(); dbg_tr += x_ - dbg_a; dbg_a = x_;
+            }
             // ---- (3) my K-slice of the chain ----
             f32x16 acc;
-            if (w == 0) {
+            if (w == 0 || (ABLATE & 4)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
             } else {
@@ -238,37 +298,52 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
                 __builtin_amdgcn_sched_barrier(0);
             }
             f32x4 *dp = (f32x4 *)(slots + (w * 2 + (g & 1)) * SLOT_FLOATS) + lane;
+            if (ABLATE & 4) {
+                if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.678f) dp[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 v4 = {acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
-                dp[c * 64] = v4;
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 v4 = {acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+                    dp[c * 64] = v4;
+                }
             }
-            // ---- (2b) advance the row group (its rows are no longer read by this step's remaining tiles) ----
-            switch (tg) {       // wave-uniform: keeps e0[][][] statically indexed (registers)
-            case 0: advance(std::integral_constant<int, 0>{}, xw); break;
-            case 1: advance(std::integral_constant<int, 1>{}, xw); break;
-            case 2: advance(std::integral_constant<int, 2>{}, xw); break;
-            case 3: advance(std::integral_constant<int, 3>{}, xw); break;
-            case 4: advance(std::integral_constant<int, 4>{}, xw); break;
-            default: break;
-            }
+        } else if (loaded) {
+            __builtin_amdgcn_s_setprio(0);
         }
-        __syncthreads();
+        // stage barrier: only the LDS traffic (slots, image) has to be complete — NOT the pv / spike stores of the
+        // epilogue, which __syncthreads() would also wait for (s_waitcnt vmcnt(0)).
+        if (ABLATE & 64) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned long long x_ = __builtin_amdgcn_s_memtime();
+            dbg_mf += x_ - dbg_a;
+            asm volatile("s_barrier" ::: "memory");
+            dbg_wait += __builtin_amdgcn_s_memtime() - x_;
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    if ((ABLATE & 64) && lane == 0 && blockIdx.x == 0) {
+        unsigned long long tot = __builtin_amdgcn_s_memtime() - dbg_t0;
+        unsigned long long *dp = (unsigned long long *)v_out + w * 8;       // v_out doubles as the debug buffer
+        dp[0] = tot; dp[1] = dbg_wait; dp[2] = dbg_epi; dp[3] = dbg_tr; dp[4] = dbg_mf;
     }
 
     // state back to HBM: the interior of the region (rows 3..10, columns 3..34)
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int gi = 0; gi < 5; ++gi)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int idx = lane + 64 * s, rr = 3 * k + erow[s], cc = idx % TRW;
-            if (in_group(k, s) && rr >= 3 && rr < 11 && cc >= 3 && cc < 35) {
-                const long goff = (long)(y0 - 3 + rr) * Wd + egx[s];
+        for (int s = 0; s < 3; ++s) {
+            if (64 * s >= TG[gi].nrows * TRW) continue;
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));            // recomputed here: not worth registers across the stage loop
+            const int idx = l2 + 64 * s, rr = TG[gi].row0 + idx / TRW, cc = idx % TRW;
+            if (idx < TG[gi].nrows * TRW && rr >= 3 && rr < 11 && cc >= 3 && cc < 35) {
+                const long goff = (long)(y0 - 3 + rr) * Wd + x0 - 3 + cc;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const long gidx = (b * 32 + 4 * w + c) * HW + goff;
-                    eps0_g[gidx] = e0[k][s][c];
-                    eps1_g[gidx] = lds[(4 * w + c) * TCH + k * TGROUP + idx];
+                    eps0_g[gidx] = e0[gi][s][c];
+                    eps1_g[gidx] = lds[(4 * w + c) * TCH + TG[gi].row0 * TRW + idx];
                 }
             }
         }
