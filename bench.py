@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: IQ windows/sec of the DCLL LIF timestep loop (radio_ml_conv.yaml, 16x16 I/Q plane, T=128).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--plane R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,6 +9,8 @@ One step = one pass of the hot path over one batch of synthetic IQ windows alrea
 net.zero_states() + net.reset() -> all T steps of all three layers (fused sequence kernels; the IQ -> spike encoding
 is fused into the first layer's kernel) -> readouts -> per-step argmax + vote -> per-class tallies (all-reduced).
 That is the span of the reference's test_radio_ml.py:142-146 plus its input encoding (:133-135).
+`--plane 128` runs the same path on the reference's argparse-default 128x128 I/Q plane (test_radio_ml.py:52; tiled
+kernels k_lif_seq_c1t / k_lif_seq_c32t, default batch 64) — a secondary configuration, not the headline number.
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` for the dominant kernel
 (k_lif_seq_c32, fp32 MFMA bound) and `cpu_baseline` (the torch-CPU port of the reference timed on this host).
 """
@@ -30,9 +32,10 @@ from snn_modulation_classification_amd import parallel  # noqa: E402
 from snn_modulation_classification_amd.data.utils import IQEncoder  # noqa: E402
 from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec  # noqa: E402
 
-T_STEPS, R, L_IQ, N_CLASSES = 128, 16, 128, 24
-# algorithmic FLOPs of one k_lif_seq_c32 launch per sample per step: 2 * c_out * (c_in*7*7) * H*W
-FLOP_C32_PER_SAMPLE_STEP = 2 * 32 * (32 * 49) * 256
+T_STEPS, L_IQ, N_CLASSES = 128, 128, 24
+R = 16          # I/Q plane resolution; --plane overrides (16 = the reference scripts' setting = the headline config)
+# algorithmic FLOPs of one k_lif_seq_c32 launch per sample per step per pixel: 2 * c_out * (c_in*7*7)
+FLOP_C32_PER_SAMPLE_STEP_PIXEL = 2 * 32 * (32 * 49)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 PEAK_HBM_GBS = 8000.0
 
@@ -108,9 +111,9 @@ def cpu_baseline(net, convs, cells_cpu, gpu_votes, n_windows):
         dt = min(dts)
     agree = float(np.mean(votes[-1] == gpu_votes[:n_windows]))
     return {"value": n_windows / dt, "unit": "IQ windows/s", "cores": cores, "kind": "port",
-            "sample": "batch of %d windows x T=%d, 16x16 plane, reset -> T x test(x[t]) -> votes, best of 3 (%.1f s "
+            "sample": "batch of %d windows x T=%d, %dx%d plane, reset -> T x test(x[t]) -> votes, best of 3 (%.1f s "
                       "each), torch %s CPU, %d threads (fastest of the calibrated counts <= cgroup quota)" %
-                      (n_windows, T, dt, torch.__version__, torch.get_num_threads()),
+                      (n_windows, T, R, R, dt, torch.__version__, torch.get_num_threads()),
             "vote_agreement_with_gpu": agree}
 
 
@@ -119,11 +122,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="IQ windows per GPU per step (weak scaling)")
-    ap.add_argument("--cpu-windows", type=int, default=512,
-                    help="CPU baseline batch (0 = skip); 512 = batch_size_test of the reference's scripts")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="IQ windows per GPU per step (weak scaling); default 4096 (16x16 plane) / 64 (larger planes)")
+    ap.add_argument("--plane", type=int, default=16, help="I/Q plane resolution R (R x R cells): 16 or a multiple of 32")
+    ap.add_argument("--cpu-windows", type=int, default=None,
+                    help="CPU baseline batch (0 = skip); default 512 = batch_size_test of the reference's scripts "
+                         "(4 on planes larger than 16x16, where the CPU path needs seconds per window)")
     ap.add_argument("--fuse-readout", type=int, default=0, help="1: readouts in the layer kernel's epilogue")
     a = ap.parse_args()
+    global R
+    R = a.plane
+    if a.batch is None:
+        a.batch = 4096 if R == 16 else 64
+    if a.cpu_windows is None:
+        a.cpu_windows = 512 if R == 16 else 4
+    hot_kernel = "k_lif_seq_c32" if R == 16 else "k_lif_seq_c32t"
 
     rank, local_rank, world = parallel.init_process_group()
     assert world == a.gpus, "launch with torchrun --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
@@ -173,7 +186,7 @@ def main():
     # dominant kernel: HIP-event time of every k_lif_seq_c32 launch of the timed region (same stream as the launch)
     c32_ms = [s.elapsed_time(e) for s, e in prof.get("lif_c32", [])]
     avg_c32_s = float(np.mean(c32_ms)) / 1e3 if c32_ms else float("nan")
-    flop_per_launch = FLOP_C32_PER_SAMPLE_STEP * T_STEPS * B
+    flop_per_launch = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T_STEPS * B
     achieved = flop_per_launch / avg_c32_s / 1e12
     # HBM bytes of the dominant kernel: PMC counters cannot be read from inside this process; the committed summary of
     # the separate `rocprofv3 --pmc` passes of this same command (profiles/r01_pmc_b4096.json) is used when the batch
@@ -182,7 +195,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_b4096.json")) as f:
             pmc = json.load(f)
-        if pmc.get("k_lif_seq_c32_batch") == B:
+        if R == 16 and pmc.get("k_lif_seq_c32_batch") == B:
             traffic = pmc["k_lif_seq_c32_traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -198,12 +211,12 @@ def main():
             "unit": "IQ windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "radio_ml_conv.yaml, 16x16 I/Q plane, T=128, arp=1.0, random_tau, batch %d per GPU%s, "
+            "config": {"workload": "radio_ml_conv.yaml, %dx%d I/Q plane, T=128, arp=1.0, random_tau, batch %d per GPU%s, "
                                    "synthetic IQ 0.4*randn(B,2,128), seeded init" %
-                                   (B, " (north_star headline batch)" if B == 4096 else ""),
+                                   (R, R, B, " (north_star headline batch)" if (B == 4096 and R == 16) else ""),
                        "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [R, R],
                        "parallelism": "batch shards, %d rank(s), tally all-reduce only" % world},
-            "roofline": {"kernel": "k_lif_seq_c32", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": hot_kernel, "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)",
                          "avg_launch_ms": avg_c32_s * 1e3, "launches": len(c32_ms),
