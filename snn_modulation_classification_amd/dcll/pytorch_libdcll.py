@@ -197,22 +197,26 @@ class ContinuousConv2D(nn.Module):
                 None if output_ is None else output_.weight, None if output_ is None else output_.bias)
 
     def _fast_step_ok(self, input, pooling):
-        """32->32, 7x7 pad 3, 16x16, pool 1, per-channel time constants: the MFMA sequence kernel serves one step."""
+        """32->32, 7x7 pad 3, pool 1, per-channel time constants, on a 16x16 plane or one with H % 8 == 0 and
+        W % 32 == 0: the MFMA sequence kernels (k_lif_seq_c32 / k_lif_seq_c32t) serve one step."""
+        H, W = tuple(input.shape[2:4])
         return (self.in_channels == 32 and self.out_channels == 32 and self.kernel_size == (7, 7) and
-                self.padding == (3, 3) and tuple(input.shape[2:4]) == (16, 16) and tuple(pooling) == (1, 1) and
-                self.stride == 1 and self.dilation == 1 and self.groups == 1 and self.bias is not None and
-                self.tau_per_channel() is not None)
+                self.padding == (3, 3) and ((H, W) == (16, 16) or (H % 8 == 0 and W % 32 == 0)) and
+                tuple(pooling) == (1, 1) and self.stride == 1 and self.dilation == 1 and self.groups == 1 and
+                self.bias is not None and self.tau_per_channel() is not None)
 
     def _step_packed(self, desc, input, st, arp, i2o, output_):
         """One step through the weight-stationary MFMA kernel (T = 1, state in HBM) for layers whose input is known
         to be a binary spike map (`binary_input`, set by ConvNetwork for every layer fed by another layer): bit-pack ->
-        k_lif_seq_c32 -> unpack; 20x faster than the generic per-step kernels and bit-identical to them."""
-        B = input.shape[0]
+        k_lif_seq_c32(t) -> unpack; 20x faster than the generic per-step kernels on the 16x16 plane and bit-identical
+        to them."""
+        B, _, H, W = input.shape
+        words = H * W // 32
         with torch.no_grad():
-            spk_in = ops.pack_spikes(input.reshape(B, 32, 256)).reshape(1, B, 32, 8)
+            spk_in = ops.pack_spikes(input.reshape(B, 32, H * W)).reshape(1, B, 32, words)
             spk, pv, v = ops.conv_lif_sequence(desc, spk_in, self.weight, self.bias, self.tau_per_channel(), st.eps0,
                                                st.eps1, arp, 1, B, want_v=True)
-            s = ops.unpack_spikes(spk.reshape(B, 32, 8)).reshape(B, 32, 16, 16)
+            s = ops.unpack_spikes(spk.reshape(B, 32, words)).reshape(B, 32, H, W)
             pv, v = pv[0], v[0]
             flat = pv.reshape(B, -1)
             p = ops.readout(flat, i2o.weight, i2o.bias) if i2o is not None else None
