@@ -1308,8 +1308,10 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
     if (rows <= 2048) {
         hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)((rows + RS_RB - 1) / RS_RB), (N + RS_NG - 1) / RS_NG), dim3(256),
                            0, st, pv, Wt, bias, out, rows, K, N);
-    } else if (fast && K % RK_KC == 0 && K >= 8 * RK_KC && rows < 256L * RO_ROWS) {
-        // fewer 128-row tiles than CUs: 32-row tiles with the K-chunk split over the waves
+    } else if (fast && K % RK_KC == 0 && K >= 65536 && rows < 256L * RO_ROWS) {
+        // long rows (large planes) and fewer 128-row tiles than CUs: 32-row tiles with the K-chunk split over the
+        // waves.  (K of the 16x16 plane, 8192, always takes k_readout_v4: its logits then do not depend on how a
+        // run is split into launches.)
         if (N <= 32)
             hipLaunchKernelGGL(k_readout_ks<1>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
         else

@@ -416,17 +416,22 @@ class Conv2dDCLLlayer(nn.Module):
             self._ro_cache = cache
         return cache[1], cache[2]
 
-    def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False):
+    def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False, batch_slice=None):
         """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,H*W/32) int32 ('packed').
-        Neuron state is read from / written back to self.i2h.state.
+        Neuron state is read from / written back to self.i2h.state (rows batch_slice .. batch_slice+B of it when
+        `batch_slice` is given: a chunk of a larger batch).
         -> (packed spikes, pv (T,B,C,H,W) or None, logits (T,B,24|48) or None).  With fuse_readout ('packed' only)
         the readout(s) are computed in the kernel's epilogue and pv is not materialised."""
         i2h = self.i2h
-        if i2h.state is None or i2h.state.eps0.shape[0] != B:
-            i2h.init_state(B, self.im_dims)
+        if batch_slice is None:
+            if i2h.state is None or i2h.state.eps0.shape[0] != B:
+                i2h.init_state(B, self.im_dims)
+            st = i2h.state
+        else:
+            # a chunk of the batch: B samples starting at batch_slice of the layer's (larger) state tensors
+            st = type(i2h.state)(*[t[batch_slice:batch_slice + B] for t in i2h.state])
         desc = i2h.make_desc(self.im_dims, self.pooling, self.target_size, self.output_layer)
         tau4 = i2h.tau_per_channel()
-        st = i2h.state
         arp = st.arp if len(st) > 2 else None
         with torch.no_grad():
             if kind == 'cells':

@@ -8,6 +8,8 @@ layers, fp32-MFMA readout over all (t, b) rows, per-step argmax and vote on devi
 """
 from ast import literal_eval
 
+import os
+
 import numpy as np
 import torch
 import yaml
@@ -60,6 +62,8 @@ class ConvNetwork(torch.nn.Module):
                                               optimizer=opt, kwargs_optimizer=layer_opt, collect_stats=True,
                                               burnin=burnin))
         self._seq_buffers = {}
+        # largest pv buffer (one layer, all T steps) the sequence path allocates; bigger batches run in chunks
+        self.pv_budget_bytes = float(os.environ.get('DCLL_PV_BUDGET_GB', '24')) * 2 ** 30
 
     # -- reference protocol (per step) ----------------------------------------------------------------------------
     def learn(self, x, labels):
@@ -95,17 +99,23 @@ class ConvNetwork(torch.nn.Module):
         return kinds[0] == 'cells' and all(k == 'packed' for k in kinds[1:])
 
     def _sequence_buffers(self, T, B, dev):
-        key = (T, B, str(dev))
-        if key not in self._seq_buffers:
+        """Inter-layer spike, pv and logit buffers of one chunk, cached: flat allocations sized for the largest batch
+        seen so far at this T, handed out as (T, B, ...) views (a smaller last chunk reuses them)."""
+        key = (T, str(dev))
+        L = self.dcll_slices[0].dclllayer
+        C, (H, W) = L.out_channels, L.output_shape
+        cache = self._seq_buffers.get(key)
+        if cache is None or cache['cap'] < B:
             self._seq_buffers.clear()
-            L = self.dcll_slices[0].dclllayer
-            C, (H, W) = L.out_channels, L.output_shape
-            self._seq_buffers[key] = dict(
-                spk=[torch.empty((T, B, C, H * W // 32), device=dev, dtype=torch.int32) for _ in range(2)],
-                pv=torch.empty((T, B, C, H, W), device=dev, dtype=torch.float32),
-                ro=[torch.empty((T, B, self.target_size * (2 if i == self.num_layers - 1 else 1)), device=dev,
-                                dtype=torch.float32) for i in range(self.num_layers)])
-        return self._seq_buffers[key]
+            n_ro = [self.target_size * (2 if i == self.num_layers - 1 else 1) for i in range(self.num_layers)]
+            cache = dict(cap=B,
+                         spk=[torch.empty(T * B * C * (H * W // 32), device=dev, dtype=torch.int32) for _ in range(2)],
+                         pv=torch.empty(T * B * C * H * W, device=dev, dtype=torch.float32),
+                         ro=[torch.empty(T * B * n, device=dev, dtype=torch.float32) for n in n_ro])
+            self._seq_buffers[key] = cache
+        return dict(spk=[t[:T * B * C * (H * W // 32)].view(T, B, C, H * W // 32) for t in cache['spk']],
+                    pv=cache['pv'][:T * B * C * H * W].view(T, B, C, H, W),
+                    ro=[t[:T * B * (t.numel() // (T * cache['cap']))].view(T, B, -1) for t in cache['ro']])
 
     def zero_states(self):
         """Zero every layer's neuron state in place (time constants untouched — unlike reset(True), quirk Q4)."""
@@ -136,10 +146,46 @@ class ConvNetwork(torch.nn.Module):
             B = iq.shape[0]
             if t0 is None:
                 t0 = np.random.randint(0, iq.shape[-1] - T + 1)       # same draw as iq2spiketrain
-            first_input, first_kind, dev = (iq, encoder.thr_i, encoder.thr_q, int(t0)), 'iq', iq.device
+            dev = iq.device
         else:
             T, B = cells.shape
-            first_input, first_kind, dev = cells.contiguous(), 'cells', cells.device
+            cells = cells.contiguous()
+            dev = cells.device
+        # Samples are independent, so a batch whose pv buffer (T*B*C*H*W floats per layer) would exceed the budget is
+        # run in chunks — on the 128x128 plane T=128 x 512 windows would otherwise need 137 GB for pv alone.
+        L0 = self.dcll_slices[0].dclllayer
+        per_sample = 4 * T * L0.out_channels * int(np.prod(L0.output_shape))
+        chunk = max(1, min(B, int(self.pv_budget_bytes // max(per_sample, 1))))
+        if chunk < B:
+            for s in self.dcll_slices:
+                if s.dclllayer.i2h.state is None or s.dclllayer.i2h.state.eps0.shape[0] != B:
+                    s.dclllayer.i2h.init_state(B, s.dclllayer.im_dims)
+            parts = []
+            for b0 in range(0, B, chunk):
+                b1 = min(B, b0 + chunk)
+                parts.append(self._sequence_chunk(
+                    (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None
+                    else cells[:, b0:b1].contiguous(),
+                    'iq' if iq is not None else 'cells', T, b1 - b0, dev, profile, fuse_readout, batch_slice=b0))
+            res = dict(logits=[torch.cat([p['logits'][i] for p in parts], 1) for i in range(self.num_layers)],
+                       clout=[torch.cat([p['clout'][i] for p in parts], 1) for i in range(self.num_layers)],
+                       vote=[torch.cat([p['vote'][i] for p in parts], 0) for i in range(self.num_layers)])
+            if 'o' in parts[0]:
+                res['o'] = torch.cat([p['o'] for p in parts], 1)
+        else:
+            res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None else cells,
+                                       'iq' if iq is not None else 'cells', T, B, dev, profile, fuse_readout)
+        if collect:
+            for i, s in enumerate(self.dcll_slices):
+                s.set_sequence_result(res['clout'][i], T)
+        return res
+
+    def _sequence_chunk(self, first_input, first_kind, T, B, dev, profile, fuse_readout, batch_slice=None):
+        """All layers over all T steps for B samples (the whole batch, or rows batch_slice.. of every layer's state)."""
+        for s in self.dcll_slices:
+            i2h = s.dclllayer.i2h
+            if batch_slice is None and (i2h.state is None or i2h.state.eps0.shape[0] != B):
+                i2h.init_state(B, s.dclllayer.im_dims)
         buf = self._sequence_buffers(T, B, dev)
 
         def timed(key, fn, *a, **kw):
@@ -161,7 +207,7 @@ class ConvNetwork(torch.nn.Module):
             spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B,
                                 first_kind if i == 0 else 'packed', want_spikes=not last,
                                 buffers=dict(spk=buf['spk'][i & 1], pv=buf['pv'], ro=buf['ro'][i]),
-                                fuse_readout=fused)
+                                fuse_readout=fused, batch_slice=batch_slice)
             if fused:
                 # readout(s) came out of the layer kernel's epilogue: (T,B,24) or, on the output layer, (T,B,48)
                 p = ro[..., :self.target_size]
@@ -181,10 +227,11 @@ class ConvNetwork(torch.nn.Module):
                     logits = ro[..., self.target_size:]
                     res['o'] = logits
             clout, vote = timed('vote', ops.argmax_vote, logits.contiguous())
-            res['logits'].append(p)
+            # a chunk's logits live in the shared per-chunk buffers: copy them out before the next chunk reuses them
+            res['logits'].append(p.clone() if batch_slice is not None else p)
             res['clout'].append(clout)
             res['vote'].append(vote)
-            if collect:
-                s.set_sequence_result(clout, T)
             cur = spk
+        if batch_slice is not None and 'o' in res:
+            res['o'] = res['o'].clone()
         return res

@@ -389,9 +389,9 @@ def test_readout_gemm_fast_path(dev, rows, K, N):
     np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
 
 
-@pytest.mark.parametrize("rows,K,N", [(2100, 4096, 24), (2049, 1024, 48), (4000, 2048, 33), (2500, 8192, 10)])
+@pytest.mark.parametrize("rows,K,N", [(2100, 65536, 24), (2049, 131072, 48), (2500, 65664, 33)])
 def test_readout_gemm_long_rows(dev, rows, K, N):
-    """k_readout_ks: more than 2048 rows but fewer 128-row tiles than CUs (T*B rows of a large plane) — 32-row tiles,
+    """k_readout_ks: more than 2048 long rows (K >= 65536: T*B rows of a large plane) but fewer 128-row tiles than CUs — 32-row tiles,
     the K-chunk split over the 4 waves, partials combined in fixed order (run-to-run identical)."""
     from snn_modulation_classification_amd import ops
     rng = np.random.RandomState(2)
@@ -402,7 +402,7 @@ def test_readout_gemm_long_rows(dev, rows, K, N):
     a2 = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev))
     assert torch.equal(a1, a2)
     ref = (pv.astype(np.float64) @ Wt.astype(np.float64).T + b).astype(np.float32)
-    np.testing.assert_allclose(a1.cpu().numpy(), ref, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(a1.cpu().numpy(), ref, atol=1e-4, rtol=0)
 
 
 @pytest.mark.parametrize("case", ["mnist_l0", "mnist_l2", "pool3", "scalar_tau", "radio_l2_out", "ref_tuple"])

@@ -143,6 +143,29 @@ def test_sequence_path_on_large_planes(R_, T, B):
             assert np.array_equal(np.array(a.dcll_slices[i].clout), np.array(b.dcll_slices[i].clout))
 
 
+def test_sequence_path_chunks_large_batches():
+    """A batch whose pv buffer would exceed net.pv_budget_bytes runs in chunks (what makes the default 128x128 plane
+    with batch_size_test 512 fit): identical results and state to the unchunked run, incl. a ragged last chunk."""
+    rng = np.random.RandomState(8)
+    T, B = 12, 11
+    cells = torch.from_numpy(rng.randint(0, 256, size=(2, T, B)).astype(np.int32)).cuda()
+    a, b = _radio_net(B, 16), _radio_net(B, 16)
+    b.pv_budget_bytes = 4 * T * 32 * 256 * 4          # 4 samples per chunk -> chunks of 4, 4, 3
+    for k in range(2):
+        a.reset()
+        b.reset()
+        ra, rb = a.test_sequence(cells[k]), b.test_sequence(cells[k])
+        for i in range(3):
+            assert torch.equal(ra["clout"][i], rb["clout"][i])
+            assert torch.equal(ra["vote"][i], rb["vote"][i])
+            assert torch.equal(ra["logits"][i], rb["logits"][i])
+            for name in ("eps0", "eps1", "arp"):
+                assert torch.equal(getattr(a.dcll_slices[i].dclllayer.i2h.state, name),
+                                   getattr(b.dcll_slices[i].dclllayer.i2h.state, name))
+            assert np.array_equal(np.array(a.dcll_slices[i].clout), np.array(b.dcll_slices[i].clout))
+        assert torch.equal(ra["o"], rb["o"])
+
+
 def test_mnist_config1_per_step(golden):
     """BASELINE config 1 geometry on the GPU per-step path (28x28, pool 2/1/2, no refractory) vs the C oracle
     (bit-exact spikes) and the reference (logits)."""
