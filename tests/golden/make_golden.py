@@ -8,6 +8,7 @@ Shims: an empty in-memory `apex`/`apex.amp`; `device='cpu'` in 
 modules; `yaml.load` given SafeLoader (PyYAML >= 6).
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz, meta.json
+    python tests/golden/make_golden.py --only-r32 # only the 32x32-plane rollout (added for the tiled kernels)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 one train_dcll step, G7 dense layer steps,
@@ -118,7 +119,7 @@ def synth_iq(B, L=128, s=1):
     return 0.4 * torch.randn(B, 2, 1, L, generator=g)
 
 
-def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.0):
+def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.0, store_readouts=True):
     convs = nets.load_network_spec(os.path.join(REF, "networks", yaml_name))
     seed(1)
     net = nets.ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
@@ -136,7 +137,15 @@ def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.
     xin = torch.Tensor(spikes)
     out = {}
     for i, s in enumerate(net.dcll_slices):
-        out.update(state_dict_np(s.dclllayer, "sd/%d/" % i))
+        sd = state_dict_np(s.dclllayer, "sd/%d/" % i)
+        if not store_readouts:
+            # the frozen readout matrices of a large plane are megabytes of uniform noise that the seeded constructor
+            # reproduces exactly (tests/test_host_logic.py): keep a float64 checksum instead of the matrix
+            for k in list(sd):
+                if k.split("/")[-1].startswith(("i2o.weight", "output_.weight")):
+                    w = sd.pop(k).astype(np.float64)
+                    out["sdsum/" + k[3:]] = np.array([w.sum(), np.abs(w).sum(), w.reshape(-1)[::4097].sum()])
+        out.update(sd)
     out["iq"] = npy(x)
     out["labels"] = labels.numpy()
     cells = np.zeros((T, B), dtype=np.int32)
@@ -202,6 +211,15 @@ def g2_rollouts(lib, nets, du):
     np.savez_compressed(os.path.join(OUT, "g2_radio_r8_t24_b2_norp_traces.npz"), **norp)
     return {"full": dict(R=16, T=128, B=2), "small": dict(R=8, T=32, B=3, netscale=0.25),
             "norp": dict(R=8, T=24, B=2, netscale=0.25, arp=0.0, random_tau=False)}
+
+
+def g2_r32(lib, nets, du):
+    """radio_ml_conv.yaml on a 32x32 plane (4 tiles of the large-plane kernels, every tile touching the plane edge on
+    three sides): T=40, B=2, free-running reference spikes / logits / argmax / votes / final state."""
+    r32 = rollout(lib, nets, du, "radio_ml_conv.yaml", R=32, T=40, B=2, args=make_args(), full_traces=False,
+                  store_readouts=False)
+    np.savez_compressed(os.path.join(OUT, "g2_radio_r32_t40_b2.npz"), **r32)
+    return dict(R=32, T=40, B=2)
 
 
 def g2_mnist(lib, nets, du):
@@ -378,6 +396,13 @@ def g8_image(du):
 def main():
     lib, nets, du = import_reference()
     torch.set_num_threads(1)        # pin the oneDNN reduction schedule used for the fixtures
+    if "--only-r32" in sys.argv:
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["g2_r32"] = g2_r32(lib, nets, du)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, default=lambda o: list(o))
+        return
     meta = {
         "torch": torch.__version__,
         "numpy": np.__version__,
@@ -385,6 +410,7 @@ def main():
         "torch_config": torch.__config__.show(),
         "g1": g1_layer_steps(lib),
         "g2": g2_rollouts(lib, nets, du),
+        "g2_r32": g2_r32(lib, nets, du),
         "g2_mnist": g2_mnist(lib, nets, du),
         "g5": {k: [{kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in d.items()} for d in v]
                for k, v in g5_specs(nets).items()},

@@ -166,6 +166,43 @@ def test_sequence_path_chunks_large_batches():
         assert torch.equal(ra["o"], rb["o"])
 
 
+def test_tiled_sequence_path_reproduces_reference_run_32x32(golden):
+    """Reference run on a 32x32 plane (fixture g2_radio_r32_t40_b2, generated by importing the reference): the tiled
+    all-T kernels must give the REFERENCE's spike trains bit for bit, its logits within 1e-4, its per-step argmax,
+    votes and final neuron state."""
+    from test_host_logic import _check_against_r32_fixture
+    g = golden("g2_radio_r32_t40_b2.npz")
+    net = _radio_net(2, 32)
+    _check_against_r32_fixture(net, g)
+    assert net.sequence_supported()
+    cells = torch.from_numpy(g["cells"]).cuda()
+    T, B = cells.shape
+    # layer by layer, for the spike trains
+    cur = cells
+    net.reset()
+    for i, s in enumerate(net.dcll_slices):
+        spk, pv, _ = s.dclllayer.forward_sequence(cur, T, B, 'cells' if i == 0 else 'packed')
+        assert np.array_equal(spk.cpu().numpy(), g["spikes/%d" % i].view(np.int32).reshape(T, B, 32, 32)), \
+            "layer %d spike trains differ from the reference" % i
+        for nm in ("eps0", "eps1"):
+            assert np.array_equal(getattr(s.dclllayer.i2h.state, nm).cpu().numpy().view(np.uint32),
+                                  g["final/%d/%s" % (i, nm)].view(np.uint32)), (i, nm)
+        np.testing.assert_allclose(s.dclllayer.i2h.state.arp.cpu().numpy(), g["final/%d/arp" % i], atol=1e-6, rtol=0)
+        cur = spk
+    # and through the network entry point
+    net2 = _radio_net(2, 32)
+    net2.reset()
+    res = net2.test_sequence(cells)
+    for i in range(3):
+        np.testing.assert_allclose(res["logits"][i].cpu().numpy(), g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+        assert np.array_equal(np.array(net2.dcll_slices[i].clout), g["clout/%d" % i])
+        assert np.array_equal(res["vote"][i].cpu().numpy(), g["vote/%d" % i])
+    np.testing.assert_allclose(res["o"].cpu().numpy(), g["o_last"], atol=LOGIT_TOL, rtol=0)
+    y = _one_hot_labels(g["labels"], T, 24)
+    assert net2.accuracy(y) == list(g["acc"])
+    assert np.array_equal(net2.confusion_matrix(y), g["confusion"])
+
+
 def test_mnist_config1_per_step(golden):
     """BASELINE config 1 geometry on the GPU per-step path (28x28, pool 2/1/2, no refractory) vs the C oracle
     (bit-exact spikes) and the reference (logits)."""

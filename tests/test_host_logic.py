@@ -179,6 +179,52 @@ def test_seeded_network_equals_reference_state_dict(golden, cpu_device, fixture,
                          for i in range(3) for k, v in g.sub("sd/%d/" % i).items()})
 
 
+def _check_against_r32_fixture(net, g):
+    """Seeded network == the reference's at 32x32: i2h parameters element for element, the (unstored) frozen readout
+    matrices by their float64 checksums."""
+    sd = net.state_dict()
+    for i in range(3):
+        for k, v in g.sub("sd/%d/" % i).items():
+            assert np.array_equal(sd["dcll_slices.%d.dclllayer.%s" % (i, k)].cpu().numpy(), v), (i, k)
+        for k, v in g.sub("sdsum/%d/" % i).items():
+            w = sd["dcll_slices.%d.dclllayer.%s" % (i, k)].cpu().numpy().astype(np.float64)
+            assert np.array_equal(np.array([w.sum(), np.abs(w).sum(), w.reshape(-1)[::4097].sum()]), v), (i, k)
+
+
+def test_seeded_network_and_oracle_on_32x32_plane(golden, cpu_device):
+    """32x32 plane (served by the tiled sequence kernels): the seeded constructor reproduces the reference's network
+    (fixture g2_radio_r32_t40_b2: i2h parameters stored, readout matrices as checksums), and the torch oracle run
+    on those parameters reproduces the reference's free-running spikes, logits, argmax and votes bit for bit."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from oracle import torch_ref as R
+    g = golden("g2_radio_r32_t40_b2.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(), (1, 32, 32), 2, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    _check_against_r32_fixture(net, g)
+    assert net.sequence_supported()
+    sds = [{k: v.detach().clone() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
+    ref = R.RefConvNetwork(sds, [dict(padding=3, pooling=1)] * 3, 1.0)
+    cells = g["cells"]
+    T, B = cells.shape
+    torch.set_num_threads(1)
+    for step in range(T):
+        x = torch.zeros(B, 1, 32 * 32)
+        x[torch.arange(B), 0, torch.from_numpy(cells[step]).long()] = 1.0
+        outs = ref.test(x.reshape(B, 1, 32, 32))
+        for i, (o, p, pv, v) in enumerate(outs):
+            sp = (v > 0).float().reshape(B, -1).numpy()
+            bits = np.unpackbits(g["spikes/%d" % i][step], axis=-1, bitorder="little")[:, :sp.shape[1]]
+            assert np.array_equal(sp, bits), (step, i)
+            assert np.array_equal(p.numpy(), g["p/%d" % i][step]), (step, i)
+    for i in range(3):
+        assert np.array_equal(np.array(ref.clout[i]), g["clout/%d" % i])
+        assert np.array_equal(ref.votes()[i], g["vote/%d" % i])
+
+
 def test_mnist_network_shapes(golden, cpu_device):
     from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
     g = golden("g2_mnist_t50_b4.npz")
