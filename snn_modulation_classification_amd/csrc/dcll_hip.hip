@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
     const int co = blockIdx.x / d.c_in, ci = blockIdx.x % d.c_in;
     const int HP = d.h + 2 * d.pad_h, WP = d.w + 2 * d.pad_w, ntap = d.kh * d.kw, npos = ch * cw;
     float *e = sm;                    // zero-padded eps1 plane of (b, ci)
-    float *red = sm + HP * WP;        // 256 floats for reductions
+    float *red = sm + HP * WP;        // 4 x (WG_MAXTAPS + 1) wave totals
     float acc[WG_MAXTAPS];
 #pragma unroll
     for (int t = 0; t < WG_MAXTAPS; ++t) acc[t] = 0.0f;
@@ -355,22 +355,27 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
                 if (t < ntap) acc[t] = __builtin_fmaf(g, eb[(t / d.kw) * WP + (t % d.kw)], acc[t]);
         }
     }
-    // reduce every tap over the 256 threads
-    for (int t = 0; t <= ntap; ++t) {
-        float val = accb;           // t == ntap: the bias gradient
+    // reduce every tap (and the bias gradient) over the 256 threads: DPP tree inside each wave (fixed order), the
+    // four wave totals through LDS — two barriers instead of nine per tap
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
 #pragma unroll
-        for (int u = 0; u < WG_MAXTAPS; ++u) val = (u == t && t < ntap) ? acc[u] : val;
-        __syncthreads();
-        red[threadIdx.x] = val;
-        __syncthreads();
-        for (int sft = 128; sft > 0; sft >>= 1) {
-            if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
-            __syncthreads();
+    for (int t = 0; t < WG_MAXTAPS; ++t) {
+        if (t < ntap) {
+            const float tot = wave_sum_to_lane63(acc[t]);
+            if (lane == 63) red[wave * (WG_MAXTAPS + 1) + t] = tot;
         }
-        if (threadIdx.x == 0) {
-            if (t < ntap) prow[(long)ci * ntap + t] = red[0];
-            else if (ci == 0) prow[rowlen - 1] = red[0];
-        }
+    }
+    {
+        const float tot = wave_sum_to_lane63(accb);
+        if (lane == 63) red[wave * (WG_MAXTAPS + 1) + WG_MAXTAPS] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x <= ntap) {
+        const int t = threadIdx.x < ntap ? threadIdx.x : WG_MAXTAPS;
+        const float tot = ((red[t] + red[(WG_MAXTAPS + 1) + t]) + red[2 * (WG_MAXTAPS + 1) + t]) + red[3 * (WG_MAXTAPS + 1) + t];
+        if (threadIdx.x < ntap) prow[(long)ci * ntap + threadIdx.x] = tot;
+        else if (ci == 0) prow[rowlen - 1] = tot;
     }
 }
 
@@ -938,24 +943,6 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
 
 // ABLATE is a diagnostic knob for experiments/ablate_c32.hip only (bit0: no epilogue, bit1: no trace update,
 // bit2: no accumulator hand-off); every product launch uses ABLATE = 0.
-// one DPP step of a wave-wide sum: v + (v moved by CTRL); lanes without a source add 0
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v)
-{
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-// sum over the 64 lanes; the total is valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v = dpp_add<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
-    v = dpp_add<0x140, 0xF>(v);      // row_mirror      -> every lane holds its 16-lane row sum
-    v = dpp_add<0x142, 0xA>(v);      // row_bcast15     -> rows 1,3 += previous row
-    v = dpp_add<0x143, 0xC>(v);      // row_bcast31     -> rows 2,3 += row 1
-    return v;
-}
-
 // NRO > 0 fuses the local readout(s) into the epilogue: logits[t][b][n] = sum_{co,pix} pv * Wro[n][co][pix] + b[n]
 // (i2o, and output_ stacked behind it on the last layer: dcll/pytorch_libdcll.py:602-606) with Wro pre-permuted to
 // the epilogue's register layout (dcll_permute_readout); pv then never travels through HBM.
@@ -1426,6 +1413,50 @@ extern "C" int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, con
     return DCLL_OK;
 }
 
+// The same gradient with every pv row read ONCE: thread = one column k of pv, up to 32 readout rows accumulated in
+// registers (g_o is wave-uniform -> scalar loads), the batch split into gridDim.y chunks whose partial sums
+// part[chunk][n][K+1] are added in chunk order by k_bwd_outgrad_reduce (deterministic, no atomics).
+__global__ __launch_bounds__(256) void k_bwd_outgrad_part(const float *__restrict__ g_o, const float *__restrict__ pvp,
+                                                           float *__restrict__ part, int B, int N, int K)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.0f;
+    if (k < K) {
+        for (int b = b0; b < b1; ++b) {
+            const float p = pvp[(long)b * K + k];
+#pragma unroll
+            for (int n = 0; n < 32; ++n)
+                if (n < N) acc[n] = __builtin_fmaf(g_o[(long)b * N + n], p, acc[n]);
+        }
+    } else if (k - K < N) {             // the bias gradient of readout row k - K, in acc[0]
+        for (int b = b0; b < b1; ++b) acc[0] += g_o[(long)b * N + (k - K)];
+    }
+    float *pp = part + (long)blockIdx.y * N * (K + 1);
+    if (k < K) {
+#pragma unroll
+        for (int n = 0; n < 32; ++n)
+            if (n < N) pp[(long)n * (K + 1) + k] = acc[n];
+    } else if (k - K < N) {
+        pp[(long)(k - K) * (K + 1) + K] = acc[0];
+    }
+}
+
+__global__ void k_bwd_outgrad_reduce(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db,
+                                     int nchunk, int N, int K)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * (K + 1)) return;
+    float tot = 0.0f;
+    for (int c = 0; c < nchunk; ++c) tot += part[(long)c * N * (K + 1) + i];
+    const int n = (int)(i / (K + 1)), k = (int)(i % (K + 1));
+    if (k < K) dW[(long)n * K + k] = tot;
+    else db[n] = tot;
+}
+
 extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
                                       const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
                                       const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
@@ -1459,7 +1490,7 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
         hipLaunchKernelGGL(k_bwd_wgrad_c32, dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1, part, B);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c32");
     } else {
-        const size_t lds = ((size_t)(d->h + 2 * d->pad_h) * (d->w + 2 * d->pad_w) + 256) * sizeof(float);
+        const size_t lds = ((size_t)(d->h + 2 * d->pad_h) * (d->w + 2 * d->pad_w) + 4 * (WG_MAXTAPS + 1)) * sizeof(float);
         if (lds > 60 * 1024) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: input plane too large for the LDS-resident weight-gradient kernel");
         if (nchunk > 64) nchunk = 64;
         if (nchunk > B) nchunk = B;
@@ -1470,10 +1501,23 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
     hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
     HIP_CHECK_LAUNCH("k_bwd_reduce");
     if (g_o) {
-        const int K = d->c_out * ph * pw;
-        hipLaunchKernelGGL(k_bwd_outgrad, dim3(nblk((long)d->target * (K + 1), 256)), dim3(256), 0, st, g_o, pv_pooled,
-                           d_outW, d_outb, B, d->target, K);
-        HIP_CHECK_LAUNCH("k_bwd_outgrad");
+        const int K = d->c_out * ph * pw, N = d->target;
+        // the partial-sum area of the weight gradient is free again (stream order): reuse it for the batch chunks
+        long nsplit = (scratch_floats - nconv) / ((long)N * (K + 1));
+        if (nsplit > 16) nsplit = 16;
+        if (nsplit > B) nsplit = B;
+        if (N <= 32 && nsplit >= 1) {
+            hipLaunchKernelGGL(k_bwd_outgrad_part, dim3(nblk((long)K + N, 256), (unsigned)nsplit), dim3(256), 0, st, g_o,
+                               pv_pooled, part, B, N, K);
+            HIP_CHECK_LAUNCH("k_bwd_outgrad_part");
+            hipLaunchKernelGGL(k_bwd_outgrad_reduce, dim3(nblk((long)N * (K + 1), 256)), dim3(256), 0, st, part, d_outW,
+                               d_outb, (int)nsplit, N, K);
+            HIP_CHECK_LAUNCH("k_bwd_outgrad_reduce");
+        } else {
+            hipLaunchKernelGGL(k_bwd_outgrad, dim3(nblk((long)N * (K + 1), 256)), dim3(256), 0, st, g_o, pv_pooled,
+                               d_outW, d_outb, B, N, K);
+            HIP_CHECK_LAUNCH("k_bwd_outgrad");
+        }
     }
     return DCLL_OK;
 }

@@ -82,3 +82,21 @@ __device__ __forceinline__ float refractory(float pvmem, float &arp, float alpha
     return v;
 }
 
+// one DPP step of a wave-wide sum: v + (v moved by CTRL); lanes without a source add 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 64 lanes; the total is valid in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);      // row_mirror      -> every lane holds its 16-lane row sum
+    v = dpp_add<0x142, 0xA>(v);      // row_bcast15     -> rows 1,3 += previous row
+    v = dpp_add<0x143, 0xC>(v);      // row_bcast31     -> rows 2,3 += row 1
+    return v;
+}
+

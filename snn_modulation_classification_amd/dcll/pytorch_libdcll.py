@@ -17,6 +17,7 @@ backward is dcll_conv_lif_backward; torch supplies only the loss module and the 
 """
 import logging
 import math
+import os
 from collections import Counter, namedtuple
 
 import numpy as np
@@ -596,9 +597,9 @@ class DCLLBase(nn.Module):
             self.crit = loss().to(device)
             self.output_crit = loss().to(device)
         if optimizer is not None:
-            self.optimizer = optimizer(dclllayer.i2h.parameters(), **kwargs_optimizer)
+            self.optimizer = self._make_optimizer(optimizer, dclllayer.i2h.parameters(), dict(kwargs_optimizer))
             if self.dclllayer.output_layer:
-                self.optimizer2 = optimizer(dclllayer.output_.parameters(), lr=1e-4)
+                self.optimizer2 = self._make_optimizer(optimizer, dclllayer.output_.parameters(), dict(lr=1e-4))
         self.burnin = burnin
         self.batch_size = batch_size
         self.collect_stats = collect_stats
@@ -645,6 +646,20 @@ class DCLLBase(nn.Module):
             writer.add_scalar(self.name + '/low_pv/' + label, pd[0], epoch)
             writer.add_scalar(self.name + '/high_pv/' + label, pd[-1], epoch)
             print(self.name + ' low:{0:1.3} high:{1:1.3}'.format(pd[0], pd[-1]))
+
+    @staticmethod
+    def _make_optimizer(optimizer, params, kwargs):
+        """optimizer(params, **kwargs) as in the reference (:634-638).  torch's Adam family runs as ONE fused
+        multi-tensor kernel per step on device parameters instead of ~10 (a local-learning step is launch- and
+        small-kernel-bound); same update rule, set DCLL_FUSED_OPTIMIZER=0 to get torch's default implementation."""
+        params = list(params)
+        if (os.environ.get('DCLL_FUSED_OPTIMIZER', '1') != '0' and optimizer in (optim.Adam, optim.AdamW) and
+                'fused' not in kwargs and 'foreach' not in kwargs and params and all(p.is_cuda for p in params)):
+            try:
+                return optimizer(params, fused=True, **kwargs)
+            except (TypeError, RuntimeError, ValueError):
+                pass
+        return optimizer(params, **kwargs)
 
     def train_dcll(self, input, target, do_train=True, regularize=0.05):
         """One local-learning step (reference :690-718): forward; after burn-in the local loss on pvoutput (+ the loss
