@@ -600,9 +600,9 @@ __global__ __launch_bounds__(256) void k_readout_v4(const float *__restrict__ pv
 }
 
 // Long rows, moderately many of them (rows = T*B of a 128x128 plane: 8192 rows of K = 524288): 128-row tiles would be
-// only 64 workgroups, so here a workgroup takes 32 rows and its 4 waves split every 128-float K-chunk between them
-// (wave w: floats 32w..32w+31); the four partial tiles are combined in LDS in fixed order (deterministic).
-constexpr int RK_ROWS = 32, RK_KC = 128, RK_LD = 129;
+// only 64 workgroups, so here a workgroup takes 32 rows and its 4 waves split every 256-float K-chunk between them
+// (wave w: floats 64w..64w+63); the four partial tiles are combined in LDS in fixed order (deterministic).
+constexpr int RK_ROWS = 32, RK_KC = 256, RK_LD = 257;
 template <int NT>
 __global__ __launch_bounds__(256) void k_readout_ks(const float *__restrict__ pv, const float *__restrict__ Wt,
                                                      const float *__restrict__ bias, float *__restrict__ out,
@@ -612,41 +612,41 @@ __global__ __launch_bounds__(256) void k_readout_ks(const float *__restrict__ pv
     float *sA = sm, *sB = sm + RK_ROWS * RK_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row0 = (long)blockIdx.x * RK_ROWS;
-    const int kq = (tid & 31) * 4, rsub = tid >> 5;         // 32 threads x float4 = one 128-float K-chunk of a row
+    const int kq = (tid & 63) * 4, rsub = tid >> 6;         // 64 threads x float4 = one 256-float K-chunk of a row
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    f32x4 ra[4], rb[NT * 4];
+    f32x4 ra[8], rb[NT * 8];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            long gr = row0 + rsub + 8 * i;
+        for (int i = 0; i < 8; ++i) {
+            long gr = row0 + rsub + 4 * i;
             ra[i] = gr < rows ? *(const f32x4 *)(pv + gr * K + k0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) {
-            int nn = rsub + 8 * i;
+        for (int i = 0; i < NT * 8; ++i) {
+            int nn = rsub + 4 * i;
             rb[i] = nn < N ? *(const f32x4 *)(Wt + (long)nn * K + k0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += RK_KC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sA[(rsub + 8 * i) * RK_LD + kq + e] = ra[i][e];
+            for (int e = 0; e < 4; ++e) sA[(rsub + 4 * i) * RK_LD + kq + e] = ra[i][e];
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i)
+        for (int i = 0; i < NT * 8; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sB[(rsub + 8 * i) * RK_LD + kq + e] = rb[i][e];
+            for (int e = 0; e < 4; ++e) sB[(rsub + 4 * i) * RK_LD + kq + e] = rb[i][e];
         __syncthreads();
         if (k0 + RK_KC < K) fetch(k0 + RK_KC);
-        const float *a = sA + (lane & 31) * RK_LD + 32 * wave + (lane >> 5);
-        const float *bb = sB + (lane & 31) * RK_LD + 32 * wave + (lane >> 5);
+        const float *a = sA + (lane & 31) * RK_LD + 64 * wave + (lane >> 5);
+        const float *bb = sB + (lane & 31) * RK_LD + 64 * wave + (lane >> 5);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+        for (int kk = 0; kk < 32; ++kk) {
             const float av = a[2 * kk];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
