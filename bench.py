@@ -193,11 +193,16 @@ def main():
     # matches, else null.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_b4096.json")) as f:
-            pmc = json.load(f)
-        if R == 16 and pmc.get("k_lif_seq_c32_batch") == B:
-            traffic = pmc["k_lif_seq_c32_traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+        if R == 16:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_b4096.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("k_lif_seq_c32_batch") == B:
+                traffic = pmc["k_lif_seq_c32_traffic_bytes_per_launch"]
+        elif R == 128 and B == 64:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_plane128_b64.json")) as f:
+                pmc = json.load(f)
+            traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if k.startswith("k_lif_seq_c32t")][0]
+    except (OSError, ValueError, KeyError, IndexError):
         pass
     kernel_ms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in prof.items()}
     if len(c32_ms) >= 2:        # the two 32->32 layers of a step (the output layer carries a second readout)
