@@ -1,0 +1,35 @@
+// Stage-phase timing of k_lif_seq_c32d (diagnostic, not product).
+#include "../snn_modulation_classification_amd/csrc/dcll_hip.hip"
+#include <vector>
+int main()
+{
+    const int B = 1024, T = 128;
+    size_t nin = (size_t)T * B * 32 * 8;
+    uint32_t *spk_in, *spk_out; float *W, *bias, *tau4, *e0, *e1, *arp, *pv; unsigned long long *dbg;
+    hipMalloc(&spk_in, nin * 4); hipMalloc(&spk_out, nin * 4); hipMemset(spk_in, 0x11, nin * 4);
+    hipMalloc(&W, 32 * 32 * 49 * 4); hipMalloc(&bias, 128); hipMalloc(&tau4, 512);
+    std::vector<float> hw(32 * 32 * 49, 1e-6f), hb(32, 1e-4f), ht(128, 0.9f);
+    hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(bias, hb.data(), 128, hipMemcpyHostToDevice); hipMemcpy(tau4, ht.data(), 512, hipMemcpyHostToDevice);
+    size_t ns = (size_t)B * 32 * 256;
+    hipMalloc(&e0, ns * 4); hipMalloc(&e1, ns * 4); hipMalloc(&arp, ns * 4);
+    hipMemset(e0, 0, ns * 4); hipMemset(e1, 0, ns * 4); hipMemset(arp, 0, ns * 4);
+    hipMalloc(&pv, (size_t)T * ns * 4); hipMalloc(&dbg, 4096); hipMemset(dbg, 0, 4096);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("k_lif_seq_c32d B=%d T=%d: %.2f ms (ideal at 157.3 TF: %.2f)\n", B, T, ms, 2.0 * 32 * 1568 * 256 * (double)T * B / 157.3e12 * 1e3);
+    }
+    hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 1>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
+    unsigned long long h[64];
+    hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
+    const double nst = 4.0 * T + 8;
+    printf("wave: cycles per stage | non-MFMA phase | barrier 2 | chains + slot write | barrier 1   (s_memtime ticks per stage)\n");
+    for (int w = 0; w < 8; ++w)
+        printf("  w%d: %8.0f | %7.0f | %7.0f | %7.0f | %7.0f\n", w, h[w * 8] / nst, h[w * 8 + 1] / nst, h[w * 8 + 2] / nst,
+               h[w * 8 + 3] / nst, h[w * 8 + 4] / nst);
+    return 0;
+}

@@ -1267,6 +1267,280 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_lif_seq_c32d — k_lif_seq_c32 with TWO pixel tiles per wave and stage (the long-sequence variant).
+//
+// Same data layout, same weight-stationary systolic chain, same pinned order.  Per stage a wave runs the K-slices of
+// the tile pair (2p, 2p+1) — image rows 4p..4p+3 — as two INDEPENDENT accumulator chains:
+//   - back-to-back MFMAs of one wave no longer depend on each other (microbenchmark: 98.3 % vs 96.2 % of peak);
+//   - the B fragment of tap row ky of the second tile IS the fragment of tap row ky+2 of the first: 9 LDS rows per
+//     channel pair feed both tiles (126 ds_read dwords per stage instead of 196);
+//   - half as many barriers / hand-off latencies per MFMA;
+//   - every wave has the same non-MFMA work in every stage (one epilogue quad-share of the pair finished by wave 7, one
+//     channel of the trace update), done by ALL waves at the start of the stage, before any MFMA of the stage is in
+//     flight.  Measured at B=4096 (ms per launch): this arrangement 100.7; the same work on one wave of a SIMD while
+//     its partner runs its chains (the arrangement of k_lif_seq_c32) 102.2; cut into pieces and interleaved into the
+//     wave's own MFMA rows 103.4 — a VALU / LDS instruction issued against an MFMA stream, another wave's or the
+//     wave's own, waits for the MFMAs in flight, so the non-MFMA work is cheapest when the matrix pipe is empty anyway.
+//   - the stage loop is unrolled by four: the pair index of the epilogue share (g & 3) and the register group of the
+//     trace share are then compile-time constants (the traces of channel c of wave w live in register group
+//     (c + w) & 3), so the non-MFMA phase is straight-line code whose two halves overlap their latencies.
+// The hand-off slots hold two tiles per wave and are therefore single-buffered: a wave reads its inputs at the start
+// of a stage and a second barrier orders those reads before this stage's slot writes.  Pipeline fill is 8
+// pair-stages, so k_lif_seq_c32 stays the kernel for short sequences.
+// ------------------------------------------------------------------------------------------------------------
+// DBG is a diagnostic knob for experiments/ablate_c32d.hip only (s_memtime stamps of workgroup 0 into v_out).
+template <bool REFRACTORY, int OUT, int DBG = 0>     // OUT bit0: pv, bit1: v
+__global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
+                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
+                                                       float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
+                                                       float *__restrict__ pv_out, float *__restrict__ v_out, int T,
+                                                       int B, float alpharp, float wrp)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * IMG_FLOATS + NWAVE * 2 * SLOT_FLOATS + 32];
+    float *slots = lds + 2 * IMG_FLOATS;        // [wave][tile of the pair][16 x 64]
+    float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = w & 3, wpar = w >> 2;        // my epilogue share: quad wq of the pair's tile wpar
+    const long b = blockIdx.x;
+
+    for (int i = tid; i < 2 * IMG_FLOATS; i += 512) lds[i] = 0.0f;
+    if (tid < 32) sbias[tid] = bias[tid];
+
+    float wf[2][49];
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+        for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
+
+    // eps0 of my 4 channels: register group grp holds channel (grp - w) & 3 (see the header), element ii = pixel
+    // ii*64 + lane; eps1 lives in the LDS images at float offset ioff + c*CHF + ii*4*ROWF
+    float e0[4][4];
+    const int ioff = (4 * w) * CHF + ((lane >> 4) + 3) * ROWF + (lane & 15) + 3;
+    const unsigned long long *in_wave = (const unsigned long long *)(spk_in + (b * 32 + 4 * w) * 8);
+    const long in_step = (long)B * 32 * 4;      // in 64-bit units
+    __syncthreads();        // images zeroed
+
+    // prologue: state from HBM, advanced to step 0 with the input bits of step 0 -> image[0]
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const int c = (grp - w) & 3;
+        const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
+        const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const long gidx = (b * 32 + 4 * w + c) * 256 + ii * 64 + lane;
+            e0[grp][ii] = eps0_g[gidx];
+            float e1 = eps1_g[gidx];
+            float xin = (float)((in_wave[c * 4 + ii] >> lane) & 1ull);
+            trace_update(xin, ta, tm, tas, ts, e0[grp][ii], e1);
+            lds[ioff + c * CHF + ii * 4 * ROWF] = e1;
+        }
+    }
+    // refractory trace of my epilogue share: tiles m = 2k + wpar (k = pair index), quad wq
+    float arp[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            arp[k][rr] = REFRACTORY ? arp_g[(b * 32 + rr + 8 * wq + 4 * h) * 256 + 32 * (2 * k + wpar) + j] : 0.0f;
+
+    const int bbase = (4 * w + h) * CHF + (j >> 4) * ROWF + (j & 15);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) asm volatile("" ::"v"(arp[k][rr]));
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) asm volatile("" ::"v"(e0[grp][ii]));
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+        for (int k = 0; k < 49; ++k) asm volatile("" ::"v"(wf[cp][k]));
+    __syncthreads();
+
+    unsigned long long dbg[4] = {0, 0, 0, 0}, dbg_t0 = 0;       // DBG only: non-MFMA phase, barrier 2, chains, barrier 1
+    if (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
+    // inputs of a wave's trace share of stage g (wave-uniform scalars + 4 eps1 values), fetched one stage ahead
+    float sv[4] = {0.f, 0.f, 0.f, 0.f}, ta = 0.f, tm = 0.f, tas = 0.f, ts = 0.f;
+    unsigned long long wm[4] = {0, 0, 0, 0};
+    auto fetch_trace_inputs = [&](const int g) {
+        const int q = g - w;
+        if (q >= 0 && q < 4 * T && (q >> 2) + 1 < T) {
+            const int p = q & 3, t = q >> 2;
+            const float *src = lds + (t & 1) * IMG_FLOATS + ioff + p * CHF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = src[i * 4 * ROWF];
+            const unsigned long long *ip = in_wave + (long)(t + 1) * in_step + p * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wm[i] = ip[i];
+            ta = tau4[0 * 32 + 4 * w + p]; tm = tau4[1 * 32 + 4 * w + p];
+            tas = tau4[2 * 32 + 4 * w + p]; ts = tau4[3 * 32 + 4 * w + p];
+        }
+    };
+    fetch_trace_inputs(0);
+    // one stage; U = g & 3 at compile time
+    auto stage = [&](const int g, auto UC) {
+        constexpr int U = decltype(UC)::value;
+        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+        if (DBG) st0 = __builtin_amdgcn_s_memtime();
+        const int q = g - w;
+        const bool active = q >= 0 && q < 4 * T;
+        const int p = q & 3, t = q >> 2;
+        // ---- (0) everything this stage reads from LDS / SMEM goes out first ----
+        //   chain inputs out of the slots (written in the previous stage)
+        f32x16 accA, accB;
+        if (active) {
+            if (w == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+            } else {
+                const f32x4 *sp = (const f32x4 *)(slots + ((w - 1) * 2) * SLOT_FLOATS) + lane;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 va = sp[c * 64], vb = sp[SLOT_FLOATS / 4 + c * 64];
+                    accA[4 * c + 0] = va[0]; accA[4 * c + 1] = va[1]; accA[4 * c + 2] = va[2]; accA[4 * c + 3] = va[3];
+                    accB[4 * c + 0] = vb[0]; accB[4 * c + 1] = vb[1]; accB[4 * c + 2] = vb[2]; accB[4 * c + 3] = vb[3];
+                }
+            }
+        }
+        //   epilogue share: quad wq of tile wpar of the pair qe = g - 8 (pair index U) that wave 7 finished last stage
+        const int qe = g - 8;
+        const bool epi = qe >= 0 && qe < 4 * T;
+        f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+        if (epi) v4 = *((const f32x4 *)(slots + (7 * 2 + wpar) * SLOT_FLOATS) + wq * 64 + lane);
+        //   trace share: channel p of step t+1 (register group U), reads image[t&1], writes image[(t+1)&1]; its inputs
+        //   (eps1 values sv, input masks wm, time constants) were fetched during the previous stage's chains
+        const bool tr = active && t + 1 < T;
+        //   first B-fragment row of the chains
+        const int i0 = (t & 1) * IMG_FLOATS + bbase + p * 4 * ROWF;
+        float bq[2][7];
+        if (active) {
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = lds[i0 + kx];
+        }
+        // ---- (1) epilogue share ----
+        if (epi) {
+            const int te = qe >> 2, me = 2 * U + wpar;
+            const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
+            const long oelem = obase * 256 + 32 * me + j;                     // + rr*256
+            uint32_t myword = 0;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = v4[rr];
+                bool s;
+                if (REFRACTORY) v = refractory(v4[rr], arp[U][rr], alpharp, wrp, s);
+                else s = v > 0.0f;
+                const unsigned long long mk = __ballot(s);
+                const uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                myword = (j == rr) ? mine : myword;
+                if (OUT & 1) pv_out[oelem + rr * 256] = sigmoidf_dev(v);
+                if (OUT & 2) v_out[oelem + rr * 256] = v;
+            }
+            if (spk_out && j < 4) spk_out[(obase + j) * 8 + me] = myword;
+        }
+        // ---- (2) trace share (dcll/pytorch_libdcll.py:493-494, every op rounded separately) ----
+        if (tr) {
+            float *dst = lds + ((t + 1) & 1) * IMG_FLOATS + ioff + p * CHF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a;                                    // x * tau_s with x in {0,1}: exact select
+                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(a) : "v"(ts), "s"(wm[i]));
+                const float bb = tas * e0[U][i];
+                e0[U][i] = a + bb;
+                const float cc = ta * sv[i];
+                const float dd = e0[U][i] * tm;
+                dst[i * 4 * ROWF] = cc + dd;
+            }
+        }
+        if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
+        // every slot read of this stage has completed before any wave writes its slots again
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (DBG) st2 = __builtin_amdgcn_s_memtime();
+        // inputs of the NEXT stage's trace share: they land while the chains run (the eps1 values it reads were
+        // written by my own trace share four stages ago; nobody else touches my channels).  Issued before the first
+        // MFMA: in the middle of the chains the same loads cost 1.5 % (24.65 vs 24.27 ms at B=1024).
+        fetch_trace_inputs(g + 1);
+        // ---- (3) my K-slice of both chains ----
+        if (active) {
+            // LDS rows 0..8 below the pair's first image row, per channel pair: row rho is tap row ky = rho of tile A
+            // (rho <= 6) and tap row ky = rho - 2 of tile B (rho >= 2); next row fetched before the MFMAs of this one.
+#pragma unroll
+            for (int r = 0; r < 18; ++r) {
+                const int cp = r / 9, rho = r % 9;
+                if (r + 1 < 18) {
+                    const int cpn = (r + 1) / 9, rhon = (r + 1) % 9;
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = lds[i0 + cpn * 2 * CHF + rhon * ROWF + kx];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    if (rho <= 6)
+                        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][rho * 7 + kx], bq[r & 1][kx], accA, 0, 0, 0);
+                    if (rho >= 2)
+                        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][(rho - 2) * 7 + kx], bq[r & 1][kx], accB, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (r == 15) {          // tile A is complete (its last tap row was rho = 6 of the second channel pair)
+                    f32x4 *dpa = (f32x4 *)(slots + (w * 2) * SLOT_FLOATS) + lane;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        dpa[c * 64] = f32x4{accA[4 * c + 0], accA[4 * c + 1], accA[4 * c + 2], accA[4 * c + 3]};
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            f32x4 *dp = (f32x4 *)(slots + (w * 2 + 1) * SLOT_FLOATS) + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                dp[c * 64] = f32x4{accB[4 * c + 0], accB[4 * c + 1], accB[4 * c + 2], accB[4 * c + 3]};
+        }
+        if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st3 = __builtin_amdgcn_s_memtime(); }
+        // stage barrier: only the LDS traffic has to be complete, not the pv / spike stores of the epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (DBG) {
+            const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+            dbg[0] += st1 - st0; dbg[1] += st2 - st1; dbg[2] += st3 - st2; dbg[3] += st4 - st3;
+        }
+    };
+
+    const int nstage = 4 * T + 8;       // a multiple of 4
+    for (int g = 0; g < nstage; g += 4) {
+        stage(g + 0, std::integral_constant<int, 0>{});
+        stage(g + 1, std::integral_constant<int, 1>{});
+        stage(g + 2, std::integral_constant<int, 2>{});
+        stage(g + 3, std::integral_constant<int, 3>{});
+    }
+
+    if (DBG && lane == 0 && b == 0) {
+        unsigned long long *dp = (unsigned long long *)v_out + w * 8;       // v_out doubles as the debug buffer
+        dp[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        dp[1] = dbg[0]; dp[2] = dbg[1]; dp[3] = dbg[2]; dp[4] = dbg[3];
+    }
+    // state back to HBM: eps1 of the last step lives in image[(T-1)&1]
+    const float *fin = lds + ((T - 1) & 1) * IMG_FLOATS;
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const int c = (grp - w) & 3;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const long gidx = (b * 32 + 4 * w + c) * 256 + ii * 64 + lane;
+            eps0_g[gidx] = e0[grp][ii];
+            eps1_g[gidx] = fin[ioff + c * CHF + ii * 4 * ROWF];
+        }
+    }
+    if (REFRACTORY) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                arp_g[(b * 32 + rr + 8 * wq + 4 * h) * 256 + 32 * (2 * k + wpar) + j] = arp[k][rr];
+    }
+}
+
 // readout weights (N, 32*256) [n][co][pix]  ->  epilogue layout [me][wq][n][lane][rr]:
 //   co = rr + 8*wq + 4*(lane>>5), pix = 32*me + (lane&31)
 __global__ void k_permute_readout(const float *__restrict__ Wt, float *__restrict__ Wp, int N)
@@ -1544,6 +1818,8 @@ extern "C" int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void 
     return DCLL_OK;
 }
 
+constexpr int DCLL_C32D_MIN_T = 24;     // shorter sequences: k_lif_seq_c32 (half the pipeline fill)
+
 template <bool R, int NRO>
 static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, const float *W, const float *b,
                        const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
@@ -1581,6 +1857,29 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
     if (d->h != 16 || d->w != 16) {         // large plane: k_lif_seq_c32t, one workgroup per (sample, 8 x 32 tile)
         if (n_ro) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout only on the 16x16 plane");
         return dcll_launch_seq_c32t(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, st);
+    }
+    if (n_ro == 0 && T >= DCLL_C32D_MIN_T) {      // long sequence: two tiles per wave and stage
+#define DCLL_LAUNCH_C32D(R, O)                                                                                          \
+    hipLaunchKernelGGL((k_lif_seq_c32d<R, O>), dim3(B), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, \
+                       pv_out, v_out, T, B, d->alpharp, d->wrp)
+        if (d->refractory) {
+            switch (out) {
+            case 0: DCLL_LAUNCH_C32D(true, 0); break;
+            case 1: DCLL_LAUNCH_C32D(true, 1); break;
+            case 2: DCLL_LAUNCH_C32D(true, 2); break;
+            default: DCLL_LAUNCH_C32D(true, 3); break;
+            }
+        } else {
+            switch (out) {
+            case 0: DCLL_LAUNCH_C32D(false, 0); break;
+            case 1: DCLL_LAUNCH_C32D(false, 1); break;
+            case 2: DCLL_LAUNCH_C32D(false, 2); break;
+            default: DCLL_LAUNCH_C32D(false, 3); break;
+            }
+        }
+#undef DCLL_LAUNCH_C32D
+        HIP_CHECK_LAUNCH("k_lif_seq_c32d");
+        return DCLL_OK;
     }
 #define DCLL_ARGS out, B, st, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out, T, d->alpharp, d->wrp
     if (d->refractory) {
