@@ -12,7 +12,7 @@ That is the span of the reference's test_radio_ml.py:142-146 plus its input enco
 `--plane 128` runs the same path on the reference's argparse-default 128x128 I/Q plane (test_radio_ml.py:52; tiled
 kernels k_lif_seq_c1t / k_lif_seq_c32t, default batch 64) — a secondary configuration, not the headline number.
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` for the dominant kernel
-(k_lif_seq_c32, fp32 MFMA bound) and `cpu_baseline` (the torch-CPU port of the reference timed on this host).
+(k_lif_seq_c32d, fp32 MFMA bound) and `cpu_baseline` (the torch-CPU port of the reference timed on this host).
 """
 import argparse
 import json
@@ -136,7 +136,7 @@ def main():
         a.batch = 4096 if R == 16 else 64
     if a.cpu_windows is None:
         a.cpu_windows = 512 if R == 16 else 4
-    hot_kernel = "k_lif_seq_c32" if R == 16 else "k_lif_seq_c32t"
+    hot_kernel = "k_lif_seq_c32d" if R == 16 else "k_lif_seq_c32t"
 
     rank, local_rank, world = parallel.init_process_group()
     assert world == a.gpus, "launch with torchrun --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
@@ -183,7 +183,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # dominant kernel: HIP-event time of every k_lif_seq_c32 launch of the timed region (same stream as the launch)
+    # dominant kernel: HIP-event time of every k_lif_seq_c32d launch of the timed region (same stream as the launch)
     c32_ms = [s.elapsed_time(e) for s, e in prof.get("lif_c32", [])]
     avg_c32_s = float(np.mean(c32_ms)) / 1e3 if c32_ms else float("nan")
     flop_per_launch = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T_STEPS * B

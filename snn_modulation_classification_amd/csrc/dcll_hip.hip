@@ -12,7 +12,8 @@
 // -ffp-contract=off is part of the arithmetic contract: the trace lines are three separately rounded ops.
 //
 // Kernels
-//   k_lif_seq_c32      the hot kernel: one 32->32 7x7 layer, ALL T timesteps, one sample per workgroup.
+//   k_lif_seq_c32d     the hot kernel (T >= 24): k_lif_seq_c32 with two pixel tiles per wave and stage — see its header.
+//   k_lif_seq_c32      one 32->32 7x7 layer, ALL T timesteps, one sample per workgroup (short sequences, per-step calls).
 //                      8 waves; wave w owns input channels 4w..4w+3 (a K-slice of the implicit GEMM):
 //                      their eps0/eps1 traces (registers + a zero-padded LDS image) and the 2x49 weight
 //                      fragments of v_mfma_f32_32x32x2_f32 (weight-stationary in VGPRs).  The fp32
