@@ -5,37 +5,35 @@
 #include "dcll_internal.h"
 
 // ------------------------------------------------------------------------------------------------------------
-// k_lif_seq_c32t — the same 32 -> 32 channel 7x7 layer over all T steps on a LARGE plane (H % 8 == 0, W % 32 == 0;
-// the reference's default 128x128 I/Q plane, test_radio_ml.py:52): one workgroup per (sample, 8 x 32 pixel tile).
-// Same machine as k_lif_seq_c32 (8 waves x 4 input channels, weights in registers, systolic accumulator hand-off,
-// one barrier per stage, epilogue split by register quad), with these differences:
-//   - an MFMA tile is ONE image row of 32 pixels (lane&31 = column), so every spike word is still one ballot half
-//     and the B-fragment reads of a half-wave are 32 consecutive floats (conflict free);
-//   - the workgroup keeps the eps1 traces of its tile PLUS the 3-pixel halo (14 rows x 38 columns per channel,
-//     row stride TRW, channel stride TCH = 32 mod 64 banks) and recomputes the halo redundantly (2.08x trace work;
-//     the halo values are the same fp32 ops on the same inputs as the owning tile computes, so the result stays
+// k_lif_seq_c32t — the 32 -> 32 channel 7x7 layer over all T steps on a LARGE plane (H % 8 == 0, W % 32 == 0; the
+// reference's default 128x128 I/Q plane, test_radio_ml.py:52): one workgroup per (sample, 8 x 32 pixel tile).
+// The machine is k_lif_seq_c32d's (dcll_hip.hip): 8 waves x 4 input channels, weights in registers, two tiles per
+// wave and stage as independent accumulator chains handed from wave to wave through single-buffered LDS slots, two
+// barriers per stage, all non-MFMA work of a stage done by every wave between them (while the matrix pipe is empty),
+// stage loop unrolled by four.  What differs:
+//   - an MFMA tile is ONE image row of 32 pixels (lane&31 = column): a spike word is still one ballot half, a
+//     half-wave's B reads are 32 consecutive floats (conflict free), and the pair (2p, 2p+1) shares 8 LDS rows per
+//     channel pair (tap row ky of the second tile = tap row ky+1 of the first): 112 ds_read dwords per stage;
+//   - the workgroup keeps the eps1 traces of its tile PLUS the 3-pixel halo (14 rows x 38 columns per channel, row
+//     stride TRW, channel stride TCH = 32 mod 64 banks) and recomputes the halo redundantly (2.08x trace work; the
+//     halo values are the same fp32 ops on the same inputs as the owning tile computes, so the result stays
 //     bit-exact).  Pixels outside the plane stay 0 = the convolution's zero padding;
 //   - only the wave that owns 4 input channels ever reads them, so ONE image suffices: region row r (last read by
-//     tile min(r,7), first needed again by tile max(0,r-6)) is advanced in place between those two reads;
-//   - chain position p (channels 4p..4p+3) sits on hardware wave 4*(p&1) + (p>>1): the two waves of a SIMD are
-//     neighbours in the chain, so their tile indices m = (g - p) & 7 always differ in parity, and every wave carries
-//     its non-MFMA work — its epilogue share AND its trace rows — in its EVEN-m stages while its SIMD partner starts
-//     its MFMAs at once (the arrangement that k_lif_seq_c32 measured best):
-//       m = 0: rows 6-8  -> step t      m = 4: rows 12-13 -> step t, rows 0-1 -> step t+1
-//       m = 2: rows 9-11 -> step t      m = 6: rows 2-5   -> step t+1
-//   - input spikes: one global load per lane fetches the (row, channel, word) triples of a row group one stage ahead;
-//     the lanes of a trace element pick their word with ds_bpermute (one VGPR held across the chain, not 8).
-// eps0 of the region lives in registers (11 element slots x 4 channels).
+//     tile min(r,7), first needed again by tile max(0,r-6)) is advanced in place between those two reads — in the
+//     non-MFMA phase of the stage with pair index p:
+//       p = 0: rows 5-7 -> step t     p = 1: rows 8-10 -> step t     p = 2: rows 11-13 -> step t
+//       p = 3: rows 0-4 -> step t+1
+//   - input spikes: one global load per lane fetches the (row, channel, word) triples of the next stage's row group
+//     while the chains run; the lanes of a trace element pick their word with ds_bpermute.
+// eps0 of the region lives in registers (9 element slots x 4 channels).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TRW = 38, TCH = 544, TIMG = 32 * TCH;
 
-// row groups of the trace schedule: first region row, number of rows
+// row group advanced in the stage with pair index p: first region row, number of rows
 struct tgroup { int row0, nrows; };
-__device__ constexpr tgroup TG[5] = {{6, 3}, {9, 3}, {12, 2}, {0, 2}, {2, 4}};
+__device__ constexpr tgroup TG[4] = {{5, 3}, {8, 3}, {11, 3}, {0, 5}};
 
-// ABLATE is a diagnostic knob for experiments/ablate_c32t.hip only (bit0: no epilogue, bit1: no trace advance,
-// bit2: no accumulator hand-off); every product launch uses ABLATE = 0.
-template <bool REFRACTORY, int OUT, int ABLATE = 0>     // OUT bit0: pv, bit1: v
+template <bool REFRACTORY, int OUT>     // OUT bit0: pv, bit1: v
 __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                        const float *__restrict__ bias, const float *__restrict__ tau4,
                                                        float *__restrict__ eps0_g, float *__restrict__ eps1_g,
@@ -44,12 +42,11 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
                                                        int B, int H, int Wd, float alpharp, float wrp)
 {
     __shared__ __attribute__((aligned(16))) float lds[TIMG + NWAVE * 2 * SLOT_FLOATS + 32];
-    float *slots = lds + TIMG;
+    float *slots = lds + TIMG;                  // [wave][tile of the pair][16 x 64]
     float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-    const int hwv = __builtin_amdgcn_readfirstlane(tid >> 6);   // hardware wave; SIMD = hwv & 3
-    const int wq = hwv & 3, wpar = hwv >> 2;                     // epilogue quad / tile parity owned by this wave
-    const int w = 2 * wq + wpar;                                 // position in the chain: channels 4w..4w+3
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // chain position: channels 4w..4w+3
+    const int wq = w & 3, wpar = w >> 2;                          // my epilogue share: quad wq of the pair's tile wpar
     const int wpr = Wd >> 5;                                  // spike words per image row = tiles per row
     const int ntile = (H >> 3) * wpr;
     const long b = blockIdx.x / ntile;
@@ -86,13 +83,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
         pb[s] = (erow(s) * 12 + (((ecol(s) - 3) >> 5) + 1)) * 4;
         sh[s] = (ecol(s) - 3) & 31;
     }
-    auto spike_bit = [&](uint32_t word, int s, int c) -> float {
-        int a = pb[s];
-        asm volatile("" : "+v"(a));
-        const uint32_t wv = (uint32_t)__builtin_amdgcn_ds_bpermute(a + 12 * c, (int)word);
-        return (float)((wv >> sh[s]) & 1u);
-    };
-    // x * tau_s for x in {0, 1} without the int->float conversion: sign-extend the spike bit to a 0 / ~0 mask and AND
+    // x * tau_s for x in {0, 1} without an int->float conversion: sign-extend the spike bit to a 0 / ~0 mask and AND
     // it onto tau_s (exact: the product is tau_s or +0.0)
     auto spike_times = [&](uint32_t word, int s, int c, float ts) -> float {
         int a = pb[s];
@@ -101,12 +92,12 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
         const int mask = __builtin_amdgcn_sbfe(wv, sh[s], 1);
         return __int_as_float(mask & __float_as_int(ts));
     };
-    float e0[5][3][4];
+    float e0[4][3][4];
     __syncthreads();        // image zeroed
 
     // prologue: state of the region from HBM (0 outside the plane), advanced to step 0 -> image
 #pragma unroll
-    for (int gi = 0; gi < 5; ++gi) {
+    for (int gi = 0; gi < 4; ++gi) {
         const uint32_t word = fetch(gi, 0);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -121,8 +112,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
                 const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
                 const long gidx = (b * 32 + 4 * w + c) * HW + (long)gy * Wd + gx;
                 float e0v = ok ? eps0_g[gidx] : 0.0f, e1 = ok ? eps1_g[gidx] : 0.0f;
-                const float xin = spike_bit(word, s, c);
-                trace_update(xin, ta, tm, tas, ts, e0v, e1);
+                const float bb = tas * e0v;
+                e0v = spike_times(word, s, c, ts) + bb;
+                const float cc = ta * e1, dd = e0v * tm;
+                e1 = cc + dd;
                 e0[gi][s][c] = e0v;
                 if (ing) lds[(4 * w + c) * TCH + TG[gi].row0 * TRW + idx] = e1;
             }
@@ -136,7 +129,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
 #pragma unroll
         for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
 
-    // refractory trace of my epilogue share: tiles (rows) m = 2k + wpar, quad wq: channel rr + 8 wq + 4h, column j
+    // refractory trace of my epilogue share: tiles (rows) m = 2k + wpar (k = pair index), quad wq
     float arp[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -156,181 +149,170 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
     __syncthreads();
 
     // advance row group GI of my 4 channels by one step with the fetched spike words.  Branch-free and batched: all
-    // ds_bpermutes and image reads go out first, then the arithmetic, then the writes — one LDS round trip per phase
-    // instead of one per element (per-element exec-mask branches made this 8.5k cycles per stage).  Lanes past the
-    // end of the group are pointed at the 12 pad floats behind their channel's 14 x 38 image (never read).
+    // ds_bpermutes and image reads go out first, then the arithmetic, then the writes — one LDS round trip per phase.
+    // Lanes past the end of the group are pointed at the 12 pad floats behind their channel's 14 x 38 image.
     auto advance = [&](auto GC, uint32_t word) {
         constexpr int GI = decltype(GC)::value;
         constexpr int NS = (TG[GI].nrows * TRW + 63) / 64;
-        float xts[NS][4], e1[NS][4];        // x * tau_s, eps1
         int off[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < NS; ++s)
             off[s] = (lane + 64 * s < TG[GI].nrows * TRW) ? TG[GI].row0 * TRW + lane + 64 * s : 14 * TRW;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                xts[s][c] = (ABLATE & 8) ? 0.0f : spike_times(word, s, c, tau4[3 * 32 + 4 * w + c]);
-                e1[s][c] = lds[(4 * w + c) * TCH + off[s]];
+        for (int ch = 0; ch < 2; ++ch) {        // two channels at a time: 12 instead of 24 transient registers
+            float xts[NS][2], e1[NS][2];        // x * tau_s, eps1
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int c = 2 * ch + k;
+                    xts[s][k] = spike_times(word, s, c, tau4[3 * 32 + 4 * w + c]);
+                    e1[s][k] = lds[(4 * w + c) * TCH + off[s]];
+                }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = 2 * ch + k;
+                const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c], tas = tau4[2 * 32 + 4 * w + c];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {      // dcll/pytorch_libdcll.py:493-494, every op rounded separately
+                    const float bb = tas * e0[GI][s][c];
+                    e0[GI][s][c] = xts[s][k] + bb;
+                    const float cc = ta * e1[s][k];
+                    const float dd = e0[GI][s][c] * tm;
+                    e1[s][k] = cc + dd;
+                }
             }
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) lds[(4 * w + 2 * ch + k) * TCH + off[s]] = e1[s][k];
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c], tas = tau4[2 * 32 + 4 * w + c];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {      // dcll/pytorch_libdcll.py:493-494, every op rounded separately
-                const float bb = tas * e0[GI][s][c];
-                e0[GI][s][c] = xts[s][c] + bb;
-                const float cc = ta * e1[s][c];
-                const float dd = e0[GI][s][c] * tm;
-                e1[s][c] = cc + dd;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lds[(4 * w + c) * TCH + off[s]] = e1[s][c];
     };
-
-    const int nstage = 8 * T + 9;
-    uint32_t fw0 = 0, fw1 = 0;          // spike words of the row group(s) my next even-m stage advances
-    unsigned long long dbg_wait = 0, dbg_t0 = 0, dbg_epi = 0, dbg_tr = 0, dbg_mf = 0;   // ABLATE & 64 only
-    if (ABLATE & 64) dbg_t0 = __builtin_amdgcn_s_memtime();
-    for (int g = 0; g < nstage; ++g) {
-        unsigned long long dbg_a = 0;
-        if (ABLATE & 64) dbg_a = __builtin_amdgcn_s_memtime();
+    // spike words of the row group stage g advances (0 if it advances none): groups 0-2 -> step t (t >= 1),
+    // group 3 -> step t+1 (t+1 < T)
+    auto fetch_for_stage = [&](const int g) -> uint32_t {
         const int q = g - w;
-        const bool active = q >= 0 && q < 8 * T;
-        const int m = q & 7, t = q >> 3;
-        // ---- (0) odd m: fetch the spike words for the groups of my next stage (m+1, even; step tn) ----
-        if (!(ABLATE & (2 | 8)) && q >= 0 && q + 1 < 8 * T && (m & 1)) {
-            const int tn = (q + 1) >> 3;
-            switch (m) {
-            case 7: if (tn >= 1) fw0 = fetch(0, tn); break;                  // m' = 0: rows 6-8 -> tn
-            case 1: if (tn >= 1) fw0 = fetch(1, tn); break;                  // m' = 2: rows 9-11 -> tn
-            case 3:                                                          // m' = 4: rows 12-13 -> tn, rows 0-1 -> tn+1
-                if (tn >= 1) fw0 = fetch(2, tn);
-                if (tn + 1 < T) fw1 = fetch(3, tn + 1);
-                break;
-            default: if (tn + 1 < T) fw0 = fetch(4, tn + 1); break;          // m' = 6: rows 2-5 -> tn+1
-            }
-        }
-        // ---- (1) epilogue share: quad wq of tile qe = g - 8 ----
+        if (q < 0 || q >= 4 * T) return 0u;
+        const int p = q & 3, t = q >> 2;
+        if (p < 3) return t >= 1 ? fetch(p, t) : 0u;
+        return t + 1 < T ? fetch(3, t + 1) : 0u;
+    };
+    uint32_t fword = fetch_for_stage(0);
+
+    // one stage; U = g & 3 at compile time
+    auto stage = [&](const int g, auto UC) {
+        constexpr int U = decltype(UC)::value;
+        const int q = g - w;
+        const bool active = q >= 0 && q < 4 * T;
+        const int p = q & 3, t = q >> 2;
+        // ---- (0) epilogue share's input: quad wq of tile wpar of the pair qe = g - 8 (pair index U) that wave 7 finished last stage
         const int qe = g - 8;
-        const bool loaded = ((g & 1) == wpar);          // <=> my m is even: this stage carries my non-MFMA work
-        if (loaded) __builtin_amdgcn_s_setprio(1);
-        if (!(ABLATE & 1) && qe >= 0 && qe < 8 * T && loaded) {
-            const int te = qe >> 3, me = qe & 7;
-            const f32x4 v4 = *((const f32x4 *)(slots + (7 * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + wq * 64 + lane);
+        const bool epi = qe >= 0 && qe < 4 * T;
+        f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+        if (epi) v4 = *((const f32x4 *)(slots + (7 * 2 + wpar) * SLOT_FLOATS) + wq * 64 + lane);
+        // ---- (1) epilogue share ----
+        if (epi) {
+            const int te = qe >> 2, me = 2 * U + wpar;
             const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
             const long oelem = obase * HW + (long)(y0 + me) * Wd + x0 + j;    // + rr*HW
-            float *pvp = pv_out + oelem, *vp = v_out + oelem;
-            auto quad = [&](float (&ar)[4]) {
-                uint32_t myword = 0;
+            uint32_t myword = 0;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    float v = v4[rr];
-                    bool s;
-                    if (REFRACTORY) v = refractory(v4[rr], ar[rr], alpharp, wrp, s);
-                    else s = v > 0.0f;
-                    unsigned long long mk = __ballot(s);
-                    uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-                    myword = (j == rr) ? mine : myword;
-                    if (OUT & 1) pvp[rr * HW] = sigmoidf_dev(v);
-                    if (OUT & 2) vp[rr * HW] = v;
-                }
-                if (spk_out && j < 4) spk_out[(obase + j) * words + (long)(y0 + me) * wpr + tx] = myword;
-            };
-            switch (me >> 1) {
-            case 0: quad(arp[0]); break;
-            case 1: quad(arp[1]); break;
-            case 2: quad(arp[2]); break;
-            default: quad(arp[3]); break;
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = v4[rr];
+                bool s;
+                if (REFRACTORY) v = refractory(v4[rr], arp[U][rr], alpharp, wrp, s);
+                else s = v > 0.0f;
+                const unsigned long long mk = __ballot(s);
+                const uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                myword = (j == rr) ? mine : myword;
+                if (OUT & 1) pv_out[oelem + rr * HW] = sigmoidf_dev(v);
+                if (OUT & 2) v_out[oelem + rr * HW] = v;
+            }
+            if (spk_out && j < 4) spk_out[(obase + j) * words + (long)(y0 + me) * wpr + tx] = myword;
+        }
+        // ---- (2) trace rows of this stage (their rows are not read between tile 2p-1 and tile 2p) ----
+        if (active) {
+            switch (p) {        // wave-uniform: keeps e0[][][] statically indexed (registers)
+            case 0: if (t >= 1) advance(std::integral_constant<int, 0>{}, fword); break;
+            case 1: if (t >= 1) advance(std::integral_constant<int, 1>{}, fword); break;
+            case 2: if (t >= 1) advance(std::integral_constant<int, 2>{}, fword); break;
+            default: if (t + 1 < T) advance(std::integral_constant<int, 3>{}, fword); break;
             }
         }
-        if (ABLATE & 64) { unsigned long long x_ = __builtin_amdgcn_s_memtime(); dbg_epi += x_ - dbg_a; dbg_a = x_; }
+        //   chain inputs out of the slots (written in the previous stage) — read last in the phase: 32 registers that
+        //   would otherwise be live across the epilogue and the trace rows (14 spilled VGPRs)
+        f32x16 accA, accB;
         if (active) {
-            // ---- (2) even m: advance my row group(s) (their rows are not read between tile m-1 and tile m) ----
-            if (!(ABLATE & 2) && !(m & 1)) {
-                switch (m) {        // wave-uniform: keeps e0[][][] statically indexed (registers)
-                case 0: if (t >= 1) advance(std::integral_constant<int, 0>{}, fw0); break;
-                case 2: if (t >= 1) advance(std::integral_constant<int, 1>{}, fw0); break;
-                case 4:
-                    if (t >= 1) advance(std::integral_constant<int, 2>{}, fw0);
-                    if (t + 1 < T) advance(std::integral_constant<int, 3>{}, fw1);
-                    break;
-                default: if (t + 1 < T) advance(std::integral_constant<int, 4>{}, fw0); break;
-                }
-            }
-            if (loaded) __builtin_amdgcn_s_setprio(0);
-            if (ABLATE & 64) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                unsigned long long x_ = __builtin_amdgcn_s_memtime(); dbg_tr += x_ - dbg_a; dbg_a = x_;
-            }
-            // ---- (3) my K-slice of the chain ----
-            f32x16 acc;
-            if (w == 0 || (ABLATE & 4)) {
+            if (w == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+                for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
             } else {
-                const f32x4 *sp = (const f32x4 *)(slots + ((w - 1) * 2 + ((g - 1) & 1)) * SLOT_FLOATS) + lane;
+                const f32x4 *sp = (const f32x4 *)(slots + ((w - 1) * 2) * SLOT_FLOATS) + lane;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    f32x4 v4 = sp[c * 64];
-                    acc[4 * c + 0] = v4[0]; acc[4 * c + 1] = v4[1]; acc[4 * c + 2] = v4[2]; acc[4 * c + 3] = v4[3];
+                    f32x4 va = sp[c * 64], vb = sp[SLOT_FLOATS / 4 + c * 64];
+                    accA[4 * c + 0] = va[0]; accA[4 * c + 1] = va[1]; accA[4 * c + 2] = va[2]; accA[4 * c + 3] = va[3];
+                    accB[4 * c + 0] = vb[0]; accB[4 * c + 1] = vb[1]; accB[4 * c + 2] = vb[2]; accB[4 * c + 3] = vb[3];
                 }
             }
-            const int i0 = bbase + m * TRW;
-            auto tapval = [&](int cp, int off) -> float { return lds[i0 + cp * 2 * TCH + off]; };
+        }
+        // every slot read of this stage has completed before any wave writes its slots again
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // spike words of the NEXT stage's row group: they land while the chains run
+        fword = fetch_for_stage(g + 1);
+        // ---- (3) my K-slice of both chains ----
+        if (active) {
+            // LDS rows 0..7 below the pair's first image row, per channel pair: row rho is tap row ky = rho of tile A
+            // (rho <= 6) and tap row ky = rho - 1 of tile B (rho >= 1); next row fetched before the MFMAs of this one.
+            const int i0 = bbase + 2 * p * TRW;
             float bq[2][7];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = tapval(0, kx);
+            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = lds[i0 + kx];
 #pragma unroll
-            for (int r = 0; r < 14; ++r) {
-                if (r + 1 < 14) {
-                    const int cpn = (r + 1) / 7, kyn = (r + 1) % 7;
+            for (int r = 0; r < 16; ++r) {
+                const int cp = r / 8, rho = r % 8;
+                if (r + 1 < 16) {
+                    const int cpn = (r + 1) / 8, rhon = (r + 1) % 8;
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = tapval(cpn, kyn * TRW + kx);
+                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = lds[i0 + cpn * 2 * TCH + rhon * TRW + kx];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r / 7][(r % 7) * 7 + kx], bq[r & 1][kx], acc, 0, 0, 0);
+                for (int kx = 0; kx < 7; ++kx) {
+                    if (rho <= 6)
+                        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][rho * 7 + kx], bq[r & 1][kx], accA, 0, 0, 0);
+                    if (rho >= 1)
+                        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][(rho - 1) * 7 + kx], bq[r & 1][kx], accB, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            f32x4 *dp = (f32x4 *)(slots + (w * 2 + (g & 1)) * SLOT_FLOATS) + lane;
-            if (ABLATE & 4) {
-                if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.678f) dp[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            } else {
+                if (r == 14) {          // tile A is complete (its last tap row was rho = 6 of the second channel pair)
+                    f32x4 *dpa = (f32x4 *)(slots + (w * 2) * SLOT_FLOATS) + lane;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x4 v4 = {acc[4 * c + 0], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
-                    dp[c * 64] = v4;
+                    for (int c = 0; c < 4; ++c)
+                        dpa[c * 64] = f32x4{accA[4 * c + 0], accA[4 * c + 1], accA[4 * c + 2], accA[4 * c + 3]};
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        } else if (loaded) {
-            __builtin_amdgcn_s_setprio(0);
+            f32x4 *dp = (f32x4 *)(slots + (w * 2 + 1) * SLOT_FLOATS) + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                dp[c * 64] = f32x4{accB[4 * c + 0], accB[4 * c + 1], accB[4 * c + 2], accB[4 * c + 3]};
         }
-        // stage barrier: only the LDS traffic (slots, image) has to be complete — NOT the pv / spike stores of the
-        // epilogue, which __syncthreads() would also wait for (s_waitcnt vmcnt(0)).
-        if (ABLATE & 64) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            unsigned long long x_ = __builtin_amdgcn_s_memtime();
-            dbg_mf += x_ - dbg_a;
-            asm volatile("s_barrier" ::: "memory");
-            dbg_wait += __builtin_amdgcn_s_memtime() - x_;
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-    }
-    if ((ABLATE & 64) && lane == 0 && blockIdx.x == 0) {
-        unsigned long long tot = __builtin_amdgcn_s_memtime() - dbg_t0;
-        unsigned long long *dp = (unsigned long long *)v_out + w * 8;       // v_out doubles as the debug buffer
-        dp[0] = tot; dp[1] = dbg_wait; dp[2] = dbg_epi; dp[3] = dbg_tr; dp[4] = dbg_mf;
+        // stage barrier: only the LDS traffic has to be complete, not the pv / spike stores of the epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    const int nstage = 4 * T + 8;       // a multiple of 4
+    for (int g = 0; g < nstage; g += 4) {
+        stage(g + 0, std::integral_constant<int, 0>{});
+        stage(g + 1, std::integral_constant<int, 1>{});
+        stage(g + 2, std::integral_constant<int, 2>{});
+        stage(g + 3, std::integral_constant<int, 3>{});
     }
 
     // state back to HBM: the interior of the region (rows 3..10, columns 3..34)
 #pragma unroll
-    for (int gi = 0; gi < 5; ++gi)
+    for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (64 * s >= TG[gi].nrows * TRW) continue;
