@@ -813,7 +813,10 @@ constexpr int C1_MAXT = 4096;       // longest window the fused IQ encoder of k_
 // bias, tap(0,0), tap(0,1), ... in order.  A = weights (lane: co = lane&31, kx parity = lane>>5; 28 VGPRs for the
 // whole sequence), B = eps1 from a zero-padded 22x24 LDS plane (per-lane base + immediate), D[co][pixel].
 // 4 waves = 8 pixel tiles of 32 (wave w: image rows 4w..4w+3); a thread also owns pixel `tid` of the traces.
-template <bool REFRACTORY>
+// FAST: c_out == 32 and exactly the outputs spk_out + pv_out — the benchmark's configuration: no per-value channel /
+// pointer guards, and stores as uniform base + 32-bit lane offset (the generic form needs 64-bit address arithmetic and
+// exec-mask branches per value: ~210 address VALU and 160 SGPR reloads per step).
+template <bool REFRACTORY, bool FAST = false>
 __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
                                                     const float *__restrict__ iq, const float *__restrict__ thr_i,
                                                     const float *__restrict__ thr_q, int L, int t0,
@@ -880,6 +883,8 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
                 for (int i = 0; i < 4; ++i)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ky][i], bp[ky * PS + 2 * i], acc, 0, 0, 0);
             uint32_t myword = 0;
+            float *pvb = pv_out + obase * 256;                      // wave-uniform base of this step's pv planes
+            const unsigned loff = 4 * h * 256 + 32 * m + j;         // + ((r&3) + 8(r>>2)) * 256 per value
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -890,13 +895,19 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
                 unsigned long long mk = __ballot(s);
                 uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
                 myword = (j == r) ? mine : myword;
-                if (co < c_out) {
+                if (FAST) {
+                    (pvb + ((r & 3) + 8 * (r >> 2)) * 256)[loff] = sigmoidf_dev(v);
+                } else if (co < c_out) {
                     if (pv_out) pv_out[(obase + co) * 256 + 32 * m + j] = sigmoidf_dev(v);
                     if (v_out) v_out[(obase + co) * 256 + 32 * m + j] = v;
                 }
             }
             const int cow = (j & 3) + 8 * (j >> 2) + 4 * h;
-            if (spk_out && j < 16 && cow < c_out) spk_out[(obase + cow) * 8 + m] = myword;
+            if (FAST) {
+                if (j < 16) (spk_out + obase * 8)[cow * 8 + m] = myword;
+            } else if (spk_out && j < 16 && cow < c_out) {
+                spk_out[(obase + cow) * 8 + m] = myword;
+            }
         }
         __syncthreads();
     }
@@ -1905,12 +1916,18 @@ static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float 
     if (d->h != 16 || d->w != 16)       // large plane: k_lif_seq_c1t, one workgroup per (sample, 8 x 32 tile)
         return dcll_launch_seq_c1t(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
                                    T, B, st);
-    if (d->refractory)
-        hipLaunchKernelGGL(k_lif_seq_c1<true>, dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,
-                           tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
-    else
-        hipLaunchKernelGGL(k_lif_seq_c1<false>, dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,
-                           tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp);
+    const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out;
+#define DCLL_LAUNCH_C1(R, F)                                                                                            \
+    hipLaunchKernelGGL((k_lif_seq_c1<R, F>), dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,  \
+                       tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp)
+    if (d->refractory) {
+        if (fastpath) DCLL_LAUNCH_C1(true, true);
+        else DCLL_LAUNCH_C1(true, false);
+    } else {
+        if (fastpath) DCLL_LAUNCH_C1(false, true);
+        else DCLL_LAUNCH_C1(false, false);
+    }
+#undef DCLL_LAUNCH_C1
     HIP_CHECK_LAUNCH("k_lif_seq_c1");
     return DCLL_OK;
 }

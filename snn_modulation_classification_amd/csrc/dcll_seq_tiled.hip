@@ -348,7 +348,8 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
 constexpr int C1T_MAXT = 4096;
 constexpr int C1T_REGION = 14 * TRW;        // 532
 
-template <bool REFRACTORY>
+// FAST: c_out == 32 and exactly the outputs spk_out + pv_out (see k_lif_seq_c1).
+template <bool REFRACTORY, bool FAST = false>
 __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *__restrict__ cells,
                                                       const float *__restrict__ iq, const float *__restrict__ thr_i,
                                                       const float *__restrict__ thr_q, int L, int t0,
@@ -439,6 +440,8 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ky][i], bp[ky * TRW + 2 * i], acc, 0, 0, 0);
             uint32_t myword = 0;
             const long opix = (long)(y0 + m) * Wd + x0 + j;
+            float *pvb = pv_out + obase * HW;                       // wave-uniform base of this step's pv planes
+            const unsigned loff = 4 * h * (unsigned)HW + (unsigned)opix;   // 32 planes fit 32 bits (launcher check)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -449,13 +452,19 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
                 unsigned long long mk = __ballot(s);
                 uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
                 myword = (j == r) ? mine : myword;
-                if (co < c_out) {
+                if (FAST) {
+                    (pvb + ((r & 3) + 8 * (r >> 2)) * HW)[loff] = sigmoidf_dev(v);
+                } else if (co < c_out) {
                     if (pv_out) pv_out[(obase + co) * HW + opix] = sigmoidf_dev(v);
                     if (v_out) v_out[(obase + co) * HW + opix] = v;
                 }
             }
             const int cow = (j & 3) + 8 * (j >> 2) + 4 * h;
-            if (spk_out && j < 16 && cow < c_out) spk_out[(obase + cow) * words + (long)(y0 + m) * wpr + tx] = myword;
+            if (FAST) {
+                if (j < 16) (spk_out + obase * words + (long)(y0 + m) * wpr + tx)[(unsigned)cow * (unsigned)words] = myword;
+            } else if (spk_out && j < 16 && cow < c_out) {
+                spk_out[(obase + cow) * words + (long)(y0 + m) * wpr + tx] = myword;
+            }
         }
         __syncthreads();
     }
@@ -487,14 +496,18 @@ int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const flo
     if (iq && T > C1T_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "fused IQ encoder: T exceeds 4096 steps");
     const long nwg = (long)B * (d->h / 8) * (d->w / 32);
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel: batch x tiles exceeds the grid limit");
-    if (d->refractory)
-        hipLaunchKernelGGL(k_lif_seq_c1t<true>, dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i,
-                           thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,
-                           d->alpharp, d->wrp);
-    else
-        hipLaunchKernelGGL(k_lif_seq_c1t<false>, dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i,
-                           thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,
-                           d->alpharp, d->wrp);
+    const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out && (long)d->h * d->w * 32 < (1L << 30);
+#define DCLL_LAUNCH_C1T(R, F)                                                                                           \
+    hipLaunchKernelGGL((k_lif_seq_c1t<R, F>), dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q,  \
+                       L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w, d->alpharp, d->wrp)
+    if (d->refractory) {
+        if (fastpath) DCLL_LAUNCH_C1T(true, true);
+        else DCLL_LAUNCH_C1T(true, false);
+    } else {
+        if (fastpath) DCLL_LAUNCH_C1T(false, true);
+        else DCLL_LAUNCH_C1T(false, false);
+    }
+#undef DCLL_LAUNCH_C1T
     HIP_CHECK_LAUNCH("k_lif_seq_c1t");
     return DCLL_OK;
 }
