@@ -1437,8 +1437,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         // ---- (1) epilogue share ----
         if (epi) {
             const int te = qe >> 2, me = 2 * U + wpar;
-            const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
-            const long oelem = obase * 256 + 32 * me + j;                     // + rr*256
+            // stores as wave-uniform base + 32-bit lane offset (+ an immediate per value): no 64-bit address VALU
+            const long ubase = (((long)te * B + b) * 32 + 8 * wq) * 256;       // channel 8 wq of this step and sample
+            float *pvb = pv_out + ubase, *vb = v_out + ubase;
+            const unsigned loff = 4 * h * 256 + 32 * me + j;                    // + rr*256 = channel rr + 8 wq + 4 h
             uint32_t myword = 0;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -1449,10 +1451,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
                 const unsigned long long mk = __ballot(s);
                 const uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
                 myword = (j == rr) ? mine : myword;
-                if (OUT & 1) pv_out[oelem + rr * 256] = sigmoidf_dev(v);
-                if (OUT & 2) v_out[oelem + rr * 256] = v;
+                if (OUT & 1) pvb[loff + rr * 256] = sigmoidf_dev(v);
+                if (OUT & 2) vb[loff + rr * 256] = v;
             }
-            if (spk_out && j < 4) spk_out[(obase + j) * 8 + me] = myword;
+            if (spk_out && j < 4) (spk_out + (ubase >> 5))[(4 * h + j) * 8 + me] = myword;
         }
         // ---- (2) trace share (dcll/pytorch_libdcll.py:493-494, every op rounded separately) ----
         if (tr) {

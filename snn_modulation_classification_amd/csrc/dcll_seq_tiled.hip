@@ -213,8 +213,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
         // ---- (1) epilogue share ----
         if (epi) {
             const int te = qe >> 2, me = 2 * U + wpar;
-            const long obase = ((long)te * B + b) * 32 + 8 * wq + 4 * h;      // + rr = channel
-            const long oelem = obase * HW + (long)(y0 + me) * Wd + x0 + j;    // + rr*HW
+            // stores as wave-uniform base (per value) + 32-bit lane offset: no 64-bit address VALU
+            const long ubase = (((long)te * B + b) * 32 + 8 * wq) * HW;        // channel 8 wq of this step and sample
+            float *pvb = pv_out + ubase, *vb = v_out + ubase;
+            const unsigned loff = 4 * h * (unsigned)HW + (unsigned)((y0 + me) * Wd + x0 + j);   // + rr*HW
             uint32_t myword = 0;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -225,10 +227,11 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
                 const unsigned long long mk = __ballot(s);
                 const uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
                 myword = (j == rr) ? mine : myword;
-                if (OUT & 1) pv_out[oelem + rr * HW] = sigmoidf_dev(v);
-                if (OUT & 2) v_out[oelem + rr * HW] = v;
+                if (OUT & 1) (pvb + rr * HW)[loff] = sigmoidf_dev(v);
+                if (OUT & 2) (vb + rr * HW)[loff] = v;
             }
-            if (spk_out && j < 4) spk_out[(obase + j) * words + (long)(y0 + me) * wpr + tx] = myword;
+            if (spk_out && j < 4)
+                (spk_out + (ubase >> 5) + (long)(y0 + me) * wpr + tx)[(unsigned)(4 * h + j) * (unsigned)words] = myword;
         }
         // ---- (2) trace rows of this stage (their rows are not read between tile 2p-1 and tile 2p) ----
         if (active) {
@@ -519,6 +522,7 @@ int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, const 
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
     const long nwg = (long)B * (d->h / 8) * (d->w / 32);
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: batch x tiles exceeds the grid limit");
+    if ((long)d->h * d->w >= (1L << 26)) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: plane larger than 2^26 pixels");
 #define DCLL_LAUNCH_C32T(R, O)                                                                                          \
     hipLaunchKernelGGL((k_lif_seq_c32t<R, O>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1,   \
                        arp, spk_out, pv_out, v_out, T, B, d->h, d->w, d->alpharp, d->wrp)
