@@ -1310,16 +1310,17 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
                                                        float *__restrict__ pv_out, float *__restrict__ v_out, int T,
                                                        int B, float alpharp, float wrp)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * IMG_FLOATS + NWAVE * 2 * SLOT_FLOATS + 32];
+    __shared__ __attribute__((aligned(16))) float lds[2 * IMG_FLOATS + (NWAVE * 2 + 1) * SLOT_FLOATS];
     float *slots = lds + 2 * IMG_FLOATS;        // [wave][tile of the pair][16 x 64]
-    float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
+    float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;     // the bias as a slot-shaped tile: wave 0's chain input
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = w & 3, wpar = w >> 2;        // my epilogue share: quad wq of the pair's tile wpar
     const long b = blockIdx.x;
 
     for (int i = tid; i < 2 * IMG_FLOATS; i += 512) lds[i] = 0.0f;
-    if (tid < 32) sbias[tid] = bias[tid];
+    // slot layout: float4 c of lane l = accumulator registers 4c..4c+3 = channels (r&3) + 8c + 4(l>>5)
+    for (int i = tid; i < SLOT_FLOATS; i += 512) sbias[i] = bias[(i & 3) + 8 * (i >> 8) + 4 * ((i >> 7) & 1)];
 
     float wf[2][49];
 #pragma unroll
@@ -1406,17 +1407,16 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         //   chain inputs out of the slots (written in the previous stage)
         f32x16 accA, accB;
         if (active) {
-            if (w == 0) {
+            // wave 0 starts both chains from the bias tile, wave w > 0 from the two tiles wave w-1 left: one code path
+            // (a branch here costs 32 v_mov per stage to merge the accumulator tuples)
+            const float *inA = (w == 0) ? sbias : slots + ((w - 1) * 2) * SLOT_FLOATS;
+            const float *inB = (w == 0) ? sbias : slots + ((w - 1) * 2 + 1) * SLOT_FLOATS;
+            const f32x4 *spa = (const f32x4 *)inA + lane, *spb = (const f32x4 *)inB + lane;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
-            } else {
-                const f32x4 *sp = (const f32x4 *)(slots + ((w - 1) * 2) * SLOT_FLOATS) + lane;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x4 va = sp[c * 64], vb = sp[SLOT_FLOATS / 4 + c * 64];
-                    accA[4 * c + 0] = va[0]; accA[4 * c + 1] = va[1]; accA[4 * c + 2] = va[2]; accA[4 * c + 3] = va[3];
-                    accB[4 * c + 0] = vb[0]; accB[4 * c + 1] = vb[1]; accB[4 * c + 2] = vb[2]; accB[4 * c + 3] = vb[3];
-                }
+            for (int c = 0; c < 4; ++c) {
+                f32x4 va = spa[c * 64], vb = spb[c * 64];
+                accA[4 * c + 0] = va[0]; accA[4 * c + 1] = va[1]; accA[4 * c + 2] = va[2]; accA[4 * c + 3] = va[3];
+                accB[4 * c + 0] = vb[0]; accB[4 * c + 1] = vb[1]; accB[4 * c + 2] = vb[2]; accB[4 * c + 3] = vb[3];
             }
         }
         //   epilogue share: quad wq of tile wpar of the pair qe = g - 8 (pair index U) that wave 7 finished last stage

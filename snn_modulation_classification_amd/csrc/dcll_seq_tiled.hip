@@ -41,9 +41,9 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
                                                        float *__restrict__ pv_out, float *__restrict__ v_out, int T,
                                                        int B, int H, int Wd, float alpharp, float wrp)
 {
-    __shared__ __attribute__((aligned(16))) float lds[TIMG + NWAVE * 2 * SLOT_FLOATS + 32];
+    __shared__ __attribute__((aligned(16))) float lds[TIMG + (NWAVE * 2 + 1) * SLOT_FLOATS];
     float *slots = lds + TIMG;                  // [wave][tile of the pair][16 x 64]
-    float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;
+    float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;     // the bias as a slot-shaped tile: wave 0's chain input
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // chain position: channels 4w..4w+3
     const int wq = w & 3, wpar = w >> 2;                          // my epilogue share: quad wq of the pair's tile wpar
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
     const long words = HW >> 5;
 
     for (int i = tid; i < TIMG; i += 512) lds[i] = 0.0f;
-    if (tid < 32) sbias[tid] = bias[tid];
+    // slot layout: float4 c of lane l = accumulator registers 4c..4c+3 = channels (r&3) + 8c + 4(l>>5)
+    for (int i = tid; i < SLOT_FLOATS; i += 512) sbias[i] = bias[(i & 3) + 8 * (i >> 8) + 4 * ((i >> 7) & 1)];
 
     // trace element slot s of a lane inside a row group: element idx = lane + 64 s of the group's rows, i.e. group row
     // idx / 38, column idx % 38; its LDS offset inside a channel image is row0 * 38 + idx.
@@ -246,17 +247,16 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
         //   would otherwise be live across the epilogue and the trace rows (14 spilled VGPRs)
         f32x16 accA, accB;
         if (active) {
-            if (w == 0) {
+            // wave 0 starts both chains from the bias tile, wave w > 0 from the two tiles wave w-1 left: one code path
+            // (a branch here costs 32 v_mov per stage to merge the accumulator tuples)
+            const float *inA = (w == 0) ? sbias : slots + ((w - 1) * 2) * SLOT_FLOATS;
+            const float *inB = (w == 0) ? sbias : slots + ((w - 1) * 2 + 1) * SLOT_FLOATS;
+            const f32x4 *spa = (const f32x4 *)inA + lane, *spb = (const f32x4 *)inB + lane;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
-            } else {
-                const f32x4 *sp = (const f32x4 *)(slots + ((w - 1) * 2) * SLOT_FLOATS) + lane;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x4 va = sp[c * 64], vb = sp[SLOT_FLOATS / 4 + c * 64];
-                    accA[4 * c + 0] = va[0]; accA[4 * c + 1] = va[1]; accA[4 * c + 2] = va[2]; accA[4 * c + 3] = va[3];
-                    accB[4 * c + 0] = vb[0]; accB[4 * c + 1] = vb[1]; accB[4 * c + 2] = vb[2]; accB[4 * c + 3] = vb[3];
-                }
+            for (int c = 0; c < 4; ++c) {
+                f32x4 va = spa[c * 64], vb = spb[c * 64];
+                accA[4 * c + 0] = va[0]; accA[4 * c + 1] = va[1]; accA[4 * c + 2] = va[2]; accA[4 * c + 3] = va[3];
+                accB[4 * c + 0] = vb[0]; accB[4 * c + 1] = vb[1]; accB[4 * c + 2] = vb[2]; accB[4 * c + 3] = vb[3];
             }
         }
         // every slot read of this stage has completed before any wave writes its slots again
