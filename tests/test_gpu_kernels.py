@@ -96,9 +96,12 @@ def _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, target=24, rng=None):
             "i2o.bias": rng.uniform(-.0055, .0055, size=(target,)).astype(np.float32)}
 
 
-@pytest.mark.parametrize("wrp,T,B,zero_state", [(1.0, 24, 3, True), (0.0, 9, 2, True), (1.0, 10, 5, False)])
+@pytest.mark.parametrize("wrp,T,B,zero_state", [(1.0, 24, 3, True), (0.0, 9, 2, True), (1.0, 10, 5, False),
+                                                 (0.0, 26, 2, False), (1.0, 31, 2, False)])
 def test_sequence_c32_vs_oracle(dev, wrp, T, B, zero_state):
-    """k_lif_seq_c32 (MFMA systolic chain, state on chip) == C oracle stepping, bit for bit, incl. final state."""
+    """k_lif_seq_c32 (T < 24) and k_lif_seq_c32d (T >= 24; two tiles per wave and stage) — MFMA systolic chain, state
+    on chip — == C oracle stepping, bit for bit, incl. final state; both variants (refractory or not), zero and
+    non-zero initial state, T not a multiple of anything convenient."""
     from snn_modulation_classification_amd import ops
     from oracle import c_oracle as C
     rng = np.random.RandomState(11)
