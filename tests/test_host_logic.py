@@ -376,3 +376,24 @@ def test_radio_ml_2016_pickle_adapter(tmp_path):
     assert nc == 11 and X.shape == (11 * 5 * 5, 2, 1, 128)
     assert np.array_equal(X[7, :, 0, :], d[(mods[1], 4)][0]) and Y[7] == 1      # block 7 = class 1, snr index 2
     assert set(Y.tolist()) == set(range(11))
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The bench lines committed under profiles/ carry every field of the bench.py contract (metric, value, roofline of
+    the dominant kernel, cpu_baseline) and are internally consistent."""
+    import json
+    for name, kernel in (("r01_bench_b4096.json", "k_lif_seq_c32d"), ("r01_bench_plane128_b64.json", "k_lif_seq_c32t")):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (name, k)
+        assert d["unit"] == "IQ windows/s" and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
+        B = d["config"]["batch_per_gpu"]
+        assert abs(d["value"] - d["n_gpus"] * B / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+        r = d["roofline"]
+        assert r["kernel"] == kernel and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
+        assert abs(r["achieved"] - r["algorithmic_flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+        assert r["traffic"] is None or r["traffic"] > 1e9
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["vote_agreement_with_gpu"] == 1.0
