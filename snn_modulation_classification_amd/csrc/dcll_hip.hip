@@ -327,33 +327,40 @@ __global__ void k_bwd_dv(dcll_conv_desc d, int ch, int cw, int ph, int pw, const
 // chunks in a fixed order.  thread = conv output position (strided), per-thread tap accumulators, LDS tree at the end.
 constexpr int WG_MAXTAPS = 64;
 __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int cw, const float *__restrict__ gvf,
-                                                    const float *__restrict__ eps1, float *__restrict__ part, int B)
+                                                    const float *__restrict__ eps1, float *__restrict__ part, int B,
+                                                    int RB)
 {
     extern __shared__ float sm[];
     const int co = blockIdx.x / d.c_in, ci = blockIdx.x % d.c_in;
-    const int HP = d.h + 2 * d.pad_h, WP = d.w + 2 * d.pad_w, ntap = d.kh * d.kw, npos = ch * cw;
-    float *e = sm;                    // zero-padded eps1 plane of (b, ci)
-    float *red = sm + HP * WP;        // 4 x (WG_MAXTAPS + 1) wave totals
+    const int WP = d.w + 2 * d.pad_w, ntap = d.kh * d.kw;
+    float *e = sm;                                // zero-padded band of the eps1 plane of (b, ci): RB + kh - 1 rows
+    float *red = sm + (RB + d.kh - 1) * WP;       // 4 x (WG_MAXTAPS + 1) wave totals
     float acc[WG_MAXTAPS];
 #pragma unroll
     for (int t = 0; t < WG_MAXTAPS; ++t) acc[t] = 0.0f;
     float accb = 0.0f;
-    for (int i = threadIdx.x; i < HP * WP; i += 256) e[i] = 0.0f;
     const long rowlen = (long)d.c_in * ntap + 1;
     float *prow = part + ((long)blockIdx.y * d.c_out + co) * rowlen;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
-        __syncthreads();
         const float *ep = eps1 + ((long)b * d.c_in + ci) * d.h * d.w;
-        for (int i = threadIdx.x; i < d.h * d.w; i += 256) e[(i / d.w + d.pad_h) * WP + (i % d.w) + d.pad_w] = ep[i];
-        __syncthreads();
-        const float *gp = gvf + ((long)b * d.c_out + co) * npos;
-        for (int pos = threadIdx.x; pos < npos; pos += 256) {
-            const float g = gp[pos];
-            accb += g;
-            const float *eb = e + (pos / cw) * WP + (pos % cw);
+        const float *gp = gvf + ((long)b * d.c_out + co) * ch * cw;
+        for (int y0 = 0; y0 < ch; y0 += RB) {         // bands of RB output rows (the whole plane when it fits LDS)
+            const int rows = min(RB, ch - y0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < (rows + d.kh - 1) * WP; i += 256) {
+                const int iy = y0 + i / WP - d.pad_h, ix = i % WP - d.pad_w;
+                e[i] = ((unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w) ? ep[iy * d.w + ix] : 0.0f;
+            }
+            __syncthreads();
+            for (int pos = threadIdx.x; pos < rows * cw; pos += 256) {
+                const int yy = pos / cw, xx = pos % cw;
+                const float g = gp[(y0 + yy) * cw + xx];
+                accb += g;
+                const float *eb = e + yy * WP + xx;
 #pragma unroll
-            for (int t = 0; t < WG_MAXTAPS; ++t)
-                if (t < ntap) acc[t] = __builtin_fmaf(g, eb[(t / d.kw) * WP + (t % d.kw)], acc[t]);
+                for (int t = 0; t < WG_MAXTAPS; ++t)
+                    if (t < ntap) acc[t] = __builtin_fmaf(g, eb[(t / d.kw) * WP + (t % d.kw)], acc[t]);
+            }
         }
     }
     // reduce every tap (and the bias gradient) over the 256 threads: DPP tree inside each wave (fixed order), the
@@ -1778,12 +1785,16 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
         hipLaunchKernelGGL(k_bwd_wgrad_c32, dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1, part, B);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c32");
     } else {
-        const size_t lds = ((size_t)(d->h + 2 * d->pad_h) * (d->w + 2 * d->pad_w) + 4 * (WG_MAXTAPS + 1)) * sizeof(float);
-        if (lds > 60 * 1024) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: input plane too large for the LDS-resident weight-gradient kernel");
+        // the eps1 plane is staged in LDS in bands of RB output rows (+ kh - 1 halo rows), at most 48 KB
+        const int WP = d->w + 2 * d->pad_w;
+        int RB = (48 * 1024 / 4 - 4 * (WG_MAXTAPS + 1)) / WP - (d->kh - 1);
+        if (RB < 1) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: input rows too wide for the LDS-staged weight-gradient kernel");
+        if (RB > ch) RB = ch;
+        const size_t lds = ((size_t)(RB + d->kh - 1) * WP + 4 * (WG_MAXTAPS + 1)) * sizeof(float);
         if (nchunk > 64) nchunk = 64;
         if (nchunk > B) nchunk = B;
         hipLaunchKernelGGL(k_bwd_wgrad, dim3(d->c_out * d->c_in, (unsigned)nchunk), dim3(256), lds, st, *d, ch, cw, scratch,
-                           eps1, part, B);
+                           eps1, part, B, RB);
         HIP_CHECK_LAUNCH("k_bwd_wgrad");
     }
     hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);

@@ -466,6 +466,60 @@ def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
         np.testing.assert_allclose(dob.cpu().numpy(), layer.out_b.grad.numpy(), **tol(layer.out_b.grad))
 
 
+@pytest.mark.parametrize("cin,cout,out_layer", [(1, 8, False), (3, 4, True)])
+def test_backward_on_128x128_plane(dev, cin, cout, out_layer):
+    """dcll_conv_lif_backward on the argparse-default 128x128 plane (train.py:40-41): the weight-gradient kernel stages
+    the eps1 plane in LDS in row bands (two bands here), the output_ gradient runs over K = c_out*128*128 columns —
+    against torch autograd through the CPU oracle ops."""
+    from snn_modulation_classification_amd import ops
+    from oracle import torch_ref as R
+    rng = np.random.RandomState(17)
+    B, hw = 2, (128, 128)
+    Wn, bn, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout, gain=3.0)
+    sdn = _sd_from(Wn, bn, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    K = cout * hw[0] * hw[1]
+    if out_layer:
+        sdn["output_.weight"] = rng.uniform(-.002, .002, size=(24, K)).astype(np.float32)
+        sdn["output_.bias"] = rng.uniform(-.002, .002, size=(24,)).astype(np.float32)
+    sd = {k: torch.from_numpy(v) for k, v in sdn.items()}
+    x = torch.from_numpy((rng.uniform(size=(B, cin) + hw) < 0.2).astype(np.float32))
+    W = sd["i2h.weight"].clone().requires_grad_(True)
+    b = sd["i2h.bias"].clone().requires_grad_(True)
+    layer = R.RefConvLayer(dict(sd, **{"i2h.weight": W, "i2h.bias": b}), 3, 1, 1.0, 0.65, out_layer)
+    if out_layer:
+        layer.out_w = sd["output_.weight"].clone().requires_grad_(True)
+        layer.out_b = sd["output_.bias"].clone().requires_grad_(True)
+    layer.init_state(B, hw)
+    s_, pv_, v_, st = R.conv_lif_step(x, W, b, layer.alpha, layer.tau_m, layer.alphas, layer.tau_s, layer.state,
+                                      layer.alpharp, layer.wrp, 1, layer.padding)
+    flat = pv_.reshape(B, -1)
+    p_ = torch.nn.functional.linear(flat, sd["i2o.weight"], sd["i2o.bias"])
+    r_p = torch.from_numpy(rng.randn(*p_.shape).astype(np.float32))
+    loss = (p_ * r_p).sum()
+    r_o = None
+    if out_layer:
+        o_ = torch.nn.functional.linear(flat.detach(), layer.out_w, layer.out_b)
+        r_o = torch.from_numpy(rng.randn(*o_.shape).astype(np.float32))
+        loss = loss + (o_ * r_o).sum()
+    loss.backward()
+    t = {k: cu(v.numpy(), dev) for k, v in sd.items()}
+    d = ops.make_conv_desc(cin, cout, hw, 7, 3, 1, 24, out_layer, True, 1.0, 0.65)
+    eps0 = torch.zeros((B, cin) + hw, device=dev)
+    eps1 = torch.zeros_like(eps0)
+    arp = torch.zeros((B, cout) + hw, device=dev)
+    s, p, o, pv, v = ops.conv_lif_step(d, x.to(dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
+                                       t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1, arp,
+                                       t["i2o.weight"], t["i2o.bias"], t.get("output_.weight"), t.get("output_.bias"))
+    dW, db, doW, dob = ops.conv_lif_backward(d, eps1, v, pv, r_p.to(dev), None if r_o is None else r_o.to(dev),
+                                             None, None, t["i2o.weight"], want_out=out_layer)
+    tol = lambda ref: dict(rtol=2e-3, atol=5e-5 * float(ref.abs().max()) + 1e-12)
+    np.testing.assert_allclose(dW.cpu().numpy(), W.grad.numpy(), **tol(W.grad))
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), **tol(b.grad))
+    if out_layer:
+        np.testing.assert_allclose(doW.cpu().numpy(), layer.out_w.grad.numpy(), **tol(layer.out_w.grad))
+        np.testing.assert_allclose(dob.cpu().numpy(), layer.out_b.grad.numpy(), **tol(layer.out_b.grad))
+
+
 def test_edge_cases_empty_and_single(dev):
     """Empty batch / zero timesteps are no-ops, B = 1 and T = 1 work (the reference itself breaks at B = 1 in
     iq2spiketrain's squeeze), invalid windows are rejected with ValueError."""
