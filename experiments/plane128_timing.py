@@ -37,3 +37,20 @@ if len(sys.argv) > 2 and sys.argv[2] == "seq":
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         parts = {k: [round(a.elapsed_time(b), 2) for a, b in v] for k, v in prof.items()}
         print("fused, B=%d T=%d: %.1f ms -> %.1f windows/s  %s" % (B, Ts, dt * 1e3, B / dt, parts))
+
+# local-learning step on the 128x128 plane: python experiments/plane128_timing.py B learn
+if len(sys.argv) > 2 and sys.argv[2] == "learn":
+    torch.manual_seed(1); np.random.seed(1)
+    lnet = ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                       opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0}, learning_rates=[1e-9],
+                       burnin=2)
+    lnet.reset(True)
+    y = torch.zeros(B, 24, device='cuda'); y[torch.arange(B), torch.randint(0, 24, (B,))] = 1
+    lnet.reset()
+    for t in range(3):
+        lnet.learn(x[t], y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in range(3, T):
+        lnet.learn(x[t], y)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (T - 3)
+    print("learn, 128x128 plane, B=%d: %.1f ms per timestep -> %.2f windows/s at T=128" % (B, dt * 1e3, B / (dt * 128)))

@@ -394,22 +394,27 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
 // registers) over the 128 pixel pairs: A[co][pixel pair], B[pixel pair][column] = one ds_read at an immediate offset
 // from the column's lane base.  Partial sums go to part[workgroup][co][1568 + 1] (k_bwd_reduce adds them in order).
 constexpr int WG32_GLD = 257;
+// TILED = false: the 16x16 plane, one sample per job, image rows / channels share their zero padding (RF 19, CF 361).
+// TILED = true: planes with h % 16 == 0 and w % 16 == 0, one 16x16 tile of a sample per job; the tile's 22x22 eps1
+// region with its real halo (zero outside the plane) is staged per channel (RF 22, CF 484).
+template <int RF, int CF, bool TILED>
 __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__ gvf, const float *__restrict__ eps1,
-                                                        float *__restrict__ part, int B)
+                                                        float *__restrict__ part, int B, int H, int Wd)
 {
-    __shared__ __attribute__((aligned(16))) float lds[IMG_FLOATS + 32 * WG32_GLD];
-    float *img = lds, *gl = lds + IMG_FLOATS;
+    constexpr int IMG = TILED ? 32 * CF : IMG_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[IMG + 32 * WG32_GLD];
+    float *img = lds, *gl = lds + IMG;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = (w == 0) ? 7 : 6;
-    for (int i = tid; i < IMG_FLOATS; i += 512) img[i] = 0.0f;
+    for (int i = tid; i < IMG; i += 512) img[i] = 0.0f;
     int bbase[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
         const int n = (w + 8 * q) * 32 + j;                  // my column in tile q (n < 1568 for q < ntile)
         const int nn = n < 1568 ? n : 0;
         const int ci = nn / 49, tap = nn % 49;
-        bbase[q] = ci * CHF + (tap / 7) * ROWF + (tap % 7) + h;
+        bbase[q] = ci * CF + (tap / 7) * RF + (tap % 7) + h;
     }
     f32x16 acc[7];
 #pragma unroll
@@ -417,12 +422,30 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
     float bsum = 0.0f;                                        // wave w, lanes: co = 4w + (lane>>4), 16 pixels per pass
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int tpr = Wd >> 4, tps = (H >> 4) * tpr;            // 16x16 tiles per row / per sample
+    const long njob = TILED ? (long)B * tps : B;
+    const long HW = (long)H * Wd;
+    for (long job = blockIdx.x; job < njob; job += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < 32 * 256; i += 512) {
-            const int c = i >> 8, p = i & 255;
-            gl[c * WG32_GLD + p] = gvf[(long)b * 8192 + i];
-            img[c * CHF + ((p >> 4) + 3) * ROWF + (p & 15) + 3] = eps1[(long)b * 8192 + i];
+        if (TILED) {
+            const long b = job / tps;
+            const int tile = (int)(job % tps), y0 = (tile / tpr) * 16, x0 = (tile % tpr) * 16;
+            for (int i = tid; i < 32 * 256; i += 512) {
+                const int c = i >> 8, p = i & 255;
+                gl[c * WG32_GLD + p] = gvf[(b * 32 + c) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15)];
+            }
+            for (int i = tid; i < 32 * CF; i += 512) {
+                const int c = i / CF, r = (i % CF) / RF, x = i % RF;
+                const int gy = y0 + r - 3, gx = x0 + x - 3;
+                img[i] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd)
+                             ? eps1[(b * 32 + c) * HW + (long)gy * Wd + gx] : 0.0f;
+            }
+        } else {
+            for (int i = tid; i < 32 * 256; i += 512) {
+                const int c = i >> 8, p = i & 255;
+                gl[c * WG32_GLD + p] = gvf[job * 8192 + i];
+                img[c * CF + ((p >> 4) + 3) * RF + (p & 15) + 3] = eps1[job * 8192 + i];
+            }
         }
         __syncthreads();
         {   // bias gradient: co = 4w + lane/16, pixels lane%16 + 16*k
@@ -435,7 +458,7 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
         for (int pp = 0; pp < 128; ++pp) {
             const int p = 2 * pp;
             const float a = ga[p];
-            const int poff = (p >> 4) * ROWF + (p & 15);
+            const int poff = (p >> 4) * RF + (p & 15);
 #pragma unroll
             for (int q = 0; q < 7; ++q)
                 if (q < ntile) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
@@ -1777,13 +1800,20 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
     float *part = scratch + nconv;
     long nchunk = (scratch_floats - nconv) / per_chunk;
     if (nchunk < 1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: scratch too small (need B*c_out*ch*cw + k*(c_out*(c_in*kh*kw+1)), k >= 1)");
-    const bool c32 = d->c_in == 32 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 &&
-                     d->h == 16 && d->w == 16;
-    if (c32) {
+    const bool c32 = d->c_in == 32 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3;
+    if (c32 && d->h == 16 && d->w == 16) {
         if (nchunk > 256) nchunk = 256;
         if (nchunk > B) nchunk = B;
-        hipLaunchKernelGGL(k_bwd_wgrad_c32, dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1, part, B);
+        hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false>), dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1,
+                           part, B, 16, 16);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c32");
+    } else if (c32 && d->h % 16 == 0 && d->w % 16 == 0) {     // large planes: one 16x16 tile of a sample per job
+        const long njob = (long)B * (d->h / 16) * (d->w / 16);
+        if (nchunk > 256) nchunk = 256;
+        if (nchunk > njob) nchunk = njob;
+        hipLaunchKernelGGL((k_bwd_wgrad_c32<22, 484, true>), dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1,
+                           part, B, d->h, d->w);
+        HIP_CHECK_LAUNCH("k_bwd_wgrad_c32 (tiled)");
     } else {
         // the eps1 plane is staged in LDS in bands of RB output rows (+ kh - 1 halo rows), at most 48 KB
         const int WP = d->w + 2 * d->pad_w;

@@ -466,15 +466,17 @@ def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
         np.testing.assert_allclose(dob.cpu().numpy(), layer.out_b.grad.numpy(), **tol(layer.out_b.grad))
 
 
-@pytest.mark.parametrize("cin,cout,out_layer", [(1, 8, False), (3, 4, True)])
-def test_backward_on_128x128_plane(dev, cin, cout, out_layer):
-    """dcll_conv_lif_backward on the argparse-default 128x128 plane (train.py:40-41): the weight-gradient kernel stages
-    the eps1 plane in LDS in row bands (two bands here), the output_ gradient runs over K = c_out*128*128 columns —
-    against torch autograd through the CPU oracle ops."""
+@pytest.mark.parametrize("cin,cout,out_layer,hw", [(1, 8, False, (128, 128)), (3, 4, True, (128, 128)),
+                                                   (32, 32, False, (32, 48)), (32, 32, True, (128, 128))])
+def test_backward_on_large_planes(dev, cin, cout, out_layer, hw):
+    """dcll_conv_lif_backward on large planes incl. the argparse default 128x128 (train.py:40-41): the generic
+    weight-gradient kernel stages the eps1 plane in LDS in row bands (two bands at 128 rows), the 32 -> 32 layers use the
+    tiled MFMA kernel, the output_ gradient runs over K = c_out*h*w columns — against torch autograd through the CPU
+    oracle ops."""
     from snn_modulation_classification_amd import ops
     from oracle import torch_ref as R
     rng = np.random.RandomState(17)
-    B, hw = 2, (128, 128)
+    B = 2                       # 32 -> 32 layers: the MFMA weight-gradient kernel over 16x16 tiles with their real halo
     Wn, bn, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout, gain=3.0)
     sdn = _sd_from(Wn, bn, alpha, tau_m, alphas, tau_s, hw, rng=rng)
     K = cout * hw[0] * hw[1]
