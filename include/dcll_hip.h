@@ -171,6 +171,16 @@ int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out
                  int64_t rows, int32_t K, int32_t N, void *stream);
 
 /*
+ * The same readout for FEW rows of a LONG K (per-step calls on a large plane: rows = batch, K = c_out*128*128): K is
+ * split into slices of 4096 over the workgroups, the partial tiles go to caller-provided scratch and are added in slice
+ * order (deterministic).  Needs K >= 65536, K % 4096 == 0, N <= 64, 16-byte aligned pv / Wt;
+ * scratch_floats >= dcll_readout_splitk_scratch(rows, K, N) (0 = this shape is not supported, use dcll_readout).
+ */
+int64_t dcll_readout_splitk_scratch(int64_t rows, int32_t K, int32_t N);
+int dcll_readout_splitk(const float *pv, const float *Wt, const float *bias, float *out, float *scratch,
+                        int64_t scratch_floats, int64_t rows, int32_t K, int32_t N, void *stream);
+
+/*
  * Per-step argmax + vote (DCLLClassification.forward :724-728, get_predictions_by_vote :44-56):
  *   logits (T,B,N) -> clout (T,B) int32 (first maximum wins, like torch.argmax) and, if vote != NULL,
  *   vote (B) int32 = mode over t in [t_begin,T) of clout, ties broken by first occurrence in time.

@@ -56,6 +56,8 @@ SIGNATURES = {
     "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_I32, _I32, _P]),
     "dcll_conv_lif_sequence_iq": (_I32, [_DP, _P, _P, _P, _I32, _I32] + [_P] * 9 + [_I32, _I32, _P]),
     "dcll_readout": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "dcll_readout_splitk_scratch": (_I64, [_I64, _I32, _I32]),
+    "dcll_readout_splitk": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "dcll_argmax_vote": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "dcll_iq_encode": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "dcll_unpack_spikes": (_I32, [_P, _P, _I64, _P]),

@@ -634,10 +634,12 @@ __global__ __launch_bounds__(256) void k_readout_v4(const float *__restrict__ pv
 // only 64 workgroups, so here a workgroup takes 32 rows and its 4 waves split every 256-float K-chunk between them
 // (wave w: floats 64w..64w+63); the four partial tiles are combined in LDS in fixed order (deterministic).
 constexpr int RK_ROWS = 32, RK_KC = 256, RK_LD = 257;
+// kslice > 0 (dcll_readout_splitk): workgroup (x, y) handles only columns [y * kslice, (y+1) * kslice) of K and writes
+// its partial tile, without the bias, to out + y * rows * N; k_readout_sum adds the slices in order.
 template <int NT>
 __global__ __launch_bounds__(256) void k_readout_ks(const float *__restrict__ pv, const float *__restrict__ Wt,
                                                      const float *__restrict__ bias, float *__restrict__ out,
-                                                     long rows, int K, int N)
+                                                     long rows, int K, int N, int kslice)
 {
     __shared__ float sm[(RK_ROWS + NT * 32) * RK_LD];
     float *sA = sm, *sB = sm + RK_ROWS * RK_LD;
@@ -662,8 +664,10 @@ __global__ __launch_bounds__(256) void k_readout_ks(const float *__restrict__ pv
             rb[i] = nn < N ? *(const f32x4 *)(Wt + (long)nn * K + k0 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += RK_KC) {
+    const int kbeg = kslice > 0 ? blockIdx.y * kslice : 0, kend = kslice > 0 ? kbeg + kslice : K;
+    if (kslice > 0) { out += (long)blockIdx.y * rows * N; bias = nullptr; }
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += RK_KC) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(256) void k_readout_ks(const float *__restrict__ pv
 #pragma unroll
             for (int e = 0; e < 4; ++e) sB[(rsub + 4 * i) * RK_LD + kq + e] = rb[i][e];
         __syncthreads();
-        if (k0 + RK_KC < K) fetch(k0 + RK_KC);
+        if (k0 + RK_KC < kend) fetch(k0 + RK_KC);
         const float *a = sA + (lane & 31) * RK_LD + 64 * wave + (lane >> 5);
         const float *bb = sB + (lane & 31) * RK_LD + 64 * wave + (lane >> 5);
 #pragma unroll
@@ -1618,9 +1622,9 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
         // waves.  (K of the 16x16 plane, 8192, always takes k_readout_v4: its logits then do not depend on how a
         // run is split into launches.)
         if (N <= 32)
-            hipLaunchKernelGGL(k_readout_ks<1>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+            hipLaunchKernelGGL(k_readout_ks<1>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, 0);
         else
-            hipLaunchKernelGGL(k_readout_ks<2>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+            hipLaunchKernelGGL(k_readout_ks<2>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, 0);
     } else if (fast && N <= 32) {
         hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast) {
@@ -1639,6 +1643,43 @@ extern "C" int dcll_readout(const float *pv, const float *Wt, const float *bias,
     if (rows == 0) return DCLL_OK;
     if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1) return fail(DCLL_ERR_INVALID, "dcll_readout: bad argument");
     return launch_readout(pv, Wt, bias, out, rows, K, N, (hipStream_t)stream);
+}
+
+__global__ void k_readout_sum(const float *__restrict__ part, const float *__restrict__ bias, float *__restrict__ out,
+                              long n_out, int N, int nslice)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    float tot = bias ? bias[i % N] : 0.0f;
+    for (int sl = 0; sl < nslice; ++sl) tot += part[(long)sl * n_out + i];
+    out[i] = tot;
+}
+
+extern "C" int64_t dcll_readout_splitk_scratch(int64_t rows, int32_t K, int32_t N)
+{
+    if (rows < 1 || N < 1 || N > 64 || K < 65536 || K % 4096 != 0) return 0;
+    return (int64_t)(K / 4096) * rows * N;
+}
+
+extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float *bias, float *out, float *scratch,
+                                   int64_t scratch_floats, int64_t rows, int32_t K, int32_t N, void *stream)
+{
+    if (rows == 0 || N == 0) return DCLL_OK;
+    if (!pv || !Wt || !out || !scratch || rows < 0 || K < 1 || N < 1)
+        return fail(DCLL_ERR_INVALID, "dcll_readout_splitk: bad argument");
+    const int64_t need = dcll_readout_splitk_scratch(rows, K, N);
+    if (need == 0 || ((((uintptr_t)pv | (uintptr_t)Wt)) & 15) != 0)
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_readout_splitk: needs K >= 65536, K % 4096 == 0, N <= 64, 16-byte aligned operands");
+    if (scratch_floats < need) return fail(DCLL_ERR_INVALID, "dcll_readout_splitk: scratch too small (dcll_readout_splitk_scratch)");
+    hipStream_t st = (hipStream_t)stream;
+    const int nslice = K / 4096;
+    dim3 grid(nblk(rows, RK_ROWS), nslice);
+    if (N <= 32) hipLaunchKernelGGL(k_readout_ks<1>, grid, dim3(256), 0, st, pv, Wt, bias, scratch, rows, K, N, 4096);
+    else hipLaunchKernelGGL(k_readout_ks<2>, grid, dim3(256), 0, st, pv, Wt, bias, scratch, rows, K, N, 4096);
+    HIP_CHECK_LAUNCH("k_readout_ks (split K)");
+    hipLaunchKernelGGL(k_readout_sum, dim3(nblk(rows * N, 256)), dim3(256), 0, st, scratch, bias, out, rows * N, N, nslice);
+    HIP_CHECK_LAUNCH("k_readout_sum");
+    return DCLL_OK;
 }
 
 extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,

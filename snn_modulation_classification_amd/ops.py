@@ -91,6 +91,16 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     o = torch.empty((B, desc.target), device=dev, dtype=torch.float32) if desc.output_layer else None
     pooled = not (desc.pool_h == 1 and desc.pool_w == 1)
     scratch = torch.empty((2, B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if pooled else None
+    if K_ro >= 65536 and not desc.output_layer and i2o_W is not None:
+        # a few rows of a very long K (large plane): the readout goes through readout() below, which can split K
+        # over the chip (dcll_readout_splitk) — inside the step call it would run on rows/4 x N/4 workgroups
+        rc = _lib.get().dcll_conv_lif_step(
+            ctypes.byref(desc), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
+            ptr(eps0), ptr(eps1), ptr(arp), None, None, None, None,
+            ptr(s), None, None, ptr(pv), ptr(v), ptr(scratch), B, stream_ptr())
+        check(rc, "dcll_conv_lif_step")
+        readout(pv.reshape(B, -1), i2o_W, i2o_b, out=p)
+        return s, p, o, pv, v
     rc = _lib.get().dcll_conv_lif_step(
         ctypes.byref(desc), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
         ptr(eps0), ptr(eps1), ptr(arp), ptr(i2o_W), ptr(i2o_b), ptr(out_W), ptr(out_b),
@@ -109,8 +119,15 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
     K = desc.c_out * ph * pw
     d_outW = torch.empty((desc.target, K), device=dev, dtype=torch.float32) if want_out else None
     d_outb = torch.empty((desc.target,), device=dev, dtype=torch.float32) if want_out else None
-    nchunk = min(B, 256)
-    n_scratch = B * desc.c_out * ch * cw + nchunk * desc.c_out * (desc.c_in * desc.kh * desc.kw + 1)
+    # partial-sum rows for the weight gradient: one per workgroup, up to 256 (a sample of a large plane is many 16x16
+    # tile jobs, so small batches still fill the chip); the same area then holds the batch chunks of the output_ gradient
+    jobs = B * max(1, (desc.h // 16) * (desc.w // 16))
+    per_chunk = desc.c_out * (desc.c_in * desc.kh * desc.kw + 1)
+    nchunk = min(jobs, 256)
+    part = nchunk * per_chunk
+    if want_out:
+        part = max(part, min(B, 8) * desc.target * (K + 1))
+    n_scratch = B * desc.c_out * ch * cw + part
     scratch = torch.empty((n_scratch,), device=dev, dtype=torch.float32)
     c = lambda t: None if t is None else _f32(t, "grad").contiguous()
     rc = _lib.get().dcll_conv_lif_backward(
@@ -242,7 +259,15 @@ def readout(pv2d, Wt, bias, out=None):
     if out is None:
         out = torch.empty((rows, N), device=pv2d.device, dtype=torch.float32)
     _expect(out, "out", torch.float32, (rows, N))
-    check(_lib.get().dcll_readout(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), rows, K, N, stream_ptr()), "dcll_readout")
+    lib = _lib.get()
+    need = lib.dcll_readout_splitk_scratch(rows, K, N) if rows <= 2048 else 0
+    if need > 0 and pv2d.data_ptr() % 16 == 0 and Wt.data_ptr() % 16 == 0:
+        # few rows of a long K (per-step calls on a large plane): K split over the workgroups, partials in scratch
+        scratch = torch.empty((need,), device=pv2d.device, dtype=torch.float32)
+        check(lib.dcll_readout_splitk(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), ptr(scratch), need, rows, K, N,
+                                      stream_ptr()), "dcll_readout_splitk")
+        return out
+    check(lib.dcll_readout(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), rows, K, N, stream_ptr()), "dcll_readout")
     return out
 
 

@@ -408,6 +408,24 @@ def test_readout_gemm_long_rows(dev, rows, K, N):
     np.testing.assert_allclose(a1.cpu().numpy(), ref, atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("rows,K,N", [(64, 524288, 24), (5, 65536, 48), (700, 131072, 10)])
+def test_readout_few_rows_long_k(dev, rows, K, N):
+    """dcll_readout_splitk (through ops.readout): few rows of a very long K — the per-step readout on a 128x128 plane —
+    K split into 4096-column slices over the chip, partial tiles summed in slice order (run-to-run identical)."""
+    from snn_modulation_classification_amd import ops, _lib
+    assert _lib.get().dcll_readout_splitk_scratch(rows, K, N) == (K // 4096) * rows * N
+    assert _lib.get().dcll_readout_splitk_scratch(rows, 8192, N) == 0
+    rng = np.random.RandomState(4)
+    pv = rng.uniform(0, 1, size=(rows, K)).astype(np.float32)
+    Wt = rng.uniform(-.002, .002, size=(N, K)).astype(np.float32)
+    b = rng.uniform(-.01, .01, size=(N,)).astype(np.float32)
+    a1 = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev))
+    a2 = ops.readout(cu(pv, dev), cu(Wt, dev), cu(b, dev))
+    assert torch.equal(a1, a2)
+    ref = (pv.astype(np.float64) @ Wt.astype(np.float64).T + b).astype(np.float32)
+    np.testing.assert_allclose(a1.cpu().numpy(), ref, atol=1e-4, rtol=0)
+
+
 @pytest.mark.parametrize("case", ["mnist_l0", "mnist_l2", "pool3", "scalar_tau", "radio_l2_out", "ref_tuple"])
 def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
     """dcll_conv_lif_backward (all four incoming gradients, pooling incl. ties routing, output layer) against torch
