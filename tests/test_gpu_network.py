@@ -333,6 +333,27 @@ def test_entry_point_train_then_restore(tmp_path):
     assert np.asarray(accs).shape == (13, 3)
 
 
+def test_entry_point_train_on_radio_ml_files(tmp_path):
+    """train.py on RadioML files through the reference's loader protocol (train.py:134-141, :196-207) — here a small
+    RadioML-2016.10a-style pickle: fixed test batches, shuffled training batches, learning + evaluation + checkpoint."""
+    import pickle
+    import train
+    mods = ['8PSK', 'AM-DSB', 'AM-SSB', 'BPSK', 'CPFSK', 'GFSK', 'PAM4', 'QAM16', 'QAM64', 'QPSK', 'WBFM']
+    rng = np.random.RandomState(0)
+    d = {(m, s): (0.4 * rng.randn(10, 2, 128)).astype(np.float32) for m in mods for s in range(0, 10, 2)}
+    (tmp_path / 'data').mkdir()
+    with open(tmp_path / 'data' / 'RML2016.10a_dict.pkl', 'wb') as f:
+        pickle.dump(d, f)
+    out_dir = train.main(['--radio_ml_data_dir', str(tmp_path / 'data'), '--min_snr', '0', '--max_snr', '8',
+                          '--per_h5_frac', '1.0', '--train_frac', '0.5', '--I_resolution', '16', '--Q_resolution', '16',
+                          '--arp', '1.0', '--burnin', '4', '--batch_size', '16', '--batch_size_test', '16',
+                          '--n_test_samples', '32', '--n_steps', '2', '--n_iters', '12', '--n_iters_test', '12',
+                          '--n_test_interval', '1', '--output', str(tmp_path / 'results'), '--learning_rates', '1e-7'])
+    acc = np.load(os.path.join(out_dir, 'acc_test.npy'))
+    assert acc.shape == (2, 2, 3) and np.isfinite(acc).all()
+    assert os.path.isfile(os.path.join(out_dir, 'parameters_1.pth'))
+
+
 def test_fused_iq_encoder_equals_cells_path():
     """dcll_conv_lif_sequence_iq (quantisation fused into the first layer's kernel) == encode on host + cells path."""
     from snn_modulation_classification_amd.data.utils import IQEncoder, iq2cells

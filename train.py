@@ -112,13 +112,23 @@ def main(argv=None):
         with open(os.path.join(out_dir, 'args.pkl'), 'wb') as f:
             pickle.dump(vars(args), f)
 
-    if not args.synthetic:
-        sys.exit('train.py of this build trains on the synthetic generator (--synthetic N); the RadioML readers '
-                 '(data/load_radio_ml.py) are wired into test_radio_ml.py.')
     from snn_modulation_classification_amd.data.utils import IQEncoder, iq2spiketrain
     n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
-    test_batches = evaluation.synthetic_modulation_batches(args.synthetic, args.batch_size_test, args.max_snr,
-                                                           max(args.n_iters_test, 128), args.seed)[:n_test]
+    gen_train = train_data = None
+    if args.synthetic:
+        test_batches = evaluation.synthetic_modulation_batches(args.synthetic, args.batch_size_test, args.max_snr,
+                                                               max(args.n_iters_test, 128), args.seed)[:n_test]
+    else:
+        # the reference's data path (train.py:134-141, :196-207): per-(class, SNR) RadioML blocks, interleaved;
+        # n_test fixed test batches drawn once, training batches from a shuffling loader that restarts when exhausted
+        from snn_modulation_classification_amd.data.load_radio_ml import get_radio_ml_loader
+        kw = dict(data_dir=args.radio_ml_data_dir, min_snr=args.min_snr, max_snr=args.max_snr,
+                  per_h5_frac=args.per_h5_frac, train_frac=args.train_frac)
+        train_data = get_radio_ml_loader(args.batch_size, train=True, **kw)
+        gen_train = iter(train_data)
+        gen_test = iter(get_radio_ml_loader(args.batch_size_test, train=False, **kw))
+        test_batches = [next(gen_test) for _ in range(n_test)]
+        n_test = len(test_batches)
     use_sequence = net.sequence_supported()
     encoder = IQEncoder(args.I_resolution, args.Q_resolution, args.I_bounds, args.Q_bounds,
                         device=pytorch_libdcll.device) if use_sequence else None
@@ -146,9 +156,19 @@ def main(argv=None):
                     sl.optimizer.param_groups[-1]['lr'] /= 2
                 net.dcll_slices[-1].optimizer2.param_groups[-1]['lr'] /= 2
                 print('Adjusting learning rates')
-            snr = int(np.random.randint(args.min_snr // 2, args.max_snr // 2 + 1) * 2)
-            samples, labels = evaluation.synthetic_modulation_batches(
-                args.batch_size, args.batch_size, snr, max(args.n_iters, 128), args.seed + 7919 * (step + 1))[0]
+            if gen_train is None:
+                snr = int(np.random.randint(args.min_snr // 2, args.max_snr // 2 + 1) * 2)
+                samples, labels = evaluation.synthetic_modulation_batches(
+                    args.batch_size, args.batch_size, snr, max(args.n_iters, 128), args.seed + 7919 * (step + 1))[0]
+            else:
+                try:
+                    samples, labels = next(gen_train)
+                except StopIteration:                         # reference :231-235
+                    gen_train = iter(train_data)
+                    samples, labels = next(gen_train)
+                if samples.shape[0] != args.batch_size:       # ragged last batch: the state is sized for batch_size
+                    gen_train = iter(train_data)
+                    samples, labels = next(gen_train)
             spikes, targets = iq2spiketrain(samples, to_one_hot(labels, target_size), **st_kw)
             input_spikes = torch.Tensor(spikes).to(pytorch_libdcll.device)
             labels_spikes = torch.as_tensor(np.asarray(targets), dtype=torch.float32).to(pytorch_libdcll.device)
