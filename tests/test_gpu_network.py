@@ -354,6 +354,20 @@ def test_entry_point_train_on_radio_ml_files(tmp_path):
     assert os.path.isfile(os.path.join(out_dir, 'parameters_1.pth'))
 
 
+def test_entry_point_train_mnist_config1(tmp_path):
+    """BASELINE config 1 through the CLI: train.py --data MNIST with mnist_conv.yaml (28x28, 10 classes, arp 0,
+    image2spiketrain), here on synthetic images: learning steps, periodic per-step test, checkpoint."""
+    import train
+    out_dir = train.main(['--data', 'MNIST', '--network_spec', os.path.join(PKG, 'networks', 'mnist_conv.yaml'),
+                          '--synthetic', '16', '--batch_size', '8', '--batch_size_test', '8', '--n_test_samples', '8',
+                          '--n_steps', '2', '--n_iters', '10', '--n_iters_test', '10', '--burnin', '4',
+                          '--n_test_interval', '1', '--output', str(tmp_path / 'results'), '--learning_rates', '1e-7'])
+    acc = np.load(os.path.join(out_dir, 'acc_test.npy'))
+    assert acc.shape == (2, 1, 3) and np.isfinite(acc).all()
+    sd = torch.load(os.path.join(out_dir, 'parameters_1.pth'))
+    assert sd['dcll_slices.0.dclllayer.i2h.weight'].shape == (16, 1, 7, 7)
+
+
 def test_fused_iq_encoder_equals_cells_path():
     """dcll_conv_lif_sequence_iq (quantisation fused into the first layer's kernel) == encode on host + cells path."""
     from snn_modulation_classification_amd.data.utils import IQEncoder, iq2cells

@@ -397,3 +397,26 @@ def test_committed_bench_lines_follow_the_contract():
         assert r["traffic"] is None or r["traffic"] > 1e9
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["vote_agreement_with_gpu"] == 1.0
+
+
+def test_mnist_idx_reader(tmp_path):
+    """data/load_mnist.py: IDX files (plain or .gz, flat or torchvision's MNIST/raw layout) -> (28,28) float32 in [0,1]
+    + int64 labels, with the reference loader's attributes (data/load_mnist.py:5-23)."""
+    import gzip, struct
+    from snn_modulation_classification_amd.data.load_mnist import get_mnist_loader
+    rng = np.random.RandomState(0)
+    raw = tmp_path / "MNIST" / "raw"
+    raw.mkdir(parents=True)
+    imgs = rng.randint(0, 256, size=(20, 28, 28)).astype(np.uint8)
+    labs = rng.randint(0, 10, size=(20,)).astype(np.uint8)
+    with gzip.open(raw / "t10k-images-idx3-ubyte.gz", "wb") as f:
+        f.write(struct.pack(">IIII", 0x0803, 20, 28, 28) + imgs.tobytes())
+    with open(raw / "t10k-labels-idx1-ubyte", "wb") as f:
+        f.write(struct.pack(">II", 0x0801, 20) + labs.tobytes())
+    loader = get_mnist_loader(8, train=False, data_dir=str(tmp_path))
+    assert loader.short_name == "MNIST" and loader.name == "MNIST_0" and loader.taskid == 0
+    xb, yb = next(iter(loader))
+    assert xb.shape == (8, 28, 28) and xb.dtype == torch.float32 and yb.dtype == torch.int64
+    assert np.array_equal(xb.numpy(), imgs[:8].astype(np.float32) / 255.0) and np.array_equal(yb.numpy(), labs[:8])
+    with pytest.raises(FileNotFoundError):
+        get_mnist_loader(8, train=True, data_dir=str(tmp_path))

@@ -30,6 +30,7 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser(description='DCLL')
     p.add_argument('--data', type=str, default='RadioML', choices=['MNIST', 'RadioML'], help='which data to use')
     p.add_argument('--radio_ml_data_dir', type=str, default='2018.01', help='folder with the RadioML HDF5 file(s)')
+    p.add_argument('--mnist_data_dir', type=str, default='./data', help='folder with the MNIST IDX files (--data MNIST)')
     p.add_argument('--min_snr', type=int, default=6, metavar='N', help='minimum SNR (inclusive)')
     p.add_argument('--max_snr', type=int, default=30, metavar='N', help='maximum SNR (inclusive)')
     p.add_argument('--per_h5_frac', type=float, default=0.5, metavar='N', help='fraction of each HDF5 file to use')
@@ -76,8 +77,8 @@ def main(argv=None):
     args = parse_args(argv)
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
-    if args.data != 'RadioML':
-        sys.exit('MNIST needs torchvision + a download (absent here); the MNIST geometry is covered by the tests.')
+    if args.data == 'MNIST':
+        return main_mnist(args)
     if args.just_ref:
         sys.exit('ReferenceConvNetwork (plain CNN baseline) is outside the DCLL hot path and not part of this build.')
     stamp = datetime.datetime.now().strftime('%b%d_%H-%M-%S')
@@ -198,6 +199,93 @@ def main(argv=None):
         print('-' * 80)
         print('Saved network parameters to `%s`.' % save_path)
         print('-' * 80)
+    return out_dir
+
+
+def main_mnist(args):
+    """--data MNIST (reference train.py:118-131): 28x28 images as frozen Poisson spike trains (image2spiketrain,
+    gain 100), 10 classes, any conv spec that fits 28x28 (networks/mnist_conv.yaml), per-step protocol for learning
+    and for the periodic test.  Images from the IDX files under --mnist_data_dir, or `--synthetic N` random images."""
+    from snn_modulation_classification_amd.data.utils import image2spiketrain
+    if args.just_ref:
+        sys.exit('ReferenceConvNetwork (plain CNN baseline) is outside the DCLL hot path and not part of this build.')
+    stamp = datetime.datetime.now().strftime('%b%d_%H-%M-%S')
+    out_dir = os.path.join(args.output, args.data, stamp)
+    os.makedirs(out_dir)
+    print('out dir: {}'.format(out_dir))
+    im_dims, target_size = (1, 28, 28), 10
+    opt = getattr(torch.optim, args.optim_type)
+    opt_param = {'betas': [0.0, args.beta], 'weight_decay': 10.0}
+    loss = getattr(torch.nn, args.loss_type)
+    convs = load_network_spec(args.network_spec)
+    net = ConvNetwork(args, im_dims, args.batch_size, convs, target_size, act=torch.nn.Sigmoid(), loss=loss, opt=opt,
+                      opt_param=opt_param, learning_rates=args.learning_rates, burnin=args.burnin)
+    if args.restore_path and os.path.isfile(args.restore_path):
+        net.load_state_dict(torch.load(args.restore_path))
+        print('Loaded the SNN model from `%s`.' % args.restore_path)
+    net = net.to(pytorch_libdcll.device)
+    net.reset(True)
+    n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
+    if args.synthetic:
+        g = torch.Generator().manual_seed(args.seed)
+        def batches(n, bs):
+            return [(torch.rand(bs, 28, 28, generator=g), torch.randint(0, 10, (bs,), generator=g)) for _ in range(n)]
+        test_batches = batches(n_test, args.batch_size_test)
+        train_data = batches(max(1, args.synthetic // args.batch_size), args.batch_size)
+    else:
+        from snn_modulation_classification_amd.data.load_mnist import get_mnist_loader
+        train_data = get_mnist_loader(args.batch_size, train=True, data_dir=args.mnist_data_dir)
+        gen_test = iter(get_mnist_loader(args.batch_size_test, train=False, data_dir=args.mnist_data_dir))
+        test_batches = [next(gen_test) for _ in range(n_test)]
+    gen_train = iter(train_data)
+    st_train = dict(input_shape=im_dims, gain=100, min_duration=args.n_iters - 1, max_duration=args.n_iters)
+    st_test = dict(input_shape=im_dims, gain=100, min_duration=args.n_iters_test - 1, max_duration=args.n_iters_test)
+    dev = pytorch_libdcll.device
+
+    def spikes_of(samples, labels, kw):
+        sp, tg = image2spiketrain(samples.numpy(), to_one_hot(labels, target_size), **kw)
+        return (torch.Tensor(sp).to(dev), torch.as_tensor(np.asarray(tg), dtype=torch.float32).to(dev))
+
+    n_tests_total = int(np.ceil(float(args.n_steps) / args.n_test_interval))
+    acc_test = np.empty([n_tests_total, n_test, len(net.dcll_slices)])
+    for step in range(args.n_steps):
+        if ((step + 1) % 1000) == 0:
+            for sl in net.dcll_slices:
+                sl.optimizer.param_groups[-1]['lr'] /= 2
+            net.dcll_slices[-1].optimizer2.param_groups[-1]['lr'] /= 2
+            print('Adjusting learning rates')
+        try:
+            samples, labels = next(gen_train)
+        except StopIteration:
+            gen_train = iter(train_data)
+            samples, labels = next(gen_train)
+        if samples.shape[0] != args.batch_size:
+            gen_train = iter(train_data)
+            samples, labels = next(gen_train)
+        x, y = spikes_of(samples, labels, st_train)
+        net.batch_size = args.batch_size
+        net.reset()
+        net.train()
+        for t in range(args.n_iters):
+            net.learn(x=x[t], labels=y[t])
+        print('[TRAIN] Step {} \t Accuracy {}'.format(str(step).zfill(5), net.accuracy(y)))
+        if (step % args.n_test_interval) == 0:
+            net.batch_size = args.batch_size_test
+            for i, (ts, tl) in enumerate(test_batches):
+                tx, ty = spikes_of(ts, tl, st_test)
+                net.reset()
+                net.eval()
+                for t in range(args.n_iters_test):
+                    net.test(x=tx[t])
+                acc_test[step // args.n_test_interval, i, :] = net.accuracy(ty)
+            print('[TEST]  Step {} \t Accuracy {} \t Ref N/A'.format(
+                str(step).zfill(5), np.mean(acc_test[step // args.n_test_interval], axis=0)))
+            if not args.no_save:
+                np.save(os.path.join(out_dir, 'acc_test.npy'), acc_test)
+                save_path = os.path.join(out_dir, 'parameters_{}.pth'.format(step))
+                torch.save(net.cpu().state_dict(), save_path)
+                net.to(dev)
+                print('Saved network parameters to `%s`.' % save_path)
     return out_dir
 
 
