@@ -203,6 +203,51 @@ def test_tiled_sequence_path_reproduces_reference_run_32x32(golden):
     assert np.array_equal(net2.confusion_matrix(y), g["confusion"])
 
 
+def test_config5_int8_weights_and_packed_spikes():
+    """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code => parity unpinned):
+    radio_ml_conv_ref.yaml with per-channel int8 conv weights and 1-bit packed inter-layer spikes.  What can be pinned:
+    the HIP path on the dequantised weights == the C oracle on the same weights, bit for bit, and routing the spikes
+    through the packed format changes nothing."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from snn_modulation_classification_amd import ops, quant
+    from oracle import c_oracle as C
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv_ref.yaml"))
+    torch.manual_seed(2)
+    np.random.seed(2)
+    B, H, W = 2, 16, 128
+    net = ConvNetwork(_args(arp=1.0), (1, H, W), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=2)
+    net.reset(True)
+    before = [s.dclllayer.i2h.weight.detach().clone() for s in net.dcll_slices]
+    qs = quant.apply_int8_weights(net)
+    for (q, scale), w0, s in zip(qs, before, net.dcll_slices):
+        w1 = s.dclllayer.i2h.weight.detach()
+        assert q.dtype == torch.int8 and int(q.abs().max()) == 127
+        assert torch.equal(w1, quant.dequantize(q, scale))
+        assert float((w1 - w0).abs().max()) <= float(scale.max()) * 0.5 * (1 + 1e-6)
+    sds = [{k: v.detach().cpu().numpy() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
+    orc = C.OracleConvNetwork(sds, convs, (H, W), 1.0)
+    rng = np.random.RandomState(0)
+    net.reset()
+    for t in range(4):
+        x = (rng.uniform(size=(B, 1, H, W)) < 0.05).astype(np.float32)
+        outs = orc.step(x)
+        cur = torch.from_numpy(x).cuda()
+        for i, s in enumerate(net.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            if outs[i]["v"] is not None:
+                assert np.array_equal(v.cpu().numpy().view(np.uint32), outs[i]["v"].view(np.uint32)), (t, i)
+            np.testing.assert_allclose(p.cpu().numpy(), outs[i]["p"], atol=LOGIT_TOL, rtol=0)
+            if i < 6:
+                assert np.array_equal(o.cpu().numpy(), outs[i]["s"]), (t, i)
+                n = o[0].numel()
+                if n % 32 == 0:         # 1-bit transport between the layers: pack -> unpack is the identity
+                    packed = ops.pack_spikes(o.reshape(B, -1))
+                    assert packed.dtype == torch.int32 and packed.shape == (B, n // 32)
+                    o = ops.unpack_spikes(packed).reshape(o.shape)
+            cur = o
+
+
 def test_mnist_config1_per_step(golden):
     """BASELINE config 1 geometry on the GPU per-step path (28x28, pool 2/1/2, no refractory) vs the C oracle
     (bit-exact spikes) and the reference (logits)."""
