@@ -186,7 +186,8 @@ def main():
     # dominant kernel: HIP-event time of every k_lif_seq_c32d launch of the timed region (same stream as the launch)
     c32_ms = [s.elapsed_time(e) for s, e in prof.get("lif_c32", [])]
     avg_c32_s = float(np.mean(c32_ms)) / 1e3 if c32_ms else float("nan")
-    flop_per_launch = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T_STEPS * B
+    # two 32->32 layers per step; a batch above the pv budget runs in chunks (more, smaller launches)
+    flop_per_launch = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T_STEPS * B * 2 * a.steps / max(1, len(c32_ms))
     achieved = flop_per_launch / avg_c32_s / 1e12
     # HBM bytes of the dominant kernel: PMC counters cannot be read from inside this process; the committed summary of
     # the separate `rocprofv3 --pmc` passes of this same command (profiles/r01_pmc_b4096.json) is used when the batch
