@@ -1682,6 +1682,110 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
     return DCLL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_lif_step_c32 — ONE timestep of a 32 -> 32 channel 7x7 layer on the 16x16 plane (the per-step drop-in and the
+// forward of a local-learning step), one sample per 512-thread workgroup, state through HBM.
+//
+// The sequence kernels hand a tile's accumulator from wave to wave; for a single step that systolic pipeline would
+// spend 9 of its 17 stages filling and draining (k_lif_seq_c32 at T = 1: 174 us at B = 512, 48 % of the MFMA time).
+// Here every wave keeps ONE pixel tile (image rows 2w, 2w+1) and runs the whole K = 1568 chain itself, in the pinned
+// order; the weights stream through LDS in 16 chunks of one input-channel pair (49 taps x 64 lanes, double-buffered,
+// next chunk fetched into registers during the MFMAs of this one).  Input is the dense fp32 map x (any values, not
+// only {0,1}), outputs are the dense s / pv / v maps of dcll_conv_lif_step: no packing, no separate trace kernel.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int STEP_WCH = 49 * 64;       // floats per weight chunk: A fragments of one channel pair
+template <bool REFRACTORY>
+__global__ __launch_bounds__(512) void k_lif_step_c32(const float *__restrict__ x, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, const float *__restrict__ alpha,
+                                                       const float *__restrict__ tau_m, const float *__restrict__ alphas,
+                                                       const float *__restrict__ tau_s, int tau_is_tensor,
+                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
+                                                       float *__restrict__ arp_g, float *__restrict__ out_s,
+                                                       float *__restrict__ out_pv, float *__restrict__ out_v,
+                                                       float alpharp, float wrp)
+{
+    __shared__ __attribute__((aligned(16))) float lds[IMG_FLOATS + 2 * STEP_WCH + 32];
+    float *img = lds, *wch = lds + IMG_FLOATS, *sbias = wch + 2 * STEP_WCH;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // my pixel tile: image rows 2w, 2w+1
+    const long b = blockIdx.x;
+
+    for (int i = tid; i < IMG_FLOATS; i += 512) img[i] = 0.0f;
+    if (tid < 32) sbias[tid] = bias[tid];
+    // weight chunk cp as A fragments: wch[tap*64 + hh*32 + co] = W[co][2cp+hh][tap]; in global memory the 98 floats of
+    // (co, channel pair cp) are contiguous.  Thread t fetches elements t, t+512, ... of the 32 x 98 block.
+    float wreg[7];
+    auto fetch_w = [&](int cp) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int idx = tid + 512 * i;
+            wreg[i] = idx < 32 * 98 ? W[(long)(idx / 98) * 1568 + cp * 98 + idx % 98] : 0.0f;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int idx = tid + 512 * i;
+            if (idx < 32 * 98) {
+                const int co = idx / 98, r = idx % 98;
+                wch[buf * STEP_WCH + (r % 49) * 64 + (r / 49) * 32 + co] = wreg[i];
+            }
+        }
+    };
+    fetch_w(0);
+    __syncthreads();        // image zeroed
+    // traces of this step (dcll/pytorch_libdcll.py:493-494): 16 elements per thread, state updated in HBM, eps1 -> image
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 512 * i, c = e >> 8, pix = e & 255;
+        const long gidx = b * 8192 + e;
+        const int ti = tau_is_tensor ? e : 0;
+        float e0 = eps0_g[gidx], e1 = eps1_g[gidx];
+        trace_update(x[gidx], alpha[ti], tau_m[ti], alphas[ti], tau_s[ti], e0, e1);
+        eps0_g[gidx] = e0;
+        eps1_g[gidx] = e1;
+        img[c * CHF + ((pix >> 4) + 3) * ROWF + (pix & 15) + 3] = e1;
+    }
+    store_w(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    __syncthreads();        // image, bias and chunk 0 in place
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+    const int bbase = h * CHF + ((j >> 4) + 2 * w) * ROWF + (j & 15);
+    for (int cp = 0; cp < 16; ++cp) {
+        if (cp + 1 < 16) fetch_w(cp + 1);                  // lands during the MFMAs below
+        const float *wa = wch + (cp & 1) * STEP_WCH + lane;
+        const float *ib = img + bbase + cp * 2 * CHF;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(ky * 7 + kx) * 64], ib[ky * ROWF + kx], acc, 0, 0, 0);
+        if (cp + 1 < 16) store_w((cp + 1) & 1);            // the other buffer: nobody reads it in this iteration
+        __syncthreads();
+    }
+    // epilogue of my tile: channel (r&3) + 8(r>>2) + 4h, pixel 32w + j
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long o = (b * 32 + co) * 256 + 32 * w + j;
+        float v = acc[r];
+        bool s;
+        if (REFRACTORY) {
+            float ar = arp_g[o];
+            v = refractory(acc[r], ar, alpharp, wrp, s);
+            arp_g[o] = ar;
+        } else {
+            s = v > 0.0f;
+        }
+        out_s[o] = s ? 1.0f : 0.0f;
+        out_pv[o] = sigmoidf_dev(v);
+        if (out_v) out_v[o] = v;
+    }
+}
+
 extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
                                   const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
                                   float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
@@ -1701,6 +1805,28 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     conv_shape(d, &ch, &cw, &ph, &pw);
     const long per = (long)d->c_in * d->h * d->w, nin = per * B;
     const long nconv = (long)B * d->c_out * ch * cw, npool = (long)B * d->c_out * ph * pw;
+    const int K = d->c_out * ph * pw;
+    if (d->c_in == 32 && d->c_out == 32 && d->h == 16 && d->w == 16 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 &&
+        d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b) {
+        // the whole layer step in one MFMA kernel (traces, conv in the pinned order, refractory, threshold, sigmoid)
+        if (d->refractory)
+            hipLaunchKernelGGL(k_lif_step_c32<true>, dim3(B), dim3(512), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
+                               d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
+        else
+            hipLaunchKernelGGL(k_lif_step_c32<false>, dim3(B), dim3(512), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
+                               d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
+        HIP_CHECK_LAUNCH("k_lif_step_c32");
+        if (i2o_W && out_p) {
+            rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
+            if (rc) return rc;
+        }
+        if (d->output_layer) {
+            if (!out_W || !out_o) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: output layer needs out_W and out_o");
+            rc = launch_readout(out_pv, out_W, out_b, out_o, B, K, d->target, st);
+            if (rc) return rc;
+        }
+        return DCLL_OK;
+    }
     hipLaunchKernelGGL(k_trace, dim3(nblk(nin, 256) > 4096 ? 4096 : nblk(nin, 256)), dim3(256), 0, st, x, alpha, tau_m,
                        alphas, tau_s, eps0, eps1, nin, per, d->tau_is_tensor);
     HIP_CHECK_LAUNCH("k_trace");
@@ -1735,7 +1861,6 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
                            out_pv, npool);
         HIP_CHECK_LAUNCH("k_pool");
     }
-    const int K = d->c_out * ph * pw;
     if (i2o_W && out_p) {
         rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
         if (rc) return rc;

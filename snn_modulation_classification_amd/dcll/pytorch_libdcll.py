@@ -198,19 +198,19 @@ class ContinuousConv2D(nn.Module):
                 None if output_ is None else output_.weight, None if output_ is None else output_.bias)
 
     def _fast_step_ok(self, input, pooling):
-        """32->32, 7x7 pad 3, pool 1, per-channel time constants, on a 16x16 plane or one with H % 8 == 0 and
-        W % 32 == 0: the MFMA sequence kernels (k_lif_seq_c32 / k_lif_seq_c32t) serve one step."""
+        """32->32, 7x7 pad 3, pool 1, per-channel time constants, on a plane with H % 8 == 0 and W % 32 == 0: the tiled
+        MFMA sequence kernel (k_lif_seq_c32t) serves one step.  (On the 16x16 plane dcll_conv_lif_step itself runs the
+        single-step MFMA kernel k_lif_step_c32 for any fp32 input.)"""
         H, W = tuple(input.shape[2:4])
         return (self.in_channels == 32 and self.out_channels == 32 and self.kernel_size == (7, 7) and
-                self.padding == (3, 3) and ((H, W) == (16, 16) or (H % 8 == 0 and W % 32 == 0)) and
+                self.padding == (3, 3) and (H % 8 == 0 and W % 32 == 0) and
                 tuple(pooling) == (1, 1) and self.stride == 1 and self.dilation == 1 and self.groups == 1 and
                 self.bias is not None and self.tau_per_channel() is not None)
 
     def _step_packed(self, desc, input, st, arp, i2o, output_):
         """One step through the weight-stationary MFMA kernel (T = 1, state in HBM) for layers whose input is known
         to be a binary spike map (`binary_input`, set by ConvNetwork for every layer fed by another layer): bit-pack ->
-        k_lif_seq_c32(t) -> unpack; 20x faster than the generic per-step kernels on the 16x16 plane and bit-identical
-        to them."""
+        k_lif_seq_c32t -> unpack; bit-identical to the generic per-step kernels."""
         B, _, H, W = input.shape
         words = H * W // 32
         with torch.no_grad():
