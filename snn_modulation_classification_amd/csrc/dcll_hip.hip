@@ -478,6 +478,64 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
 }
 
 // dW / db = fixed-order sum of the partial rows part[chunk][co][rowlen] (rowlen = c_in*ntap + 1, last = bias gradient)
+// k_bwd_dv for layers without pooling: thread = one position k = (co, y, x) of the map, the (<= 32) readout weights of
+// that position in registers, a chunk of samples looped over (g_p is wave-uniform -> scalar loads): i2o_W is read once
+// per chunk instead of once per sample (786 KB x B through L2 before).
+__global__ __launch_bounds__(256) void k_bwd_dv_nopool(int K, int N, const float *__restrict__ v,
+                                                        const float *__restrict__ g_p, const float *__restrict__ g_pv,
+                                                        const float *__restrict__ g_v, const float *__restrict__ i2o_W,
+                                                        float *__restrict__ gvf, int B, int per_block)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float wk[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) wk[n] = (g_p && n < N) ? i2o_W[(long)n * K + k] : 0.0f;
+    const int b0 = blockIdx.y * per_block, b1 = min(B, b0 + per_block);
+    for (int b = b0; b < b1; ++b) {
+        const long i = (long)b * K + k;
+        float g = g_pv ? g_pv[i] : 0.0f;
+        if (g_p) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int n = 0; n < 32; ++n)
+                if (n < N) acc = __builtin_fmaf(g_p[(long)b * N + n], wk[n], acc);
+            g += acc;
+        }
+        const float pv = sigmoidf_dev(v[i]);
+        float out = g * pv * (1.0f - pv);
+        if (g_v) out += g_v[i];
+        gvf[i] = out;
+    }
+}
+
+// The same sum with four threads per output (64 outputs x 4 groups of partial rows per workgroup), the four group sums
+// combined in fixed order through LDS: a quarter of the dependent-load latency of k_bwd_reduce (54 -> ~15 us for 256
+// partial rows of 50 208 floats), still deterministic.
+__global__ __launch_bounds__(256) void k_bwd_reduce4(const float *__restrict__ part, float *__restrict__ dW,
+                                                      float *__restrict__ db, int nchunk, int c_out, long rowlen)
+{
+    __shared__ float red[4][64];
+    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    const long total = c_out * rowlen;
+    float acc = 0.0f;
+    if (i < total) {
+        const int per = (nchunk + 3) / 4, c0 = grp * per, c1 = min(nchunk, c0 + per);
+        for (int c = c0; c < c1; ++c) acc += part[(long)c * total + i];
+    }
+    red[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && i < total) {
+        const int l = threadIdx.x & 63;
+        const float tot = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+        const int co = (int)(i / rowlen);
+        const long n = i % rowlen;
+        if (n < rowlen - 1) dW[(long)co * (rowlen - 1) + n] = tot;
+        else if (db) db[co] = tot;
+    }
+}
+
 __global__ void k_bwd_reduce(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int nchunk,
                              int c_out, long rowlen)
 {
@@ -1957,8 +2015,14 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
     int ch, cw, ph, pw;
     conv_shape(d, &ch, &cw, &ph, &pw);
     const long nconv = (long)B * d->c_out * ch * cw;
-    hipLaunchKernelGGL(k_bwd_dv, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, v, g_p, g_pv, g_v, i2o_W,
-                       scratch, nconv);
+    if (d->pool_h == 1 && d->pool_w == 1 && d->target <= 32) {
+        const int Kmap = d->c_out * ch * cw, per_block = 16;
+        hipLaunchKernelGGL(k_bwd_dv_nopool, dim3(nblk(Kmap, 256), nblk(B, per_block)), dim3(256), 0, st, Kmap, d->target,
+                           v, g_p, g_pv, g_v, i2o_W, scratch, B, per_block);
+    } else {
+        hipLaunchKernelGGL(k_bwd_dv, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, v, g_p, g_pv, g_v, i2o_W,
+                           scratch, nconv);
+    }
     HIP_CHECK_LAUNCH("k_bwd_dv");
     // weight gradient: partial sums over batch chunks (after the g_v_full plane in scratch), then a fixed-order reduce
     const long rowlen = (long)d->c_in * d->kh * d->kw + 1;
@@ -1993,7 +2057,10 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
                            eps1, part, B, RB);
         HIP_CHECK_LAUNCH("k_bwd_wgrad");
     }
-    hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+    if (nchunk >= 16)
+        hipLaunchKernelGGL(k_bwd_reduce4, dim3(nblk(per_chunk, 64)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+    else
+        hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
     HIP_CHECK_LAUNCH("k_bwd_reduce");
     if (g_o) {
         const int K = d->c_out * ph * pw, N = d->target;
