@@ -1773,22 +1773,22 @@ __global__ __launch_bounds__(512) void k_lif_step_c32(const float *__restrict__ 
     // weight chunk cp as A fragments: wch[tap*64 + hh*32 + co] = W[co][2cp+hh][tap]; in global memory the 98 floats of
     // (co, channel pair cp) are contiguous.  Thread t fetches elements t, t+512, ... of the 32 x 98 block.
     float wreg[7];
+    int goff[7], loff[7];               // per-thread element offsets, computed once: index arithmetic inside the chunk
+#pragma unroll                          // loop would be ~140 VALU per iteration issued against the MFMA stream
+    for (int i = 0; i < 7; ++i) {
+        const int idx = tid + 512 * i, co = idx / 98, r = idx % 98;
+        goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
+        loff[i] = (r % 49) * 64 + (r / 49) * 32 + co;
+    }
     auto fetch_w = [&](int cp) {
+        const float *wc = W + cp * 98;          // wave-uniform base of the chunk
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int idx = tid + 512 * i;
-            wreg[i] = idx < 32 * 98 ? W[(long)(idx / 98) * 1568 + cp * 98 + idx % 98] : 0.0f;
-        }
+        for (int i = 0; i < 7; ++i) wreg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int idx = tid + 512 * i;
-            if (idx < 32 * 98) {
-                const int co = idx / 98, r = idx % 98;
-                wch[buf * STEP_WCH + (r % 49) * 64 + (r / 49) * 32 + co] = wreg[i];
-            }
-        }
+        for (int i = 0; i < 7; ++i)
+            if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
     };
     fetch_w(0);
     __syncthreads();        // image zeroed
