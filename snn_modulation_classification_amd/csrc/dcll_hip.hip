@@ -12,7 +12,7 @@
 // -ffp-contract=off is part of the arithmetic contract: the trace lines are three separately rounded ops.
 //
 // Kernels
-//   k_lif_seq_c32d     the hot kernel (T >= 24): k_lif_seq_c32 with two pixel tiles per wave and stage — see its header.
+//   k_lif_seq_c32d     the hot kernel (T >= 8): k_lif_seq_c32 with two pixel tiles per wave and stage — see its header.
 //   k_lif_seq_c32      one 32->32 7x7 layer, ALL T timesteps, one sample per workgroup (short sequences, per-step calls).
 //                      8 waves; wave w owns input channels 4w..4w+3 (a K-slice of the implicit GEMM):
 //                      their eps0/eps1 traces (registers + a zero-padded LDS image) and the 2x49 weight
@@ -2106,7 +2106,7 @@ extern "C" int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void 
     return DCLL_OK;
 }
 
-constexpr int DCLL_C32D_MIN_T = 24;     // shorter sequences: k_lif_seq_c32 (half the pipeline fill)
+constexpr int DCLL_C32D_MIN_T = 8;      // shorter sequences: k_lif_seq_c32 (half the pipeline fill)
 
 template <bool R, int NRO>
 static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, const float *W, const float *b,

@@ -97,9 +97,10 @@ def _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, target=24, rng=None):
 
 
 @pytest.mark.parametrize("wrp,T,B,zero_state", [(1.0, 24, 3, True), (0.0, 9, 2, True), (1.0, 10, 5, False),
-                                                 (0.0, 26, 2, False), (1.0, 31, 2, False)])
+                                                 (0.0, 26, 2, False), (1.0, 31, 2, False), (1.0, 5, 3, False),
+                                                 (0.0, 7, 2, True), (1.0, 1, 4, False)])
 def test_sequence_c32_vs_oracle(dev, wrp, T, B, zero_state):
-    """k_lif_seq_c32 (T < 24) and k_lif_seq_c32d (T >= 24; two tiles per wave and stage) — MFMA systolic chain, state
+    """k_lif_seq_c32 (T < 8) and k_lif_seq_c32d (T >= 8; two tiles per wave and stage) — MFMA systolic chain, state
     on chip — == C oracle stepping, bit for bit, incl. final state; both variants (refractory or not), zero and
     non-zero initial state, T not a multiple of anything convenient."""
     from snn_modulation_classification_amd import ops
@@ -133,7 +134,7 @@ def test_sequence_c32_vs_oracle(dev, wrp, T, B, zero_state):
     assert bits_equal(eps1.cpu().numpy(), orc.state[1])
     if wrp > 0:
         assert bits_equal(arp.cpu().numpy(), orc.state[2])
-    assert 0.01 < spk_d[1:].mean() < 0.9, "degenerate test: spikes all equal"
+    assert (0.01 if T > 1 else 0.001) < (spk_d[1:] if T > 1 else spk_d).mean() < 0.9, "degenerate test: spikes all equal"
 
 
 @pytest.mark.parametrize("hw,wrp,T,B,zero_state", [((32, 32), 1.0, 11, 2, True), ((16, 64), 0.0, 10, 3, False),
