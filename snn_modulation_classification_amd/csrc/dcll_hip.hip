@@ -1742,18 +1742,20 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
 
 // ------------------------------------------------------------------------------------------------------------
 // k_lif_step_c32 — ONE timestep of a 32 -> 32 channel 7x7 layer on the 16x16 plane (the per-step drop-in and the
-// forward of a local-learning step), one sample per 512-thread workgroup, state through HBM.
+// forward of a local-learning step), one sample per 256-thread workgroup, state through HBM.
 //
 // The sequence kernels hand a tile's accumulator from wave to wave; for a single step that systolic pipeline would
 // spend 9 of its 17 stages filling and draining (k_lif_seq_c32 at T = 1: 174 us at B = 512, 48 % of the MFMA time).
-// Here every wave keeps ONE pixel tile (image rows 2w, 2w+1) and runs the whole K = 1568 chain itself, in the pinned
-// order; the weights stream through LDS in 16 chunks of one input-channel pair (49 taps x 64 lanes, double-buffered,
-// next chunk fetched into registers during the MFMAs of this one).  Input is the dense fp32 map x (any values, not
+// Here every wave keeps a PAIR of pixel tiles (image rows 4w..4w+3) and runs both whole K = 1568 chains itself, in
+// the pinned order, as two independent accumulator chains; the weights stream through LDS in 16 chunks of one
+// input-channel pair (49 taps x 64 lanes, double-buffered, next chunk fetched into registers during the MFMAs of this
+// one).  A row of 7 weight fragments is read once and serves tile A at tap row ky and tile B two rows later; a row of
+// B fragments serves both tiles: 112 ds_read dwords per 98 MFMAs.  Input is the dense fp32 map x (any values, not
 // only {0,1}), outputs are the dense s / pv / v maps of dcll_conv_lif_step: no packing, no separate trace kernel.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int STEP_WCH = 49 * 64;       // floats per weight chunk: A fragments of one channel pair
 template <bool REFRACTORY>
-__global__ __launch_bounds__(512) void k_lif_step_c32(const float *__restrict__ x, const float *__restrict__ W,
+__global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ x, const float *__restrict__ W,
                                                        const float *__restrict__ bias, const float *__restrict__ alpha,
                                                        const float *__restrict__ tau_m, const float *__restrict__ alphas,
                                                        const float *__restrict__ tau_s, int tau_is_tensor,
@@ -1765,37 +1767,39 @@ __global__ __launch_bounds__(512) void k_lif_step_c32(const float *__restrict__ 
     __shared__ __attribute__((aligned(16))) float lds[IMG_FLOATS + 2 * STEP_WCH + 32];
     float *img = lds, *wch = lds + IMG_FLOATS, *sbias = wch + 2 * STEP_WCH;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // my pixel tile: image rows 2w, 2w+1
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // my tile pair: image rows 4w..4w+3
     const long b = blockIdx.x;
 
-    for (int i = tid; i < IMG_FLOATS; i += 512) img[i] = 0.0f;
+    for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
     // weight chunk cp as A fragments: wch[tap*64 + hh*32 + co] = W[co][2cp+hh][tap]; in global memory the 98 floats of
-    // (co, channel pair cp) are contiguous.  Thread t fetches elements t, t+512, ... of the 32 x 98 block.
-    float wreg[7];
-    int goff[7], loff[7];               // per-thread element offsets, computed once: index arithmetic inside the chunk
-#pragma unroll                          // loop would be ~140 VALU per iteration issued against the MFMA stream
-    for (int i = 0; i < 7; ++i) {
-        const int idx = tid + 512 * i, co = idx / 98, r = idx % 98;
+    // (co, channel pair cp) are contiguous.  Thread t moves elements t, t+256, ... of the 32 x 98 block; the index
+    // arithmetic is done once (inside the chunk loop it would be issued against the MFMA stream).
+    constexpr int NW = 13;
+    float wreg[NW];
+    int goff[NW], loff[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
         goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
         loff[i] = (r % 49) * 64 + (r / 49) * 32 + co;
     }
     auto fetch_w = [&](int cp) {
         const float *wc = W + cp * 98;          // wave-uniform base of the chunk
 #pragma unroll
-        for (int i = 0; i < 7; ++i) wreg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
+        for (int i = 0; i < NW; ++i) wreg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i)
+        for (int i = 0; i < NW; ++i)
             if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
     };
     fetch_w(0);
     __syncthreads();        // image zeroed
-    // traces of this step (dcll/pytorch_libdcll.py:493-494): 16 elements per thread, state updated in HBM, eps1 -> image
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int e = tid + 512 * i, c = e >> 8, pix = e & 255;
+    // traces of this step (dcll/pytorch_libdcll.py:493-494): 32 elements per thread, state updated in HBM, eps1 -> image
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int e = tid + 256 * i, c = e >> 8, pix = e & 255;
         const long gidx = b * 8192 + e;
         const int ti = tau_is_tensor ? e : 0;
         float e0 = eps0_g[gidx], e1 = eps1_g[gidx];
@@ -1805,43 +1809,58 @@ __global__ __launch_bounds__(512) void k_lif_step_c32(const float *__restrict__ 
         img[c * CHF + ((pix >> 4) + 3) * ROWF + (pix & 15) + 3] = e1;
     }
     store_w(0);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     __syncthreads();        // image, bias and chunk 0 in place
+    f32x16 accA, accB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
-    const int bbase = h * CHF + ((j >> 4) + 2 * w) * ROWF + (j & 15);
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+    const int bbase = h * CHF + ((j >> 4) + 4 * w) * ROWF + (j & 15);
     for (int cp = 0; cp < 16; ++cp) {
         if (cp + 1 < 16) fetch_w(cp + 1);                  // lands during the MFMAs below
         const float *wa = wch + (cp & 1) * STEP_WCH + lane;
         const float *ib = img + bbase + cp * 2 * CHF;
+        // LDS rows rho = 0..8 below the pair's first image row: row rho is tap row ky = rho of tile A (rho <= 6) and
+        // tap row ky = rho - 2 of tile B (rho >= 2); the weight fragments of tap row ky are read once (at rho = ky)
+        // and kept for tile B two rows later
+        float wr[3][7];
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
+        for (int rho = 0; rho < 9; ++rho) {
+            float bq[7];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(ky * 7 + kx) * 64], ib[ky * ROWF + kx], acc, 0, 0, 0);
+            for (int kx = 0; kx < 7; ++kx) bq[kx] = ib[rho * ROWF + kx];
+            if (rho <= 6) {
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[(rho * 7 + kx) * 64];
+            }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                if (rho <= 6) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[rho % 3][kx], bq[kx], accA, 0, 0, 0);
+                if (rho >= 2) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[(rho - 2) % 3][kx], bq[kx], accB, 0, 0, 0);
+            }
+        }
         if (cp + 1 < 16) store_w((cp + 1) & 1);            // the other buffer: nobody reads it in this iteration
         __syncthreads();
     }
-    // epilogue of my tile: channel (r&3) + 8(r>>2) + 4h, pixel 32w + j
+    // epilogue of my two tiles: channel (r&3) + 8(r>>2) + 4h, pixel 32(2w + tl) + j
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long o = (b * 32 + co) * 256 + 32 * w + j;
-        float v = acc[r];
-        bool s;
-        if (REFRACTORY) {
-            float ar = arp_g[o];
-            v = refractory(acc[r], ar, alpharp, wrp, s);
-            arp_g[o] = ar;
-        } else {
-            s = v > 0.0f;
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const long o = (b * 32 + co) * 256 + 32 * (2 * w + tl) + j;
+            const float pvm = tl ? accB[r] : accA[r];
+            float v = pvm;
+            bool s;
+            if (REFRACTORY) {
+                float ar = arp_g[o];
+                v = refractory(pvm, ar, alpharp, wrp, s);
+                arp_g[o] = ar;
+            } else {
+                s = v > 0.0f;
+            }
+            out_s[o] = s ? 1.0f : 0.0f;
+            out_pv[o] = sigmoidf_dev(v);
+            if (out_v) out_v[o] = v;
         }
-        out_s[o] = s ? 1.0f : 0.0f;
-        out_pv[o] = sigmoidf_dev(v);
-        if (out_v) out_v[o] = v;
-    }
 }
 
 extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
@@ -1868,10 +1887,10 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
         d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b) {
         // the whole layer step in one MFMA kernel (traces, conv in the pinned order, refractory, threshold, sigmoid)
         if (d->refractory)
-            hipLaunchKernelGGL(k_lif_step_c32<true>, dim3(B), dim3(512), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
+            hipLaunchKernelGGL(k_lif_step_c32<true>, dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
                                d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
         else
-            hipLaunchKernelGGL(k_lif_step_c32<false>, dim3(B), dim3(512), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
+            hipLaunchKernelGGL(k_lif_step_c32<false>, dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
                                d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
         HIP_CHECK_LAUNCH("k_lif_step_c32");
         if (i2o_W && out_p) {
