@@ -63,6 +63,8 @@ def parse_args(argv=None):
                    help='evaluate N seeded synthetic IQ windows per SNR instead of reading HDF5')
     p.add_argument('--out_dir', type=str, default=None, help='where to write results (default: dir of restore_path)')
     p.add_argument('--no_sequence_path', action='store_true', help='force the per-step path (net.test per timestep)')
+    p.add_argument('--min_snr', type=int, default=6, metavar='N', help='first SNR evaluated (reference: fixed 6)')
+    p.add_argument('--max_snr', type=int, default=30, metavar='N', help='last SNR evaluated (reference: fixed 30)')
     return p.parse_args(argv)
 
 
@@ -159,7 +161,7 @@ def main(argv=None):
                             device=pytorch_libdcll.device) if use_sequence else None
 
         accs = []
-        snrs = np.array(range(6, 32, 2))
+        snrs = np.array(range(args.min_snr, args.max_snr + 2, 2))        # reference :114: range(6, 32, 2)
         total_cm = np.zeros((TARGET_SIZE, TARGET_SIZE), dtype=int)
         for snr in snrs:
             t_start = time.time()

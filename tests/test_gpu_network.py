@@ -413,6 +413,26 @@ def test_entry_point_train_mnist_config1(tmp_path):
     assert sd['dcll_slices.0.dclllayer.i2h.weight'].shape == (16, 1, 7, 7)
 
 
+def test_entry_point_test_radio_ml_on_files(tmp_path):
+    """test_radio_ml.py on RadioML files (a small 2016.10a-style pickle): per-SNR accuracies and confusion matrices,
+    fused path == per-step path."""
+    import pickle
+    import test_radio_ml
+    mods = ['8PSK', 'AM-DSB', 'AM-SSB', 'BPSK', 'CPFSK', 'GFSK', 'PAM4', 'QAM16', 'QAM64', 'QPSK', 'WBFM']
+    rng = np.random.RandomState(1)
+    d = {(m, s): (0.4 * rng.randn(6, 2, 128)).astype(np.float32) for m in mods for s in range(0, 6, 2)}
+    (tmp_path / 'data').mkdir()
+    with open(tmp_path / 'data' / 'RML2016.10a_dict.pkl', 'wb') as f:
+        pickle.dump(d, f)
+    common = ['--radio_ml_data_dir', str(tmp_path / 'data'), '--min_snr', '0', '--max_snr', '4', '--per_h5_frac', '1.0',
+              '--train_frac', '0.5', '--I_resolution', '16', '--Q_resolution', '16', '--arp', '1.0', '--burnin', '4',
+              '--n_iters_test', '16', '--batch_size_test', '11', '--n_test_samples', '22']
+    a = test_radio_ml.main(common + ['--out_dir', str(tmp_path / 'seq')])
+    b = test_radio_ml.main(common + ['--out_dir', str(tmp_path / 'step'), '--no_sequence_path'])
+    assert np.asarray(a).shape == (3, 3) and np.array_equal(np.asarray(a), np.asarray(b))
+    assert np.load(tmp_path / 'seq' / 'confusion_matrix_snr_4.npy').sum() == 22
+
+
 def test_fused_iq_encoder_equals_cells_path():
     """dcll_conv_lif_sequence_iq (quantisation fused into the first layer's kernel) == encode on host + cells path."""
     from snn_modulation_classification_amd.data.utils import IQEncoder, iq2cells
