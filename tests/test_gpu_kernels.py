@@ -137,6 +137,38 @@ def test_sequence_c32_vs_oracle(dev, wrp, T, B, zero_state):
     assert (0.01 if T > 1 else 0.001) < (spk_d[1:] if T > 1 else spk_d).mean() < 0.9, "degenerate test: spikes all equal"
 
 
+@pytest.mark.parametrize("hw,T", [((16, 16), 12), ((16, 16), 3), ((32, 32), 6)])
+@pytest.mark.parametrize("wrp", [1.0, 0.0])
+def test_sequence_output_variants_agree(dev, hw, T, wrp):
+    """Every compiled output variant of the 32 -> 32 sequence kernels (pv and / or v written or not, spikes written or
+    not: the OUT template parameter of k_lif_seq_c32 / c32d / c32t) leaves the same state and, where produced, the same
+    spikes, pv and v."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(23)
+    H, Wd = hw
+    B = 2
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
+    x = (rng.uniform(size=(T, B, 32, H * Wd)) < 0.1).astype(np.float32)
+    d = ops.make_conv_desc(32, 32, hw, 7, 3, 1, 24, False, wrp > 0, wrp)
+    spk_in = ops.pack_spikes(cu(x, dev))
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    ref = None
+    for want_pv in (True, False):
+        for want_v in (True, False):
+            for want_spikes in (True, False):
+                st = [torch.zeros((B, 32, H, Wd), device=dev) for _ in range(3)]
+                spk, pv, v = ops.conv_lif_sequence(d, spk_in, cu(W, dev), cu(b, dev), tau4, st[0], st[1],
+                                                   st[2] if wrp > 0 else None, T, B, want_spikes=want_spikes,
+                                                   want_pv=want_pv, want_v=want_v)
+                got = dict(spk=spk, pv=pv, v=v, eps0=st[0], eps1=st[1], arp=st[2])
+                if ref is None:
+                    ref = got
+                    assert float(ref["spk"].ne(0).float().mean()) > 0
+                for k, val in got.items():
+                    if val is not None:
+                        assert torch.equal(val, ref[k]), (k, want_pv, want_v, want_spikes)
+
+
 @pytest.mark.parametrize("hw,wrp,T,B,zero_state", [((32, 32), 1.0, 11, 2, True), ((16, 64), 0.0, 10, 3, False),
                                                     ((24, 96), 1.0, 9, 2, False), ((128, 128), 1.0, 3, 1, True)])
 def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
