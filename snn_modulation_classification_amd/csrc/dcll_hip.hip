@@ -1526,6 +1526,20 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) bq[0][kx] = lds[i0 + kx];
         }
+        // ---- (2) trace share (dcll/pytorch_libdcll.py:493-494, every op rounded separately) ----
+        if (tr) {
+            float *dst = lds + ((t + 1) & 1) * IMG_FLOATS + ioff + p * CHF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a;                                    // x * tau_s with x in {0,1}: exact select
+                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(a) : "v"(ts), "s"(wm[i]));
+                const float bb = tas * e0[U][i];
+                e0[U][i] = a + bb;
+                const float cc = ta * sv[i];
+                const float dd = e0[U][i] * tm;
+                dst[i * 4 * ROWF] = cc + dd;
+            }
+        }
         // ---- (1) epilogue share ----
         if (epi) {
             const int te = qe >> 2, me = 2 * U + wpar;
@@ -1547,20 +1561,6 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
                 if (OUT & 2) vb[loff + rr * 256] = v;
             }
             if (spk_out && j < 4) (spk_out + (ubase >> 5))[(4 * h + j) * 8 + me] = myword;
-        }
-        // ---- (2) trace share (dcll/pytorch_libdcll.py:493-494, every op rounded separately) ----
-        if (tr) {
-            float *dst = lds + ((t + 1) & 1) * IMG_FLOATS + ioff + p * CHF;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float a;                                    // x * tau_s with x in {0,1}: exact select
-                asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(a) : "v"(ts), "s"(wm[i]));
-                const float bb = tas * e0[U][i];
-                e0[U][i] = a + bb;
-                const float cc = ta * sv[i];
-                const float dd = e0[U][i] * tm;
-                dst[i * 4 * ROWF] = cc + dd;
-            }
         }
         if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
         // every slot read of this stage has completed before any wave writes its slots again

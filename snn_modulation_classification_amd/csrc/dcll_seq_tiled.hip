@@ -211,6 +211,15 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
         const bool epi = qe >= 0 && qe < 4 * T;
         f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
         if (epi) v4 = *((const f32x4 *)(slots + (7 * 2 + wpar) * SLOT_FLOATS) + wq * 64 + lane);
+        // ---- (2) trace rows of this stage (their rows are not read between tile 2p-1 and tile 2p) ----
+        if (active) {
+            switch (p) {        // wave-uniform: keeps e0[][][] statically indexed (registers)
+            case 0: if (t >= 1) advance(std::integral_constant<int, 0>{}, fword); break;
+            case 1: if (t >= 1) advance(std::integral_constant<int, 1>{}, fword); break;
+            case 2: if (t >= 1) advance(std::integral_constant<int, 2>{}, fword); break;
+            default: if (t + 1 < T) advance(std::integral_constant<int, 3>{}, fword); break;
+            }
+        }
         // ---- (1) epilogue share ----
         if (epi) {
             const int te = qe >> 2, me = 2 * U + wpar;
@@ -233,15 +242,6 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
             }
             if (spk_out && j < 4)
                 (spk_out + (ubase >> 5) + (long)(y0 + me) * wpr + tx)[(unsigned)(4 * h + j) * (unsigned)words] = myword;
-        }
-        // ---- (2) trace rows of this stage (their rows are not read between tile 2p-1 and tile 2p) ----
-        if (active) {
-            switch (p) {        // wave-uniform: keeps e0[][][] statically indexed (registers)
-            case 0: if (t >= 1) advance(std::integral_constant<int, 0>{}, fword); break;
-            case 1: if (t >= 1) advance(std::integral_constant<int, 1>{}, fword); break;
-            case 2: if (t >= 1) advance(std::integral_constant<int, 2>{}, fword); break;
-            default: if (t + 1 < T) advance(std::integral_constant<int, 3>{}, fword); break;
-            }
         }
         //   chain inputs out of the slots (written in the previous stage) — read last in the phase: 32 registers that
         //   would otherwise be live across the epilogue and the trace rows (14 spilled VGPRs)
