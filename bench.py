@@ -167,6 +167,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    net._sequence_buffers(T_STEPS, min(B, max(1, int(net.pv_budget_bytes // (4 * T_STEPS * 32 * R * R)))), dev)  # allocate once, outside the timed region
+    if world > 1:
+        # create the RCCL communicator now (lazy otherwise: it would land in the first step, timed when --warmup 0)
+        dist.all_reduce(torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
     log("rank %d/%d: network built, B=%d per GPU" % (rank, world, B))
     for _ in range(a.warmup):
         step()
