@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         }
         if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
         // every slot read of this stage has completed before any wave writes its slots again
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        lds_barrier();
         if (DBG) st2 = __builtin_amdgcn_s_memtime();
         // inputs of the NEXT stage's trace share: they land while the chains run (the eps1 values it reads were
         // written by my own trace share four stages ago; nobody else touches my channels).  Issued before the first
@@ -1606,7 +1606,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         }
         if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st3 = __builtin_amdgcn_s_memtime(); }
         // stage barrier: only the LDS traffic has to be complete, not the pv / spike stores of the epilogue
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        lds_barrier();
         if (DBG) {
             const unsigned long long st4 = __builtin_amdgcn_s_memtime();
             dbg[0] += st1 - st0; dbg[1] += st2 - st1; dbg[2] += st3 - st2; dbg[3] += st4 - st3;

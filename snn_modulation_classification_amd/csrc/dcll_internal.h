@@ -82,6 +82,16 @@ __device__ __forceinline__ float refractory(float pvmem, float &arp, float alpha
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS (and scalar) operations, then
+// s_barrier — without the s_waitcnt vmcnt(0) that __syncthreads() adds for its global-memory fence, so a wave does not
+// stall on its own pv / spike stores.  The builtin keeps the barrier convergent for the compiler.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // one DPP step of a wave-wide sum: v + (v moved by CTRL); lanes without a source add 0
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v)

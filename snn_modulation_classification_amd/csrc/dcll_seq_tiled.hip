@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
             }
         }
         // every slot read of this stage has completed before any wave writes its slots again
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        lds_barrier();
         // spike words of the NEXT stage's row group: they land while the chains run
         fword = fetch_for_stage(g + 1);
         // ---- (3) my K-slice of both chains ----
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
                 dp[c * 64] = f32x4{accB[4 * c + 0], accB[4 * c + 1], accB[4 * c + 2], accB[4 * c + 3]};
         }
         // stage barrier: only the LDS traffic has to be complete, not the pv / spike stores of the epilogue
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        lds_barrier();
     };
 
     const int nstage = 4 * T + 8;       // a multiple of 4
