@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
         const int cell = iq ? scell[t] : cells[(long)t * B + b];
         trace_update(cell == pix ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0, e1);
         plane[(y + 3) * PS + x + 3] = e1;
-        __syncthreads();
+        lds_barrier();      // LDS-only: does not wait for this step's pv stores
         const long obase = ((long)t * B + b) * c_out;
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
                 spk_out[(obase + cow) * 8 + m] = myword;
             }
         }
-        __syncthreads();
+        lds_barrier();      // LDS-only: does not wait for this step's pv stores
     }
     eps0_g[(long)b * 256 + pix] = e0;
     eps1_g[(long)b * 256 + pix] = e1;

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
             trace_update(cell == gpix[s] ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0[s], e1[s]);
             if (tid + 256 * s < C1T_REGION) plane[tid + 256 * s] = e1[s];
         }
-        __syncthreads();
+        lds_barrier();      // LDS-only: does not wait for this step's pv stores
         const long obase = ((long)t * B + b) * c_out;
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
                 spk_out[(obase + cow) * words + (long)(y0 + m) * wpr + tx] = myword;
             }
         }
-        __syncthreads();
+        lds_barrier();      // LDS-only: does not wait for this step's pv stores
     }
     // state back: the interior of the region
 #pragma unroll
