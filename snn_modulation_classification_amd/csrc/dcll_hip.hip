@@ -22,12 +22,18 @@
 //                      skewed by one tile (a systolic chain), one s_barrier per tile-stage.
 //   k_lif_seq_c1       first layer (c_in = 1, one input spike per step as a cell index or raw IQ): fp32 MFMA with the
 //                      49 taps padded to 28 k-pairs by zero weights, weight-stationary, one sample per workgroup.
-//   k_trace / k_conv_lif / k_pool   generic per-step path (any geometry, state in HBM) — the exact drop-in for
-//                      `.forward`; same pinned order.
+//   k_lif_step_c32     ONE step of a 32->32 7x7 layer on the 16x16 plane (per-step drop-in, learning forward): no
+//                      systolic hand-off, every wave runs two whole chains, weights stream through LDS.
+//   k_trace / k_conv_lif_tiled / k_conv_lif / k_pool   generic per-step path (any geometry, state in HBM) — the exact
+//                      drop-in for `.forward`; same pinned order.
 //   k_dense_lif        DenseDCLLlayer step.
-//   k_readout          fp32-MFMA GEMM for i2o / output_ over many rows.
+//   k_bwd_dv[_nopool], k_bwd_wgrad_c32 (MFMA, 16x16 plane or 16x16 tiles with halo), k_bwd_wgrad (any geometry, row
+//                      bands), k_bwd_reduce[4], k_bwd_outgrad[_part/_reduce]   backward of one layer step (local learning).
+//   k_readout_v4 / k_readout_ks / k_readout_rows / k_readout (+ k_readout_sum)   fp32-MFMA GEMMs for i2o / output_:
+//                      many rows, long rows (also split over K with caller scratch), few rows, any shape.
 //   k_argmax, k_vote   per-step argmax and vote.
-//   k_iq_encode, k_pack, k_unpack     glue.
+//   k_iq_encode, k_pack, k_unpack, k_permute_readout     glue.
+// The kernels for planes larger than 16x16 (k_lif_seq_c32t, k_lif_seq_c1t) live in dcll_seq_tiled.hip.
 #include "dcll_internal.h"
 
 static thread_local char g_err[DCLL_ERR_LEN] = "";
