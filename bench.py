@@ -129,6 +129,8 @@ def main():
                     help="CPU baseline batch (0 = skip); default 512 = batch_size_test of the reference's scripts "
                          "(4 on planes larger than 16x16, where the CPU path needs seconds per window)")
     ap.add_argument("--fuse-readout", type=int, default=0, help="1: readouts in the layer kernel's epilogue")
+    ap.add_argument("--output-only", type=int, default=0,
+                    help="1: serving mode — hidden layers skip pv and their local readouts (NOT the headline workload)")
     a = ap.parse_args()
     global R
     R = a.plane
@@ -157,8 +159,9 @@ def main():
         net.zero_states()
         net.reset()
         res = net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False, profile=profile,
-                                fuse_readout=bool(a.fuse_readout))
-        tal = parallel.allreduce_tallies(parallel.tallies(res["vote"], labels, N_CLASSES))
+                                fuse_readout=bool(a.fuse_readout), output_only=bool(a.output_only))
+        votes = [v if v is not None else res["vote"][-1] for v in res["vote"]]      # output_only: hidden layers have none
+        tal = parallel.allreduce_tallies(parallel.tallies(votes, labels, N_CLASSES))
         return res, tal
 
     def fence():
@@ -224,7 +227,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "radio_ml_conv.yaml, %dx%d I/Q plane, T=128, arp=1.0, random_tau, batch %d per GPU%s, "
                                    "synthetic IQ 0.4*randn(B,2,128), seeded init" %
-                                   (R, R, B, " (north_star headline batch)" if (B == 4096 and R == 16) else ""),
+                                   (R, R, B, (" (north_star headline batch)" if (B == 4096 and R == 16) else "") +
+                                    (", OUTPUT-ONLY serving mode (hidden-layer readouts skipped)" if a.output_only else "")),
                        "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [R, R],
                        "parallelism": "batch shards, %d rank(s), tally all-reduce only" % world},
             "roofline": {"kernel": hot_kernel, "bound": "mfma", "achieved": achieved,

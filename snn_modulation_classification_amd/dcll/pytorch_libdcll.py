@@ -417,7 +417,8 @@ class Conv2dDCLLlayer(nn.Module):
             self._ro_cache = cache
         return cache[1], cache[2]
 
-    def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False, batch_slice=None):
+    def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False, batch_slice=None,
+                         want_pv=True):
         """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,H*W/32) int32 ('packed').
         Neuron state is read from / written back to self.i2h.state (rows batch_slice .. batch_slice+B of it when
         `batch_slice` is given: a chunk of a larger batch).
@@ -437,12 +438,13 @@ class Conv2dDCLLlayer(nn.Module):
         with torch.no_grad():
             if kind == 'cells':
                 spk, pv, _ = ops.conv_lif_sequence_cells(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,
-                                                         T, B, want_spikes=want_spikes, out=buffers)
+                                                         T, B, want_spikes=want_spikes, want_pv=want_pv, out=buffers)
                 return spk, pv, None
             if kind == 'iq':        # inp = (iq (B,2,L), thr_i, thr_q, t0): encoder fused into the layer kernel
                 iq, thr_i, thr_q, t0 = inp
                 spk, pv, _ = ops.conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, i2h.weight, i2h.bias, tau4, st.eps0,
-                                                      st.eps1, arp, T, B, want_spikes=want_spikes, out=buffers)
+                                                      st.eps1, arp, T, B, want_spikes=want_spikes, want_pv=want_pv,
+                                                      out=buffers)
                 return spk, pv, None
             if fuse_readout:
                 Wp, rb = self.fused_readout_weights()
@@ -451,7 +453,7 @@ class Conv2dDCLLlayer(nn.Module):
                                                           ro_Wp=Wp, ro_b=rb)
                 return spk, None, logits
             spk, pv, _ = ops.conv_lif_sequence(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp, T, B,
-                                               want_spikes=want_spikes, out=buffers)
+                                               want_spikes=want_spikes, want_pv=want_pv, out=buffers)
         return spk, pv, None
 
 

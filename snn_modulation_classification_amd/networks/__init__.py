@@ -125,7 +125,7 @@ class ConvNetwork(torch.nn.Module):
 
     @torch.no_grad()
     def test_sequence(self, cells=None, collect=True, profile=None, fuse_readout=False, iq=None, encoder=None,
-                      T=None, t0=None):
+                      T=None, t0=None, output_only=False):
         """Equivalent of `for t in range(T): net.test(x[t])` for input given as cell indices (T,B) int32 on device
         (one input spike per sample per step, what iq2spiketrain produces), or as the raw IQ batch `iq` (B,2,L) with an
         `IQEncoder` — then the quantisation runs inside the first layer's kernel (T steps from sample t0; t0 drawn
@@ -136,6 +136,10 @@ class ConvNetwork(torch.nn.Module):
         the pv round trip through HBM: 124 vs 113 ms per layer launch at B=4096), hence off by default.
         `profile`: optional dict; (start, end) torch.cuda.Event pairs of every launch are appended under
         'lif_c1' / 'lif_c32' / 'readout' / 'vote' (events live on the current stream = the launch stream).
+
+        `output_only` (serving mode, no reference counterpart): only the output layer's prediction is wanted, so the
+        hidden layers neither materialise pv nor run their local readouts (their entries in the result are None and
+        their `clout` is left untouched) — the spike trains and the output layer's logits / votes are unchanged.
 
         Returns a dict with device tensors: 'logits' (per layer, (T,B,target); last entry = output_ layer),
         'clout' (per layer (T,B) int32) and 'vote' (per layer (B) int32)."""
@@ -166,21 +170,25 @@ class ConvNetwork(torch.nn.Module):
                 parts.append(self._sequence_chunk(
                     (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None
                     else cells[:, b0:b1].contiguous(),
-                    'iq' if iq is not None else 'cells', T, b1 - b0, dev, profile, fuse_readout, batch_slice=b0))
-            res = dict(logits=[torch.cat([p['logits'][i] for p in parts], 1) for i in range(self.num_layers)],
-                       clout=[torch.cat([p['clout'][i] for p in parts], 1) for i in range(self.num_layers)],
-                       vote=[torch.cat([p['vote'][i] for p in parts], 0) for i in range(self.num_layers)])
+                    'iq' if iq is not None else 'cells', T, b1 - b0, dev, profile, fuse_readout, batch_slice=b0,
+                    output_only=output_only))
+            cat = lambda key, dim: [None if parts[0][key][i] is None else torch.cat([p[key][i] for p in parts], dim)
+                                    for i in range(self.num_layers)]
+            res = dict(logits=cat('logits', 1), clout=cat('clout', 1), vote=cat('vote', 0))
             if 'o' in parts[0]:
                 res['o'] = torch.cat([p['o'] for p in parts], 1)
         else:
             res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None else cells,
-                                       'iq' if iq is not None else 'cells', T, B, dev, profile, fuse_readout)
+                                       'iq' if iq is not None else 'cells', T, B, dev, profile, fuse_readout,
+                                       output_only=output_only)
         if collect:
             for i, s in enumerate(self.dcll_slices):
-                s.set_sequence_result(res['clout'][i], T)
+                if res['clout'][i] is not None:
+                    s.set_sequence_result(res['clout'][i], T)
         return res
 
-    def _sequence_chunk(self, first_input, first_kind, T, B, dev, profile, fuse_readout, batch_slice=None):
+    def _sequence_chunk(self, first_input, first_kind, T, B, dev, profile, fuse_readout, batch_slice=None,
+                        output_only=False):
         """All layers over all T steps for B samples (the whole batch, or rows batch_slice.. of every layer's state)."""
         for s in self.dcll_slices:
             i2h = s.dclllayer.i2h
@@ -204,10 +212,18 @@ class ConvNetwork(torch.nn.Module):
             L = s.dclllayer
             last = (i == self.num_layers - 1)
             fused = fuse_readout and i > 0
+            hidden_skip = output_only and not last
             spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B,
                                 first_kind if i == 0 else 'packed', want_spikes=not last,
                                 buffers=dict(spk=buf['spk'][i & 1], pv=buf['pv'], ro=buf['ro'][i]),
-                                fuse_readout=fused, batch_slice=batch_slice)
+                                fuse_readout=fused and not hidden_skip, batch_slice=batch_slice,
+                                want_pv=not hidden_skip)
+            if hidden_skip:
+                res['logits'].append(None)
+                res['clout'].append(None)
+                res['vote'].append(None)
+                cur = spk
+                continue
             if fused:
                 # readout(s) came out of the layer kernel's epilogue: (T,B,24) or, on the output layer, (T,B,48)
                 p = ro[..., :self.target_size]

@@ -143,6 +143,27 @@ def test_sequence_path_on_large_planes(R_, T, B):
             assert np.array_equal(np.array(a.dcll_slices[i].clout), np.array(b.dcll_slices[i].clout))
 
 
+def test_sequence_output_only_mode():
+    """test_sequence(output_only=True): hidden layers skip pv + local readouts; the output layer's logits, argmax and
+    votes and every layer's state are identical to the full run (incl. a chunked batch)."""
+    rng = np.random.RandomState(12)
+    T, B = 16, 9
+    cells = torch.from_numpy(rng.randint(0, 256, size=(T, B)).astype(np.int32)).cuda()
+    a, b, c = _radio_net(B, 16), _radio_net(B, 16), _radio_net(B, 16)
+    c.pv_budget_bytes = 4 * T * 32 * 256 * 4
+    ra = a.test_sequence(cells)
+    for net in (b, c):
+        net.reset()
+        r = net.test_sequence(cells, output_only=True)
+        assert r["logits"][0] is None and r["clout"][1] is None and r["vote"][0] is None
+        assert torch.equal(r["clout"][2], ra["clout"][2]) and torch.equal(r["vote"][2], ra["vote"][2])
+        assert torch.equal(r["o"], ra["o"]) and torch.equal(r["logits"][2], ra["logits"][2])
+        for i in range(3):
+            for name in ("eps0", "eps1", "arp"):
+                assert torch.equal(getattr(a.dcll_slices[i].dclllayer.i2h.state, name),
+                                   getattr(net.dcll_slices[i].dclllayer.i2h.state, name))
+
+
 def test_sequence_path_chunks_large_batches():
     """A batch whose pv buffer would exceed net.pv_budget_bytes runs in chunks (what makes the default 128x128 plane
     with batch_size_test 512 fit): identical results and state to the unchunked run, incl. a ragged last chunk."""
