@@ -132,6 +132,11 @@ def main():
     ap.add_argument("--output-only", type=int, default=0,
                     help="1: serving mode — hidden layers skip pv and their local readouts (NOT the headline workload)")
     a = ap.parse_args()
+    if a.gpus > 1 and not parallel.under_launcher():
+        # started plainly (`python bench.py --gpus N`): this process becomes the launcher of N fresh rank processes and
+        # never touches the GPU itself; rank 0's JSON line goes straight to our stdout.  Under torchrun the ranks
+        # arrive here with RANK / WORLD_SIZE set and fall through.
+        sys.exit(parallel.spawn_local_ranks(a.gpus))
     global R
     R = a.plane
     if a.batch is None:
@@ -141,7 +146,7 @@ def main():
     hot_kernel = "k_lif_seq_c32d" if R == 16 else "k_lif_seq_c32t"
 
     rank, local_rank, world = parallel.init_process_group()
-    assert world == a.gpus, "launch with torchrun --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
+    assert world == a.gpus, "torchrun --nproc-per-node must equal --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     dev = torch.device("cuda", parallel.local_device(local_rank))
     torch.cuda.set_device(dev)
@@ -166,14 +171,13 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        parallel.barrier()
         torch.cuda.synchronize()
 
     net._sequence_buffers(T_STEPS, min(B, max(1, int(net.pv_budget_bytes // (4 * T_STEPS * 32 * R * R)))), dev)  # allocate once, outside the timed region
     if world > 1:
         # create the RCCL communicator now (lazy otherwise: it would land in the first step, timed when --warmup 0)
-        dist.all_reduce(torch.zeros(1, device=dev))
+        parallel.all_reduce_(torch.zeros(1, device=dev))
         torch.cuda.synchronize()
     log("rank %d/%d: network built, B=%d per GPU" % (rank, world, B))
     for _ in range(a.warmup):
@@ -188,7 +192,7 @@ def main():
     log("timed region done: %.3f s for %d steps" % (dt, a.steps))
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # dominant kernel: HIP-event time of every k_lif_seq_c32d launch of the timed region (same stream as the launch)
@@ -200,19 +204,22 @@ def main():
     # HBM bytes of the dominant kernel: PMC counters cannot be read from inside this process; the committed summary of
     # the separate `rocprofv3 --pmc` passes of this same command (profiles/r01_pmc_b4096.json) is used when the batch
     # matches, else null.
-    traffic = None
-    try:
-        if R == 16:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_b4096.json")) as f:
+    traffic, traffic_src = None, None
+    for name in (("r02_pmc_b%d.json" % B, "r01_pmc_b%d.json" % B) if R == 16 else ("r02_pmc_plane%d_b%d.json" % (R, B),
+                                                                                  "r01_pmc_plane%d_b%d.json" % (R, B))):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
-            if pmc.get("k_lif_seq_c32_batch") == B:
+            if R == 16:
+                if pmc.get("k_lif_seq_c32_batch") != B:
+                    continue
                 traffic = pmc["k_lif_seq_c32_traffic_bytes_per_launch"]
-        elif R == 128 and B == 64:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_plane128_b64.json")) as f:
-                pmc = json.load(f)
-            traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if k.startswith("k_lif_seq_c32t")][0]
-    except (OSError, ValueError, KeyError, IndexError):
-        pass
+            else:
+                traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if k.startswith("k_lif_seq_c32t")][0]
+            traffic_src = "profiles/%s (builder-side rocprofv3 --pmc passes of this command; not measured in this run)" % name
+            break
+        except (OSError, ValueError, KeyError, IndexError):
+            continue
     kernel_ms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in prof.items()}
     if len(c32_ms) >= 2:        # the two 32->32 layers of a step (the output layer carries a second readout)
         kernel_ms["lif_c32_layer1"] = float(np.mean(c32_ms[0::2]))
@@ -230,10 +237,13 @@ def main():
                                    (R, R, B, (" (north_star headline batch)" if (B == 4096 and R == 16) else "") +
                                     (", OUTPUT-ONLY serving mode (hidden-layer readouts skipped)" if a.output_only else "")),
                        "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [R, R],
-                       "parallelism": "batch shards, %d rank(s), tally all-reduce only" % world},
+                       "parallelism": "batch shards, %d rank(s) on %d GPU(s)%s, tally all-reduce only (backend %s)" %
+                                      (world, min(world, torch.cuda.device_count()),
+                                       " — REHEARSAL: ranks share a device" if world > torch.cuda.device_count() else "",
+                                       dist.get_backend() if world > 1 else "none")},
             "roofline": {"kernel": hot_kernel, "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)",
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)",
                          "avg_launch_ms": avg_c32_s * 1e3, "launches": len(c32_ms),
                          "algorithmic_flop_per_launch": flop_per_launch,
                          "hbm": {"achieved_GBps": (traffic / avg_c32_s / 1e9) if traffic else None,

@@ -66,13 +66,9 @@ SIGNATURES = {
 
 
 def build(force=False):
-    """Compile csrc/dcll_hip.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    src = os.path.join(CSRC, "dcll_hip.hip")
-    hdr = os.path.join(os.path.dirname(_PKG), "include", "dcll_hip.h")
-    stale = (not os.path.exists(SO_PATH)) or any(
-        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(SO_PATH) for f in (src, hdr))
-    if force or stale:
-        subprocess.check_call(["make", "-s", "-B", "-C", CSRC])
+    """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU).  `make` decides what is stale from
+    its dependency rules (every source, dcll_internal.h, the ABI header, the Makefile itself); force=True rebuilds all."""
+    subprocess.check_call(["make", "-s", "-C", CSRC] + (["-B"] if force else []))
     return SO_PATH
 
 

@@ -43,9 +43,9 @@ def _mode_first_seen(row):
 
 def _clout_to_numpy(pvoutput):
     """clout as a (T,B) integer array; entries may be numpy arrays or (device) tensors appended without a sync."""
-    if len(pvoutput) and isinstance(pvoutput[0], torch.Tensor):
+    if len(pvoutput) and all(isinstance(c, torch.Tensor) for c in pvoutput):
         return torch.stack(list(pvoutput)).cpu().numpy()
-    return np.asarray(pvoutput)
+    return np.asarray([c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in pvoutput])
 
 
 def get_predictions_by_vote(pvoutput, labels):
@@ -69,6 +69,14 @@ def _as_pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+def _check_act(act):
+    """Every kernel computes pv = sigmoid(v) (and the backward its derivative): any other activation would silently
+    give wrong pv and gradients, so it is refused here (the reference's callers only ever pass nn.Sigmoid())."""
+    if not isinstance(act, nn.Sigmoid):
+        raise NotImplementedError('the HIP kernels implement act = nn.Sigmoid() only, got %r' % (act,))
+    return act
+
+
 class ContinuousConv2D(nn.Module):
     """Two leaky traces on the input + conv + threshold / sigmoid (reference :296-429)."""
     NeuronState = namedtuple('NeuronState', ('eps0', 'eps1'))
@@ -85,7 +93,7 @@ class ContinuousConv2D(nn.Module):
         self.padding = _as_pair(padding)
         self.stride, self.dilation, self.groups = stride, dilation, groups
         self.random_tau = random_tau
-        self.act = act
+        self.act = _check_act(act)
         self.spiking = spiking
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
         if bias:
@@ -473,7 +481,7 @@ class CLLDenseModule(nn.Module):
         else:
             self.register_parameter('bias', None)
         self.reset_parameters()
-        self.act = act
+        self.act = _check_act(act)
         self.random_tau = random_tau
         self._set_tau(torch.Tensor([alpha]), torch.Tensor([alphas]))
         self.spiking = spiking
@@ -615,8 +623,13 @@ class DCLLBase(nn.Module):
     def clout(self):
         """Per-step argmax of the slice as the reference keeps it: a list of T numpy arrays (B,).  Internally the
         entries stay on the device until somebody looks (one transfer instead of one sync per timestep)."""
-        if self._clout and isinstance(self._clout[0], torch.Tensor):
-            self._clout = list(torch.stack(self._clout).cpu().numpy())
+        if any(isinstance(c, torch.Tensor) for c in self._clout):
+            # device entries (appended without a sync, possibly after an earlier look converted the older ones):
+            # one stacked transfer for all of them
+            idx = [k for k, c in enumerate(self._clout) if isinstance(c, torch.Tensor)]
+            host = torch.stack([self._clout[k].to(torch.int64) for k in idx]).cpu().numpy()
+            for k, row in zip(idx, host):
+                self._clout[k] = row
         return self._clout
 
     @clout.setter
@@ -688,7 +701,8 @@ class DCLLBase(nn.Module):
                 loss = tgt_loss
             loss.backward()
             from .. import parallel
-            parallel.allreduce_mean_grads(p for p in self.dclllayer.parameters() if p.grad is not None)
+            parallel.allreduce_mean_grads([p for p in self.dclllayer.parameters() if p.grad is not None],
+                                          local_n=input.shape[0])
             if do_train:
                 self.optimizer.step()
                 if self.dclllayer.output_layer:
@@ -710,7 +724,7 @@ class DCLLClassification(DCLLBase):
     def set_sequence_result(self, clout_dev, n_steps):
         """Install the per-step argmax of a whole-sequence run ((T,B) int32 on device) as `clout`."""
         self.iter += n_steps
-        self._clout = list(clout_dev.to(torch.int64))
+        self._clout.extend(clout_dev.to(torch.int64))       # like n_steps calls of forward(): appended, not replaced
 
     def write_stats(self, writer, label, epoch):
         super().write_stats(writer, label, epoch)

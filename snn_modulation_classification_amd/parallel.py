@@ -1,11 +1,20 @@
 """Batch sharding over the GPUs of one node.
 
 The DCLL forward path has no cross-sample operation, so every rank (one process per GPU) runs the full network on
-a contiguous shard of the batch with replicated weights and NO data-path collective.  The only exchange is the
-aggregation of per-class tallies at the end of an evaluation — one small all-reduce (RCCL over xGMI on GPUs, gloo in
-the CPU tests): confusion matrix [pred, label] + (correct, total) counters per layer.
+a contiguous shard of the batch with replicated weights and NO data-path collective.  The only exchanges are
+  - evaluation: one small all-reduce of per-class tallies (confusion matrix [pred, label] + (correct, total) per layer);
+  - local learning: one all-reduce per timestep of the gradients of all slices in ONE flat bucket.
+RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests and in rehearsals where several ranks share one GPU
+(DCLL_DIST_BACKEND=gloo: device tensors are staged through the host, RCCL refuses two ranks on one device).
+
+`spawn_local_ranks` is the launcher of the entry points (`bench.py --gpus N`, `test_radio_ml.py --gpus N`,
+`train.py --gpus N`) when they are started plainly instead of under torchrun: the parent never touches the GPU.
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -15,6 +24,11 @@ def env_ranks():
     """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when launched plainly."""
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
             int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def under_launcher():
+    """True if this process was started as one rank of a job (torchrun or spawn_local_ranks)."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
 def local_device(local_rank):
@@ -38,8 +52,46 @@ def init_process_group(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_device(local_rank))
             kw["device_id"] = torch.device("cuda", local_device(local_rank))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        if backend == "gloo":
+            # gloo announces its connections with a printf on stdout; stdout is reserved for the job's report (rank 0's
+            # one JSON line), so fd 1 points at stderr while the group forms
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+                dist.barrier()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def all_reduce_(t, op=None):
+    """In-place all-reduce of `t` over the ranks (no-op for a single process).  Under the gloo rehearsal backend a
+    device tensor is staged through the host (gloo's device support is not relied upon); under RCCL it is reduced
+    where it lives."""
+    if not is_distributed():
+        return t
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=op)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def barrier():
+    if is_distributed():
+        dist.barrier()
 
 
 def shard_range(total, rank, world):
@@ -63,9 +115,7 @@ def tallies(votes, labels, n_classes):
 
 def allreduce_tallies(t):
     """Sum the tallies of all shards (no-op for a single process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
+    return all_reduce_(t)
 
 
 def split_tallies(t, n_classes):
@@ -75,18 +125,89 @@ def split_tallies(t, n_classes):
     return cm, acc
 
 
-def allreduce_mean_grads(params):
-    """Average .grad over the ranks (the local losses are means over the LOCAL batch, so the global-batch gradient is
-    the mean of the shard gradients for equal shards).  One flat all-reduce per call; no-op for a single process."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+def allreduce_mean_tensors(tensors, local_n=None):
+    """Replace every tensor (the gradients of local mean losses) by its global-batch value: ONE flat bucket, one
+    all-reduce.  With `local_n` (samples of this rank's shard) the shards are weighted by their size, so ragged shards
+    give exactly the mean over the global batch; without it the shards are taken to be equal.  No-op for one process."""
+    tensors = [t for t in tensors if t is not None]
+    if not is_distributed() or not tensors:
         return
-    grads = [p.grad for p in params]
-    if not grads:
-        return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= dist.get_world_size()
+    w = float(local_n) if local_n is not None else 1.0
+    flat = torch.cat([t.reshape(-1) for t in tensors] + [torch.ones(1, device=tensors[0].device, dtype=tensors[0].dtype)])
+    flat *= w
+    all_reduce_(flat)
+    flat /= flat[-1].clone()
     off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+
+
+def allreduce_mean_grads(params, local_n=None):
+    """Average .grad over the ranks (the local losses are means over the LOCAL batch, so the global-batch gradient is
+    the shard-size-weighted mean of the shard gradients).  One flat all-reduce per call; no-op for a single process."""
+    allreduce_mean_tensors([p.grad for p in params], local_n)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_local_ranks(n, argv=None, timeout=None):
+    """Start `n` fresh processes of the running script (one rank per GPU of this node) with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, wait for them and return the exit code (0 iff every rank exited 0).
+    Rank 0 inherits stdout (its one JSON line / report is the job's output); the other ranks' stdout goes to stderr.
+    The CALLER must not have initialised the GPU: it only launches and waits (never re-execs).  If the node has fewer
+    GPUs than ranks the job is a rehearsal: ranks share GPUs and the backend falls to gloo unless DCLL_DIST_BACKEND
+    says otherwise."""
+    argv = list(sys.argv if argv is None else argv)
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n_dev = torch.cuda.device_count()           # does not initialise the GPU
+    if n_dev < n and "DCLL_DIST_BACKEND" not in env:
+        env["DCLL_DIST_BACKEND"] = "gloo"
+        print("[launcher] %d ranks on %d GPU(s): rehearsal, ranks share devices, backend gloo" % (n, n_dev),
+              file=sys.stderr, flush=True)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable] + argv, env=e, stdout=None if r == 0 else sys.stderr))
+    t0 = time.time()
+    rc = 0
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("[launcher] rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr,
+                          flush=True)
+            if rc != 0 or (timeout is not None and time.time() - t0 > timeout):
+                if rc == 0:
+                    rc = 124
+                break
+            if live:
+                time.sleep(0.1)
+    finally:
+        for r in live:                          # exact PIDs of the children this call started
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    return rc

@@ -19,6 +19,7 @@ import time
 import numpy as np
 import torch
 
+from snn_modulation_classification_amd import parallel
 from snn_modulation_classification_amd.data.utils import IQEncoder, iq2spiketrain, to_one_hot
 from snn_modulation_classification_amd.dcll import pytorch_libdcll
 from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
@@ -65,6 +66,8 @@ def parse_args(argv=None):
     p.add_argument('--no_sequence_path', action='store_true', help='force the per-step path (net.test per timestep)')
     p.add_argument('--min_snr', type=int, default=6, metavar='N', help='first SNR evaluated (reference: fixed 6)')
     p.add_argument('--max_snr', type=int, default=30, metavar='N', help='last SNR evaluated (reference: fixed 30)')
+    p.add_argument('--gpus', type=int, default=1, metavar='N',
+                   help='ranks (one process per GPU): every test batch is sharded over them, tallies are all-reduced')
     return p.parse_args(argv)
 
 
@@ -104,8 +107,19 @@ def load_batches(args, snr, n_batches):
 
 
 def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
-    """One batch through all timesteps; returns (per-layer accuracy list, confusion matrix of the last layer)."""
+    """One batch through all timesteps; returns (per-layer accuracy list, confusion matrix of the last layer).
+    Under several ranks every rank evaluates its contiguous shard of the batch (no data-path collective: samples are
+    independent) and the per-layer correct counts + the confusion matrix are summed over the ranks."""
     T = args.n_iters_test
+    rank, _, world = parallel.env_ranks()
+    if world > 1:
+        lo, hi = parallel.shard_range(samples.shape[0], rank, world)
+        samples, labels1h = samples[lo:hi], labels1h[lo:hi]
+        net.batch_size = hi - lo
+        if hi == lo:                                    # more ranks than samples: this rank only joins the reduction
+            tal = torch.zeros(len(net.dcll_slices) + 1 + TARGET_SIZE * TARGET_SIZE, dtype=torch.int64)
+            parallel.all_reduce_(tal)
+            return _split_eval_tally(tal, len(net.dcll_slices))
     if use_sequence:
         targets = labels1h.unsqueeze(0).repeat(T, 1, 1)
         net.reset()
@@ -126,24 +140,53 @@ def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
         for t in range(T):
             net.test(x=test_input[t])
     targets = torch.as_tensor(np.asarray(targets), dtype=torch.float32)
-    return net.accuracy(targets), net.confusion_matrix(targets)
+    acc, cm = net.accuracy(targets), net.confusion_matrix(targets)
+    if world > 1:
+        n = samples.shape[0]
+        tal = torch.tensor([int(round(a * n)) for a in acc] + [n] + [int(v) for v in np.asarray(cm).reshape(-1)],
+                           dtype=torch.int64)
+        parallel.all_reduce_(tal)
+        return _split_eval_tally(tal, len(acc))
+    return acc, cm
+
+
+def _split_eval_tally(tal, n_layers):
+    """[correct per layer..., total, confusion matrix...] summed over the ranks -> (accuracies, confusion matrix)"""
+    total = max(int(tal[n_layers]), 1)
+    acc = [float(tal[i]) / total for i in range(n_layers)]
+    cm = tal[n_layers + 1:].reshape(TARGET_SIZE, TARGET_SIZE).numpy().astype(int)
+    return acc, cm
 
 
 def main(argv=None):
     args = parse_args(argv)
+    if args.gpus > 1 and not parallel.under_launcher():
+        # plain start: become the launcher of one fresh process per rank (never touches the GPU itself)
+        return sys.exit(parallel.spawn_local_ranks(args.gpus, argv=[os.path.abspath(__file__)] +
+                                                   (sys.argv[1:] if argv is None else list(argv))))
+    rank, local_rank, world = parallel.init_process_group()
+    if world > 1 and torch.cuda.is_available():
+        pytorch_libdcll.device = 'cuda:%d' % parallel.local_device(local_rank)
+        torch.cuda.set_device(parallel.local_device(local_rank))
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     out_dir = args.out_dir or (os.path.dirname(args.restore_path) if args.restore_path else '.')
     os.makedirs(out_dir or '.', exist_ok=True)
-    with open(os.path.join(out_dir, 'snr_evaluation.txt'), 'a+') as logfile:
+    # every rank evaluates its shard; rank 0 alone reports and writes the result files
+    with open(os.path.join(out_dir, 'snr_evaluation.txt') if rank == 0 else os.devnull, 'a+') as logfile:
         def say(text):
+            if rank != 0:
+                return
             print(text)
             logfile.write(text + '\n')
 
         im_dims = (1, args.Q_resolution, args.I_resolution)
         n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
         convs = load_network_spec(args.network_spec)
-        net = ConvNetwork(args, im_dims, args.batch_size_test, convs, TARGET_SIZE, act=torch.nn.Sigmoid(), loss=None,
+        # the network is sized for this rank's shard of a test batch (identical weights / time constants on every
+        # rank: their RNG draws do not depend on the batch size)
+        lo, hi = parallel.shard_range(args.batch_size_test, rank, world)
+        net = ConvNetwork(args, im_dims, max(hi - lo, 1), convs, TARGET_SIZE, act=torch.nn.Sigmoid(), loss=None,
                           opt=None, opt_param={}, learning_rates=None, burnin=args.burnin)
         if args.restore_path:
             say('-' * 80)
@@ -178,21 +221,28 @@ def main(argv=None):
             if args.print_all_confusion_matrices:
                 say('Confusion matrix:')
                 say(np.array2string(cm, max_line_width=300))
-            np.save(os.path.join(out_dir, 'confusion_matrix_snr_%d.npy' % snr), cm)
+            if rank == 0:
+                np.save(os.path.join(out_dir, 'confusion_matrix_snr_%d.npy' % snr), cm)
             accs.append(acc)
             total_cm += cm
         say('---\nTotal confusion matrix:')
         say(np.array2string(total_cm, max_line_width=300))
         npy_out = os.path.join(out_dir, 'snr_evaluation_accs.npy')
-        np.save(npy_out, accs)
+        if rank == 0:
+            np.save(npy_out, accs)
         say('Wrote `%s`.' % npy_out)
         try:                                  # plots are optional extras of the reference (:170-188)
+            if rank != 0:
+                raise RuntimeError('rank 0 writes the plots')
             import matplotlib
             matplotlib.use('Agg')
             import matplotlib.pyplot as plt
             plt.imsave(os.path.join(out_dir, 'total_confusion_matrix.png'), total_cm, cmap='gray')
         except Exception:
             pass
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
     return accs
 
 

@@ -1,0 +1,99 @@
+"""The HIP path under more than one rank, rehearsed on ONE GPU: two fresh child processes share cuda:0 (backend gloo,
+DCLL_DIST_BACKEND — RCCL refuses two ranks on one device), each runs the real network on its shard_range of the batch.
+What 8(e) promises is asserted: sharding changes no per-sample result, the all-reduced tallies equal the single-process
+tallies, and a local-learning run with the per-timestep gradient all-reduce equals the full-batch run.
+Also: `bench.py --gpus 2` started plainly launches its own ranks and prints one JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "rank_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(out_dir, world, B, T, timeout=900):
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:
+        r = subprocess.run([sys.executable, WORKER, out_dir, str(B), str(T)], env=base, timeout=timeout,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DCLL_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, WORKER, out_dir, str(B), str(T)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, se[-3000:])
+
+
+@pytest.mark.timeout(1500)
+def test_two_ranks_sharing_one_gpu_equal_the_single_process_run(tmp_path):
+    B, T = 1024, 128
+    out = str(tmp_path)
+    _run_ranks(out, 1, B, T)
+    _run_ranks(out, 2, B, T)
+    full = np.load(os.path.join(out, "rank_0_of_1.npz"))
+    parts = [np.load(os.path.join(out, "rank_%d_of_2.npz" % r)) for r in range(2)]
+    assert (int(parts[0]["lo"]), int(parts[0]["hi"]), int(parts[1]["lo"]), int(parts[1]["hi"])) == (0, 512, 512, 1024)
+    # evaluation: concatenated per-rank results == the single-process run, bit for bit; tallies equal on every rank
+    for i in range(3):
+        for key in ("clout%d", "host_clout%d"):
+            assert np.array_equal(np.concatenate([p[key % i] for p in parts], axis=1), full[key % i]), key % i
+        assert np.array_equal(np.concatenate([p["vote%d" % i] for p in parts]), full["vote%d" % i])
+    assert np.array_equal(np.concatenate([p["o"] for p in parts], axis=1).view(np.uint32), full["o"].view(np.uint32))
+    for p in parts:
+        assert np.array_equal(p["tallies"], full["tallies"])
+    assert int(full["tallies"][0, -1]) == B and full["tallies"].shape == (3, 24 * 24 + 2)
+    # learning: both ranks hold the same parameters, and they equal the full-batch run (sums in another order)
+    for key in ["w0", "w1", "w2", "b0", "b1", "b2", "ow", "ob"]:
+        assert np.array_equal(parts[0][key], parts[1][key]), key
+    for key in ["g0_w0", "g0_w1", "g0_w2", "g0_b0", "g0_b1", "g0_b2", "g0_ow"]:
+        assert np.array_equal(parts[0][key], parts[1][key]), key
+        ref = full[key]
+        np.testing.assert_allclose(parts[0][key], ref, rtol=2e-3, atol=1e-5 * np.abs(ref).max(), err_msg=key)
+    for key in ["w0", "w1", "w2", "b0", "b1", "b2", "ow", "ob"]:
+        ref = full[key]
+        np.testing.assert_allclose(parts[0][key], ref, rtol=0, atol=2e-3 * np.abs(ref).max(), err_msg=key)
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two ranks before touching the GPU and
+    relays rank 0's single JSON line (on this 1-GPU box the ranks share the device and fall to gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "256"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 512
+    assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out
+    assert "cpu_baseline" not in out            # rank 0 at N = 1 only

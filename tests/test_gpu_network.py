@@ -252,12 +252,12 @@ def test_config5_int8_weights_and_packed_spikes():
     net.reset()
     for t in range(4):
         x = (rng.uniform(size=(B, 1, H, W)) < 0.05).astype(np.float32)
-        outs = orc.step(x)
+        outs = orc.step(x, want_v=True)
         cur = torch.from_numpy(x).cuda()
         for i, s in enumerate(net.dcll_slices):
             o, p, pv, v = s.forward(cur, ignore_burnin=True)
-            if outs[i]["v"] is not None:
-                assert np.array_equal(v.cpu().numpy().view(np.uint32), outs[i]["v"].view(np.uint32)), (t, i)
+            assert outs[i]["v"] is not None
+            assert np.array_equal(v.cpu().numpy().view(np.uint32), outs[i]["v"].view(np.uint32)), (t, i)
             np.testing.assert_allclose(p.cpu().numpy(), outs[i]["p"], atol=LOGIT_TOL, rtol=0)
             if i < 6:
                 assert np.array_equal(o.cpu().numpy(), outs[i]["s"]), (t, i)
@@ -566,12 +566,12 @@ def test_ref_yaml_network_on_128_plane_per_step():
     net.reset()
     for t in range(4):
         x = (rng.uniform(size=(B, 1, H, W)) < 0.05).astype(np.float32)
-        outs = orc.step(x)
+        outs = orc.step(x, want_v=True)
         cur = torch.from_numpy(x).cuda()
         for i, s in enumerate(net.dcll_slices):
             o, p, pv, v = s.forward(cur, ignore_burnin=True)
-            assert np.array_equal(v.cpu().numpy().view(np.uint32), outs[i]["v"].view(np.uint32) if outs[i]["v"] is not None
-                                  else v.cpu().numpy().view(np.uint32))
+            assert outs[i]["v"] is not None
+            assert np.array_equal(v.cpu().numpy().view(np.uint32), outs[i]["v"].view(np.uint32)), (t, i)
             np.testing.assert_allclose(p.cpu().numpy(), outs[i]["p"], atol=LOGIT_TOL, rtol=0)
             if i < 6:
                 assert np.array_equal(o.cpu().numpy(), outs[i]["s"]), (t, i)

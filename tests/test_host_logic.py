@@ -297,6 +297,23 @@ def test_classification_slice_bookkeeping(cpu_device):
         s.train_dcll(torch.zeros(3, 1, 8, 8), y[0])
     s.init(3, init_states=False)
     assert s.iter == 0 and s.clout == []
+    # a sequence result is APPENDED like T calls of forward() (reference :724-728), also after somebody looked at clout
+    s.set_sequence_result(torch.tensor([[0, 1, 2]], dtype=torch.int32), 1)
+    assert len(s.clout) == 1 and isinstance(s.clout[0], np.ndarray)
+    s.set_sequence_result(torch.tensor([[4, 4, 4], [3, 3, 3]], dtype=torch.int32), 2)
+    assert s.iter == 3 and len(s._clout) == 3
+    assert [c.tolist() for c in s.clout] == [[0, 1, 2], [4, 4, 4], [3, 3, 3]]
+    assert L.get_predictions_by_vote(s.clout, y)[0].shape == (3,)
+
+
+def test_non_sigmoid_activation_is_refused(cpu_device):
+    """Every kernel hard-codes sigmoid: another `act` must fail loudly instead of giving wrong pv / gradients."""
+    L = cpu_device
+    with pytest.raises(NotImplementedError):
+        L.Conv2dDCLLlayer(1, 4, kernel_size=3, padding=1, pooling=1, im_dims=(8, 8), target_size=5, act=torch.nn.ReLU())
+    with pytest.raises(NotImplementedError):
+        L.DenseDCLLlayer(8, 4, target_size=5, act=torch.nn.Tanh())
+    L.Conv2dDCLLlayer(1, 4, kernel_size=3, padding=1, pooling=1, im_dims=(8, 8), target_size=5, act=torch.nn.Sigmoid())
 
 
 # ---------------------------------------------------------------------------------------------- entry points

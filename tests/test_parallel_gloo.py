@@ -99,3 +99,68 @@ def test_two_rank_gradient_mean(tmp_path):
     p.grad = torch.ones(2)
     parallel.allreduce_mean_grads([p])
     assert p.grad.tolist() == [1.0, 1.0]
+
+
+def _ragged_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_process_group(backend="gloo")
+    # rank r holds n_r = 3 + 2r samples whose per-sample "gradient" is the sample index: local mean, as a local loss gives
+    n = 3 + 2 * rank
+    start = sum(3 + 2 * r for r in range(rank))
+    g = [torch.tensor([float(np.mean(np.arange(start, start + n)))]), torch.full((2, 2), float(rank))]
+    parallel.allreduce_mean_tensors(g, local_n=n)
+    np.save(os.path.join(out_dir, "r_%d.npy" % rank), np.concatenate([t.reshape(-1).numpy() for t in g]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gradient_mean_with_ragged_shards(tmp_path):
+    """Shards of different sizes: the bucket is weighted by the shard size, so the result is the global-batch mean."""
+    port = _free_port()
+    mp.spawn(_ragged_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    expect = np.concatenate([[np.mean(np.arange(8))], np.full(4, 5.0 / 8.0)])       # 3 + 5 samples
+    for rank in range(2):
+        assert np.allclose(np.load(os.path.join(str(tmp_path), "r_%d.npy" % rank)), expect)
+
+
+_LAUNCHED = '''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from snn_modulation_classification_amd import parallel
+if len(sys.argv) > 2 and not parallel.under_launcher():
+    sys.exit(parallel.spawn_local_ranks(int(sys.argv[2])))
+rank, local_rank, world = parallel.init_process_group(backend="gloo")
+t = torch.tensor([float(rank + 1)])
+parallel.all_reduce_(t)
+if sys.argv[1] == "fail" and rank == 1:
+    sys.exit(7)
+if rank == 0:
+    print('{"world": %%d, "sum": %%g}' %% (world, float(t)))
+else:
+    print("noise from rank", rank)
+parallel.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(180)
+def test_launcher_starts_ranks_and_relays_rank0(tmp_path):
+    """`python script.py ... N` started plainly becomes the launcher of N fresh rank processes (what bench.py --gpus N
+    does): rank 0's stdout is the job's stdout, a failing rank fails the job."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "job.py"
+    script.write_text(_LAUNCHED % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(script), "ok", "3"], capture_output=True, text=True, env=env, timeout=150)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"world": 3, "sum": 6.0}
+    assert "noise from rank" in r.stderr
+    r = subprocess.run([sys.executable, str(script), "fail", "2"], capture_output=True, text=True, env=env, timeout=150)
+    assert r.returncode == 7
