@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCLL_ABI_VERSION 1
+#define DCLL_ABI_VERSION 2
 
 enum {
     DCLL_OK = 0,
@@ -132,11 +132,19 @@ int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W
  *   fused local readout (n_ro = 24 or 48; 0 = none): ro_out (T,B,n_ro) = flatten(pv) . Wro^T + ro_b, i.e. i2o and,
  *   stacked behind it on the output layer, output_ (:602-606), computed in the epilogue so that pv never leaves the
  *   chip.  ro_Wp = the (n_ro, c_out*h*w) weight matrix re-laid-out by dcll_permute_readout; ro_b (n_ro).
+ *   state_scratch  2*B*c_in*h*w floats, REQUIRED on planes other than 16x16 (may be NULL on 16x16): the tiled kernels
+ *                  read a tile's initial traces plus a halo owned by neighbouring tiles, so the launch first snapshots
+ *                  eps0 / eps1 there (stream-ordered copies), reads only the snapshot and writes only eps0 / eps1.
+ *   pv_lowhigh     NULL = off.  Else uint64 [n][2], n = dcll_pv_lowhigh_steps(iter0, T): for every step t of this call
+ *                  with (iter0 + t + 1) % 20 == 0 — DCLLBase.forward's histogram steps, :658-661 — the number of pv
+ *                  values in the first and in the last of the 19 bins of np.linspace(0, 1, 20) (what write_stats
+ *                  reports, :678-688).  iter0 = the slice's iteration count before the call.  Needs pv_out.
  */
 int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                            const float *tau4, float *eps0, float *eps1, float *arp,
                            uint32_t *spk_out, float *pv_out, float *v_out,
                            const float *ro_Wp, const float *ro_b, float *ro_out, int32_t n_ro,
+                           float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
                            int32_t T, int32_t B, void *stream);
 
 /* Re-lay-out a readout matrix Wt (N, 32*16*16) [n][co][pix] for the fused epilogue of dcll_conv_lif_sequence:
@@ -147,11 +155,13 @@ int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void *stream);
  * First-layer sequence kernel (c_in==1): the input is exactly one spike per sample per step (iq2spiketrain,
  * data/utils.py:43-87), given as its cell index q*w+i.  Geometry: c_in==1, c_out<=32, 7x7, pad 3, pool 1, plane 16x16
  * or h % 8 == 0 and w % 32 == 0.
- *   cells (T,B) int32 ; tau4 (4,1) ; other arguments as dcll_conv_lif_sequence.
+ *   cells (T,B) int32 ; tau4 (4,1) ; other arguments as dcll_conv_lif_sequence (state_scratch: 2*B*h*w floats).
  */
 int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *W, const float *b,
                                  const float *tau4, float *eps0, float *eps1, float *arp,
-                                 uint32_t *spk_out, float *pv_out, float *v_out, int32_t T, int32_t B, void *stream);
+                                 uint32_t *spk_out, float *pv_out, float *v_out,
+                                 float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
+                                 int32_t T, int32_t B, void *stream);
 
 /*
  * Same kernel with iq2spiketrain's quantisation (data/utils.py:60-82) fused in: the input is the raw IQ window
@@ -161,7 +171,16 @@ int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, 
 int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
                               int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
                               float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
+                              float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
                               int32_t T, int32_t B, void *stream);
+
+/*
+ * The pv statistics of DCLLBase.forward (:658-661) as a call of its own (the per-step path uses it with T = 1):
+ * pv (T, per_step) fp32 = the pv outputs of T consecutive steps, per_step = B*c_out*ph*pw values each; counts as
+ * pv_lowhigh above, uint64 [dcll_pv_lowhigh_steps(iter0, T)][2].  Steps that are not histogram steps are not read.
+ */
+int dcll_pv_lowhigh(const float *pv, int64_t per_step, int32_t T, int32_t iter0, uint64_t *counts, void *stream);
+int32_t dcll_pv_lowhigh_steps(int32_t iter0, int32_t T);    /* (iter0 + T) / 20 - iter0 / 20 */
 
 /*
  * Local readout for many rows at once: out[r, n] = sum_k pv[r,k]*Wt[n,k] + bias[n]   (i2o / output_, :602-606),

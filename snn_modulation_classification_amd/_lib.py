@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_PKG, "libdcll_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class DCLLHipError(RuntimeError):
@@ -51,10 +51,12 @@ SIGNATURES = {
     "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_I32, _P]),
     "dcll_conv_lif_backward": (_I32, [_DP] + [_P] * 13 + [_I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
-    "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _I32, _I32, _P]),
+    "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _P, _P, _I32, _I32, _I32, _P]),
     "dcll_permute_readout": (_I32, [_P, _P, _I32, _P]),
-    "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_I32, _I32, _P]),
-    "dcll_conv_lif_sequence_iq": (_I32, [_DP, _P, _P, _P, _I32, _I32] + [_P] * 9 + [_I32, _I32, _P]),
+    "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_P, _P, _I32, _I32, _I32, _P]),
+    "dcll_conv_lif_sequence_iq": (_I32, [_DP, _P, _P, _P, _I32, _I32] + [_P] * 9 + [_P, _P, _I32, _I32, _I32, _P]),
+    "dcll_pv_lowhigh": (_I32, [_P, _I64, _I32, _I32, _P, _P]),
+    "dcll_pv_lowhigh_steps": (_I32, [_I32, _I32]),
     "dcll_readout": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
     "dcll_readout_splitk_scratch": (_I64, [_I64, _I32, _I32]),
     "dcll_readout_splitk": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),

@@ -2109,6 +2109,95 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
     return DCLL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// pv activity statistics (DCLLBase.forward, dcll/pytorch_libdcll.py:658-661 + write_stats :678-688): on every step whose
+// 1-based iteration count is a multiple of 20 the reference histograms pv on the host (np.histogram, 19 bins over
+// [0,1]) and reports only the first and the last bin.  Here: two counters per sampled step, pv < e1 and pv >= e18 with
+// the edges of np.linspace(0, 1, 20) — evaluated exactly like numpy's float64 comparison by comparing against the
+// smallest float32 >= edge — counted in one pass over the sampled steps' pv planes (wave ballots + popcount, one
+// atomic pair per workgroup).  counts[k][0..1], k = index of the sampled step inside the call.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pv_lowhigh(const float *__restrict__ pv, long per_step, int iter0,
+                                                     float thr_low, float thr_high,
+                                                     unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned red[2][4];
+    const int k = blockIdx.y;
+    const long t = ((long)(iter0 / 20) + k + 1) * 20 - iter0 - 1;          // 0-based step of the k-th sampled iteration
+    const float *p = pv + t * per_step;
+    unsigned lo = 0, hi = 0;                                                // wave-uniform
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if ((((uintptr_t)p) & 15) == 0) {
+        const long n4 = per_step >> 2;
+        for (; i < n4 + stride - 1 - (n4 + stride - 1) % stride; i += stride) {     // uniform trip count (ballots)
+            f32x4 v = {.5f, .5f, .5f, .5f};
+            const bool in = i < n4;
+            if (in) v = ((const f32x4 *)p)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo += __popcll(__ballot(in && v[e] < thr_low));
+                hi += __popcll(__ballot(in && v[e] >= thr_high));
+            }
+        }
+        i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x;                  // scalar tail (per_step % 4 floats)
+    }
+    for (; i < per_step + stride - 1 - (per_step + stride - 1) % stride; i += stride) {
+        const bool in = i < per_step;
+        const float v = in ? p[i] : 0.5f;
+        lo += __popcll(__ballot(in && v < thr_low));
+        hi += __popcll(__ballot(in && v >= thr_high));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned tot = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (tot) atomicAdd(counts + 2 * k + threadIdx.x, (unsigned long long)tot);
+    }
+}
+
+// smallest float32 >= e: for a float32 x, (x < e in float64) <=> x < f32_ceil(e), and likewise for >=
+static float f32_ceil(double e)
+{
+    float f = (float)e;
+    if ((double)f < e) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+static inline int n_sampled_steps(int iter0, int T) { return (iter0 + T) / 20 - iter0 / 20; }
+
+static int launch_pv_lowhigh(const float *pv, long per_step, int T, int iter0, unsigned long long *counts,
+                             hipStream_t st, const char *who)
+{
+    if (iter0 < 0) return fail(DCLL_ERR_INVALID, "negative iteration count", who);
+    const int ns = n_sampled_steps(iter0, T);
+    if (ns == 0) return DCLL_OK;
+    if (!pv) return fail(DCLL_ERR_INVALID, "pv statistics need the pv output of the call", who);
+    if (hipMemsetAsync(counts, 0, (size_t)ns * 2 * sizeof(unsigned long long), st) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DCLL_ERR_LAUNCH, "hipMemsetAsync of the pv counters failed", who);
+    }
+    const double e1 = 1.0 / 19.0, e18 = 18.0 * (1.0 / 19.0);               // np.linspace(0, 1, 20)[1], [18]
+    long nb = (per_step / 4 + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_pv_lowhigh, dim3((unsigned)nb, (unsigned)ns), dim3(256), 0, st, pv, per_step, iter0,
+                       f32_ceil(e1), f32_ceil(e18), counts);
+    HIP_CHECK_LAUNCH("k_pv_lowhigh");
+    return DCLL_OK;
+}
+
+extern "C" int dcll_pv_lowhigh(const float *pv, int64_t per_step, int32_t T, int32_t iter0, uint64_t *counts,
+                               void *stream)
+{
+    if (T == 0 || per_step == 0) return DCLL_OK;
+    if (!counts || T < 0 || per_step < 0) return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: bad argument");
+    return launch_pv_lowhigh(pv, per_step, T, iter0, (unsigned long long *)counts, (hipStream_t)stream, "dcll_pv_lowhigh");
+}
+
+extern "C" int32_t dcll_pv_lowhigh_steps(int32_t iter0, int32_t T) { return (iter0 < 0 || T < 0) ? 0 : n_sampled_steps(iter0, T); }
+
 static int check_seq_geometry(const dcll_conv_desc *d, int c_in, const char *who)
 {
     int rc = check_desc(d);
@@ -2133,6 +2222,12 @@ extern "C" int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void 
 
 constexpr int DCLL_C32D_MIN_T = 8;      // shorter sequences: k_lif_seq_c32 (half the pipeline fill)
 
+static int dcll_conv_lif_sequence_run(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+                                      const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
+                                      float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
+                                      float *ro_out, int32_t n_ro, float *state_scratch, int32_t T, int32_t B,
+                                      void *stream);
+
 template <bool R, int NRO>
 static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, const float *W, const float *b,
                        const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
@@ -2154,10 +2249,24 @@ static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, c
 extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                                       const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
                                       float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
-                                      float *ro_out, int32_t n_ro, int32_t T, int32_t B, void *stream)
+                                      float *ro_out, int32_t n_ro, float *state_scratch, uint64_t *pv_lowhigh,
+                                      int32_t iter0, int32_t T, int32_t B, void *stream)
 {
     int rc = check_seq_geometry(d, 32, "dcll_conv_lif_sequence");
     if (rc) return rc;
+    rc = dcll_conv_lif_sequence_run(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out,
+                                    n_ro, state_scratch, T, B, stream);
+    if (rc || !pv_lowhigh || T <= 0 || B <= 0) return rc;
+    return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * d->w, T, iter0, (unsigned long long *)pv_lowhigh,
+                             (hipStream_t)stream, "dcll_conv_lif_sequence");
+}
+
+static int dcll_conv_lif_sequence_run(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+                                      const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
+                                      float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
+                                      float *ro_out, int32_t n_ro, float *state_scratch, int32_t T, int32_t B,
+                                      void *stream)
+{
     if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
     if (!spk_in || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: refractory layer needs arp");
@@ -2169,7 +2278,7 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
     if (d->h != 16 || d->w != 16) {         // large plane: k_lif_seq_c32t, one workgroup per (sample, 8 x 32 tile)
         if (n_ro) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout only on the 16x16 plane");
-        return dcll_launch_seq_c32t(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, st);
+        return dcll_launch_seq_c32t(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, state_scratch, T, B, st);
     }
     if (n_ro == 0 && T >= DCLL_C32D_MIN_T) {      // long sequence: two tiles per wave and stage
 #define DCLL_LAUNCH_C32D(R, O)                                                                                          \
@@ -2211,12 +2320,19 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
 
 static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
                      const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4, float *eps0,
-                     float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, int T, int B,
-                     hipStream_t st)
+                     float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, float *state_scratch,
+                     uint64_t *pv_lowhigh, int iter0, int T, int B, hipStream_t st)
 {
+    if (pv_lowhigh) {       // statistics pass over the sampled steps' pv planes after the layer kernel
+        int rc = launch_c1(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
+                           state_scratch, nullptr, 0, T, B, st);
+        if (rc) return rc;
+        return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * d->w, T, iter0, (unsigned long long *)pv_lowhigh, st,
+                                 "dcll_conv_lif_sequence_cells/_iq");
+    }
     if (d->h != 16 || d->w != 16)       // large plane: k_lif_seq_c1t, one workgroup per (sample, 8 x 32 tile)
         return dcll_launch_seq_c1t(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
-                                   T, B, st);
+                                   state_scratch, T, B, st);
     const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out;
 #define DCLL_LAUNCH_C1(R, F)                                                                                            \
     hipLaunchKernelGGL((k_lif_seq_c1<R, F>), dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,  \
@@ -2235,7 +2351,8 @@ static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float 
 
 extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *W, const float *b,
                                             const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
-                                            float *pv_out, float *v_out, int32_t T, int32_t B, void *stream)
+                                            float *pv_out, float *v_out, float *state_scratch, uint64_t *pv_lowhigh,
+                                            int32_t iter0, int32_t T, int32_t B, void *stream)
 {
     int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_cells");
     if (rc) return rc;
@@ -2243,14 +2360,15 @@ extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32
     if (!cells || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: refractory layer needs arp");
     if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: negative size");
-    return launch_c1(d, cells, nullptr, nullptr, nullptr, 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B,
-                     (hipStream_t)stream);
+    return launch_c1(d, cells, nullptr, nullptr, nullptr, 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
+                     state_scratch, pv_lowhigh, iter0, T, B, (hipStream_t)stream);
 }
 
 extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
                                          int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
                                          float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
-                                         float *v_out, int32_t T, int32_t B, void *stream)
+                                         float *v_out, float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
+                                         int32_t T, int32_t B, void *stream)
 {
     int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_iq");
     if (rc) return rc;
@@ -2259,8 +2377,8 @@ extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *i
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: refractory layer needs arp");
     if (T < 0 || B < 0 || t0 < 0 || t0 + T > L) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: window [t0, t0+T) outside the IQ row");
     if (T > C1_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence_iq: at most 4096 timesteps per launch");
-    return launch_c1(d, nullptr, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B,
-                     (hipStream_t)stream);
+    return launch_c1(d, nullptr, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
+                     state_scratch, pv_lowhigh, iter0, T, B, (hipStream_t)stream);
 }
 
 extern "C" int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t T, int32_t B, int32_t N,

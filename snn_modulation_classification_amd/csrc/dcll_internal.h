@@ -45,13 +45,13 @@ static inline int fail(int code, const char *msg, const char *who = nullptr)
 __attribute__((visibility("hidden")))
 int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                          const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
-                         float *v_out, int32_t T, int32_t B, hipStream_t st);
+                         float *v_out, float *state_scratch, int32_t T, int32_t B, hipStream_t st);
 // k_lif_seq_c1t: the first layer (c_in 1) on such planes, input as cell indices or raw IQ
 __attribute__((visibility("hidden")))
 int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
                         const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4,
-                        float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, int T,
-                        int B, hipStream_t st);
+                        float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
+                        float *state_scratch, int T, int B, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------------------
 // shared device helpers

@@ -36,10 +36,12 @@ __device__ constexpr tgroup TG[4] = {{5, 3}, {8, 3}, {11, 3}, {0, 5}};
 template <bool REFRACTORY, int OUT>     // OUT bit0: pv, bit1: v
 __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
                                                        const float *__restrict__ bias, const float *__restrict__ tau4,
-                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
-                                                       float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
-                                                       float *__restrict__ pv_out, float *__restrict__ v_out, int T,
-                                                       int B, int H, int Wd, float alpharp, float wrp)
+                                                       const float *__restrict__ eps0_in,
+                                                       const float *__restrict__ eps1_in, float *__restrict__ eps0_g,
+                                                       float *__restrict__ eps1_g, float *__restrict__ arp_g,
+                                                       uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
+                                                       float *__restrict__ v_out, int T, int B, int H, int Wd,
+                                                       float alpharp, float wrp)
 {
     __shared__ __attribute__((aligned(16))) float lds[TIMG + (NWAVE * 2 + 1) * SLOT_FLOATS];
     float *slots = lds + TIMG;                  // [wave][tile of the pair][16 x 64]
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
                 const float ta = tau4[0 * 32 + 4 * w + c], tm = tau4[1 * 32 + 4 * w + c];
                 const float tas = tau4[2 * 32 + 4 * w + c], ts = tau4[3 * 32 + 4 * w + c];
                 const long gidx = (b * 32 + 4 * w + c) * HW + (long)gy * Wd + gx;
-                float e0v = ok ? eps0_g[gidx] : 0.0f, e1 = ok ? eps1_g[gidx] : 0.0f;
+                float e0v = ok ? eps0_in[gidx] : 0.0f, e1 = ok ? eps1_in[gidx] : 0.0f;
                 const float bb = tas * e0v;
                 e0v = spike_times(word, s, c, ts) + bb;
                 const float cc = ta * e1, dd = e0v * tm;
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
                                                       const float *__restrict__ iq, const float *__restrict__ thr_i,
                                                       const float *__restrict__ thr_q, int L, int t0,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
-                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
+                                                      const float *__restrict__ tau4, const float *__restrict__ eps0_in,
+                                                      const float *__restrict__ eps1_in, float *__restrict__ eps0_g,
                                                       float *__restrict__ eps1_g, float *__restrict__ arp_g,
                                                       uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
                                                       float *__restrict__ v_out, int T, int B, int H, int Wd,
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
         const int gy = y0 - 3 + rr, gx = x0 - 3 + cc;
         const bool ok = idx < C1T_REGION && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
         gpix[s] = ok ? gy * Wd + gx : -1;
-        e0[s] = ok ? eps0_g[b * HW + gpix[s]] : 0.0f;
-        e1[s] = ok ? eps1_g[b * HW + gpix[s]] : 0.0f;
+        e0[s] = ok ? eps0_in[b * HW + gpix[s]] : 0.0f;
+        e1[s] = ok ? eps1_in[b * HW + gpix[s]] : 0.0f;
     }
     float wf[7][4];
 #pragma unroll
@@ -491,18 +494,38 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
     }
 }
 
+// The workgroups of one launch read their tile's initial traces PLUS a 3-pixel halo that belongs to neighbouring tiles
+// and write their interior back at the end; nothing orders the workgroups of a grid, so a late workgroup could read a
+// neighbour's already advanced state as its initial halo.  Race-free by construction: the initial state is snapshot
+// into caller scratch (stream-ordered device copies) and every read goes to the snapshot, every write to the state.
+static int snapshot_state(const float *eps0, const float *eps1, float *scratch, long n, hipStream_t st, const char *who)
+{
+    if (!scratch) return fail(DCLL_ERR_INVALID, "planes larger than 16x16 need state_scratch (2*B*c_in*h*w floats)", who);
+    if (hipMemcpyAsync(scratch, eps0, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(scratch + n, eps1, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DCLL_ERR_LAUNCH, "state snapshot copy failed", who);
+    }
+    return DCLL_OK;
+}
+
 int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
                         const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4,
-                        float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, int T,
-                        int B, hipStream_t st)
+                        float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
+                        float *state_scratch, int T, int B, hipStream_t st)
 {
     if (iq && T > C1T_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "fused IQ encoder: T exceeds 4096 steps");
     const long nwg = (long)B * (d->h / 8) * (d->w / 32);
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel: batch x tiles exceeds the grid limit");
+    const long nstate = (long)B * d->h * d->w;
+    int rc = snapshot_state(eps0, eps1, state_scratch, nstate, st, "dcll_conv_lif_sequence_cells/_iq");
+    if (rc) return rc;
+    const float *eps0_in = state_scratch, *eps1_in = state_scratch + nstate;
     const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out && (long)d->h * d->w * 32 < (1L << 30);
 #define DCLL_LAUNCH_C1T(R, F)                                                                                           \
     hipLaunchKernelGGL((k_lif_seq_c1t<R, F>), dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q,  \
-                       L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w, d->alpharp, d->wrp)
+                       L, t0, W, b, tau4, eps0_in, eps1_in, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,         \
+                       d->alpharp, d->wrp)
     if (d->refractory) {
         if (fastpath) DCLL_LAUNCH_C1T(true, true);
         else DCLL_LAUNCH_C1T(true, false);
@@ -517,15 +540,19 @@ int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const flo
 
 int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                          const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
-                         float *v_out, int32_t T, int32_t B, hipStream_t st)
+                         float *v_out, float *state_scratch, int32_t T, int32_t B, hipStream_t st)
 {
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
     const long nwg = (long)B * (d->h / 8) * (d->w / 32);
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: batch x tiles exceeds the grid limit");
     if ((long)d->h * d->w >= (1L << 26)) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: plane larger than 2^26 pixels");
+    const long nstate = (long)B * 32 * d->h * d->w;
+    int rc = snapshot_state(eps0, eps1, state_scratch, nstate, st, "dcll_conv_lif_sequence");
+    if (rc) return rc;
+    const float *eps0_in = state_scratch, *eps1_in = state_scratch + nstate;
 #define DCLL_LAUNCH_C32T(R, O)                                                                                          \
-    hipLaunchKernelGGL((k_lif_seq_c32t<R, O>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, W, b, tau4, eps0, eps1,   \
-                       arp, spk_out, pv_out, v_out, T, B, d->h, d->w, d->alpharp, d->wrp)
+    hipLaunchKernelGGL((k_lif_seq_c32t<R, O>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, W, b, tau4, eps0_in,      \
+                       eps1_in, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w, d->alpharp, d->wrp)
     if (d->refractory) {
         switch (out) {
         case 0: DCLL_LAUNCH_C32T(true, 0); break;

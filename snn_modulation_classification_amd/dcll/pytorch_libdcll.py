@@ -426,13 +426,19 @@ class Conv2dDCLLlayer(nn.Module):
         return cache[1], cache[2]
 
     def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False, batch_slice=None,
-                         want_pv=True):
+                         want_pv=True, lowhigh_iter0=None):
         """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,H*W/32) int32 ('packed').
         Neuron state is read from / written back to self.i2h.state (rows batch_slice .. batch_slice+B of it when
         `batch_slice` is given: a chunk of a larger batch).
         -> (packed spikes, pv (T,B,C,H,W) or None, logits (T,B,24|48) or None).  With fuse_readout ('packed' only)
-        the readout(s) are computed in the kernel's epilogue and pv is not materialised."""
+        the readout(s) are computed in the kernel's epilogue and pv is not materialised.
+        `lowhigh_iter0` (the slice's iteration count before the sequence): also count pv's first / last histogram bin
+        on the reference's histogram steps (:658-661); the (n,2) int64 counters are left in buffers['lowhigh']."""
         i2h = self.i2h
+        buffers = {} if buffers is None else buffers
+        buffers.pop('lowhigh', None)
+        if not want_pv or fuse_readout:
+            lowhigh_iter0 = None                  # no pv is materialised: no statistics (documented in test_sequence)
         if batch_slice is None:
             if i2h.state is None or i2h.state.eps0.shape[0] != B:
                 i2h.init_state(B, self.im_dims)
@@ -446,13 +452,14 @@ class Conv2dDCLLlayer(nn.Module):
         with torch.no_grad():
             if kind == 'cells':
                 spk, pv, _ = ops.conv_lif_sequence_cells(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,
-                                                         T, B, want_spikes=want_spikes, want_pv=want_pv, out=buffers)
+                                                         T, B, want_spikes=want_spikes, want_pv=want_pv, out=buffers,
+                                                         lowhigh_iter0=lowhigh_iter0)
                 return spk, pv, None
             if kind == 'iq':        # inp = (iq (B,2,L), thr_i, thr_q, t0): encoder fused into the layer kernel
                 iq, thr_i, thr_q, t0 = inp
                 spk, pv, _ = ops.conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, i2h.weight, i2h.bias, tau4, st.eps0,
                                                       st.eps1, arp, T, B, want_spikes=want_spikes, want_pv=want_pv,
-                                                      out=buffers)
+                                                      out=buffers, lowhigh_iter0=lowhigh_iter0)
                 return spk, pv, None
             if fuse_readout:
                 Wp, rb = self.fused_readout_weights()
@@ -461,7 +468,8 @@ class Conv2dDCLLlayer(nn.Module):
                                                           ro_Wp=Wp, ro_b=rb)
                 return spk, None, logits
             spk, pv, _ = ops.conv_lif_sequence(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp, T, B,
-                                               want_spikes=want_spikes, want_pv=want_pv, out=buffers)
+                                               want_spikes=want_spikes, want_pv=want_pv, out=buffers,
+                                               lowhigh_iter0=lowhigh_iter0)
         return spk, pv, None
 
 
@@ -647,16 +655,28 @@ class DCLLBase(nn.Module):
         self.iter += 1
         o, p, pv, pvmem = self.dclllayer.forward(input)
         if self.collect_stats and (self.iter % 20) == 0:
-            # the reference histograms pv on the host (np.histogram, 19 bins over [0,1]); same bins on the device,
-            # only the 19 counts cross PCIe (and only when write_stats asks for them)
-            self.activity_hist.append(torch.histc(pv.detach().float(), bins=19, min=0.0, max=1.0))
+            # the reference histograms pv on the host (np.histogram, 19 bins over [0,1]) and reports only the first and
+            # the last bin (:678-688): those two are counted on the device (dcll_pv_lowhigh, numpy's bin edges), 16
+            # bytes cross PCIe, and only when write_stats asks for them
+            self.activity_hist.append((ops.pv_lowhigh(pv.detach(), 1, self.iter - 1)[0], pv.numel()))
         return o, p, pv, pvmem
+
+    def _activity_rows(self):
+        """activity_hist as the (n, 19) array the reference keeps: bins 0 and 18 are exact, the other 17 bins are not
+        tracked (their total sits in bin 9) — write_stats (:678-688) reads only pd[0] and pd[-1]."""
+        rows = []
+        for counts, numel in self.activity_hist:
+            lo, hi = (int(c) for c in counts.cpu())
+            h = np.zeros(19)
+            h[0], h[-1], h[9] = lo, hi, numel - lo - hi
+            rows.append(h)
+        return np.asarray(rows)
 
     def write_stats(self, writer, label, epoch):
         writer.add_histogram(self.name + '/weight', self.dclllayer.i2h.weight.flatten(), epoch)
         writer.add_histogram(self.name + '/bias', self.dclllayer.i2h.bias.flatten(), epoch)
         if self.collect_stats and len(self.activity_hist):
-            pd = np.mean([h.cpu().numpy() if isinstance(h, torch.Tensor) else h for h in self.activity_hist], axis=0)
+            pd = np.mean(self._activity_rows(), axis=0)
             pd = pd / pd.sum()
             writer.add_scalar(self.name + '/low_pv/' + label, pd[0], epoch)
             writer.add_scalar(self.name + '/high_pv/' + label, pd[-1], epoch)
@@ -721,10 +741,15 @@ class DCLLClassification(DCLLBase):
             self._clout.append(logits.argmax(1).detach())
         return o, p, pv, pvmem
 
-    def set_sequence_result(self, clout_dev, n_steps):
-        """Install the per-step argmax of a whole-sequence run ((T,B) int32 on device) as `clout`."""
+    def set_sequence_result(self, clout_dev, n_steps, lowhigh=None, numel=0):
+        """Install the results of a whole-sequence run as n_steps calls of forward() would have left them: the per-step
+        argmax ((T,B) int32 on device) appended to `clout`, the iteration count advanced, and — `lowhigh` (n,2) int64
+        device counters of the histogram steps, `numel` pv values per step — the pv statistics appended to
+        `activity_hist` (reference :658-661)."""
         self.iter += n_steps
         self._clout.extend(clout_dev.to(torch.int64))       # like n_steps calls of forward(): appended, not replaced
+        if lowhigh is not None and self.collect_stats:
+            self.activity_hist.extend((row, numel) for row in lowhigh)
 
     def write_stats(self, writer, label, epoch):
         super().write_stats(writer, label, epoch)

@@ -108,14 +108,19 @@ class ConvNetwork(torch.nn.Module):
         if cache is None or cache['cap'] < B:
             self._seq_buffers.clear()
             n_ro = [self.target_size * (2 if i == self.num_layers - 1 else 1) for i in range(self.num_layers)]
+            cmax = max(s.dclllayer.in_channels for s in self.dcll_slices)
             cache = dict(cap=B,
                          spk=[torch.empty(T * B * C * (H * W // 32), device=dev, dtype=torch.int32) for _ in range(2)],
                          pv=torch.empty(T * B * C * H * W, device=dev, dtype=torch.float32),
-                         ro=[torch.empty(T * B * n, device=dev, dtype=torch.float32) for n in n_ro])
+                         ro=[torch.empty(T * B * n, device=dev, dtype=torch.float32) for n in n_ro],
+                         # snapshot area of the tiled kernels (planes other than 16x16): initial eps0 / eps1 of a layer
+                         state_scratch=(torch.empty(2 * B * cmax * H * W, device=dev, dtype=torch.float32)
+                                        if (H, W) != (16, 16) else None))
             self._seq_buffers[key] = cache
         return dict(spk=[t[:T * B * C * (H * W // 32)].view(T, B, C, H * W // 32) for t in cache['spk']],
                     pv=cache['pv'][:T * B * C * H * W].view(T, B, C, H, W),
-                    ro=[t[:T * B * (t.numel() // (T * cache['cap']))].view(T, B, -1) for t in cache['ro']])
+                    ro=[t[:T * B * (t.numel() // (T * cache['cap']))].view(T, B, -1) for t in cache['ro']],
+                    state_scratch=cache['state_scratch'])
 
     def zero_states(self):
         """Zero every layer's neuron state in place (time constants untouched — unlike reset(True), quirk Q4)."""
@@ -174,7 +179,9 @@ class ConvNetwork(torch.nn.Module):
                     output_only=output_only))
             cat = lambda key, dim: [None if parts[0][key][i] is None else torch.cat([p[key][i] for p in parts], dim)
                                     for i in range(self.num_layers)]
-            res = dict(logits=cat('logits', 1), clout=cat('clout', 1), vote=cat('vote', 0))
+            res = dict(logits=cat('logits', 1), clout=cat('clout', 1), vote=cat('vote', 0),
+                       lowhigh=[None if parts[0]['lowhigh'][i] is None else sum(p['lowhigh'][i] for p in parts)
+                                for i in range(self.num_layers)])
             if 'o' in parts[0]:
                 res['o'] = torch.cat([p['o'] for p in parts], 1)
         else:
@@ -184,7 +191,9 @@ class ConvNetwork(torch.nn.Module):
         if collect:
             for i, s in enumerate(self.dcll_slices):
                 if res['clout'][i] is not None:
-                    s.set_sequence_result(res['clout'][i], T)
+                    L = s.dclllayer
+                    s.set_sequence_result(res['clout'][i], T, lowhigh=res['lowhigh'][i],
+                                          numel=B * L.out_channels * int(np.prod(L.output_shape)))
         return res
 
     def _sequence_chunk(self, first_input, first_kind, T, B, dev, profile, fuse_readout, batch_slice=None,
@@ -207,17 +216,20 @@ class ConvNetwork(torch.nn.Module):
             return out
 
         cur = first_input
-        res = dict(logits=[], clout=[], vote=[])
+        res = dict(logits=[], clout=[], vote=[], lowhigh=[])
         for i, s in enumerate(self.dcll_slices):
             L = s.dclllayer
             last = (i == self.num_layers - 1)
             fused = fuse_readout and i > 0
             hidden_skip = output_only and not last
+            lbuf = dict(spk=buf['spk'][i & 1], pv=buf['pv'], ro=buf['ro'][i], state_scratch=buf['state_scratch'])
+            # pv statistics of the reference's histogram steps (:658-661) for slices that collect them; counted from
+            # the slice's iteration count as T calls of forward() would
             spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B,
-                                first_kind if i == 0 else 'packed', want_spikes=not last,
-                                buffers=dict(spk=buf['spk'][i & 1], pv=buf['pv'], ro=buf['ro'][i]),
+                                first_kind if i == 0 else 'packed', want_spikes=not last, buffers=lbuf,
                                 fuse_readout=fused and not hidden_skip, batch_slice=batch_slice,
-                                want_pv=not hidden_skip)
+                                want_pv=not hidden_skip, lowhigh_iter0=s.iter if s.collect_stats else None)
+            res['lowhigh'].append(lbuf.get('lowhigh'))
             if hidden_skip:
                 res['logits'].append(None)
                 res['clout'].append(None)

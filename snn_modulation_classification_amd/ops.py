@@ -164,12 +164,48 @@ def permute_readout(Wt):
     return Wp
 
 
+def _seq_extras(desc, B, T, dev, out, lowhigh_iter0):
+    """(state_scratch, pv_lowhigh counters, iter0) of a sequence call.  Planes other than 16x16 run the tiled kernels,
+    which read a snapshot of the initial state (halo reads must not see a neighbour tile's final state): the scratch
+    comes from `out['state_scratch']` or is allocated here.  lowhigh_iter0 = the slice's iteration count before the
+    call turns the pv statistics on (None = off)."""
+    scratch = None
+    if (desc.h, desc.w) != (16, 16):
+        n = 2 * B * desc.c_in * desc.h * desc.w
+        scratch = out.get("state_scratch")
+        if scratch is None or scratch.numel() < n:
+            scratch = torch.empty((n,), device=dev, dtype=torch.float32)
+        _expect(scratch, "state_scratch", torch.float32)
+    counts, iter0 = None, 0
+    if lowhigh_iter0 is not None:
+        iter0 = int(lowhigh_iter0)
+        counts = torch.zeros((pv_lowhigh_steps(iter0, T), 2), device=dev, dtype=torch.int64)
+    return scratch, counts, iter0
+
+
+def pv_lowhigh_steps(iter0, T):
+    """Number of histogram steps (1-based iteration count % 20 == 0, reference :658-661) among T steps after iter0."""
+    return int(_lib.get().dcll_pv_lowhigh_steps(int(iter0), int(T)))
+
+
+def pv_lowhigh(pv, T, iter0):
+    """pv (T, ...) fp32 -> int64 (n, 2): per histogram step the counts of pv in the first / last of the reference's 19
+    bins over [0, 1] (dcll_pv_lowhigh)."""
+    _expect(pv, "pv", torch.float32)
+    pv = pv.contiguous()
+    counts = torch.zeros((pv_lowhigh_steps(iter0, T), 2), device=pv.device, dtype=torch.int64)
+    check(_lib.get().dcll_pv_lowhigh(ptr(pv), pv.numel() // max(T, 1), T, int(iter0), ptr(counts), stream_ptr()),
+          "dcll_pv_lowhigh")
+    return counts
+
+
 def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_pv=True,
-                      want_v=False, out=None, ro_Wp=None, ro_b=None):
+                      want_v=False, out=None, ro_Wp=None, ro_b=None, lowhigh_iter0=None):
     """All T steps of one 32->32 layer in one launch (k_lif_seq_c32). spk_in: (T,B,32,8) int32 packed.
-    With ro_Wp / ro_b the local readout(s) are fused: returns (spk, pv, v, logits (T,B,n_ro))."""
+    With ro_Wp / ro_b the local readout(s) are fused: returns (spk, pv, v, logits (T,B,n_ro)).
+    With lowhigh_iter0 the pv statistics of the histogram steps are returned in out['lowhigh'] ((n,2) int64)."""
     dev = W.device
-    out = out or {}
+    out = {} if out is None else out
     words = desc.h * desc.w // 32
     _expect(spk_in, "spk_in", torch.int32, (T, B, desc.c_in, words))
     _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau4=tau4)
@@ -190,20 +226,23 @@ def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spik
         if logits is None:
             logits = torch.empty((T, B, n_ro), device=dev, dtype=torch.float32)
         _expect(logits, "ro_out", torch.float32, (T, B, n_ro))
+    scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
     rc = _lib.get().dcll_conv_lif_sequence(ctypes.byref(desc), ptr(spk_in), ptr(W), ptr(b), ptr(tau4), ptr(eps0),
                                            ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), ptr(ro_Wp), ptr(ro_b),
-                                           ptr(logits), n_ro, T, B, stream_ptr())
+                                           ptr(logits), n_ro, ptr(scratch), ptr(counts), iter0, T, B, stream_ptr())
     check(rc, "dcll_conv_lif_sequence")
+    if counts is not None:
+        out["lowhigh"] = counts
     if ro_Wp is not None:
         return spk, pv, v, logits
     return spk, pv, v
 
 
 def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_pv=True,
-                            want_v=False, out=None):
+                            want_v=False, out=None, lowhigh_iter0=None):
     """All T steps of the first layer (c_in = 1) from cell indices (T,B) int32 (k_lif_seq_c1)."""
     dev = W.device
-    out = out or {}
+    out = {} if out is None else out
     words = desc.h * desc.w // 32
     _expect(cells, "cells", torch.int32, (T, B))
     _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau4=tau4)
@@ -214,18 +253,21 @@ def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want
     if want_pv and pv is None:
         pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
     v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+    scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
     rc = _lib.get().dcll_conv_lif_sequence_cells(ctypes.byref(desc), ptr(cells), ptr(W), ptr(b), ptr(tau4),
-                                                 ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), T, B,
-                                                 stream_ptr())
+                                                 ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v),
+                                                 ptr(scratch), ptr(counts), iter0, T, B, stream_ptr())
     check(rc, "dcll_conv_lif_sequence_cells")
+    if counts is not None:
+        out["lowhigh"] = counts
     return spk, pv, v
 
 
 def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True,
-                         want_pv=True, want_v=False, out=None):
+                         want_pv=True, want_v=False, out=None, lowhigh_iter0=None):
     """First layer from the raw IQ window (B,2,L): iq2spiketrain's quantisation fused into k_lif_seq_c1."""
     dev = W.device
-    out = out or {}
+    out = {} if out is None else out
     iq = iq.reshape(B, 2, -1).contiguous()
     L = iq.shape[-1]
     words = desc.h * desc.w // 32
@@ -240,10 +282,13 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
     if want_pv and pv is None:
         pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
     v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+    scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
     rc = _lib.get().dcll_conv_lif_sequence_iq(ctypes.byref(desc), ptr(iq), ptr(thr_i), ptr(thr_q), L, t0, ptr(W), ptr(b),
-                                              ptr(tau4), ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), T, B,
-                                              stream_ptr())
+                                              ptr(tau4), ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v),
+                                              ptr(scratch), ptr(counts), iter0, T, B, stream_ptr())
     check(rc, "dcll_conv_lif_sequence_iq")
+    if counts is not None:
+        out["lowhigh"] = counts
     return spk, pv, v
 
 

@@ -634,3 +634,83 @@ def test_operand_validation_before_the_abi(dev):
                               st(2, 32), st(2, 32), 3, 2)
     with pytest.raises(ValueError):       # readout bias of the wrong length
         ops.readout(torch.zeros((4, 64), device=dev), torch.zeros((5, 64), device=dev), torch.zeros(4, device=dev))
+
+
+def test_tiled_sequence_state_update_is_race_free(dev):
+    """The tiled kernels read a tile's initial traces plus a 3-pixel halo that neighbouring tiles own and write their
+    interior back at the end; nothing orders the workgroups of a grid.  With far more workgroups than CUs (40 samples
+    x 16 tiles = 640 > 256) and a non-zero initial state, every sample's spikes and final state must still equal the
+    C oracle bit for bit: the launch snapshots the initial state (state_scratch) and reads only the snapshot."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(21)
+    hw, (H, Wd), T, B, wrp = (64, 64), (64, 64), 2, 40, 1.0
+    # 32 -> 32 layer (k_lif_seq_c32t)
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    orc = C.OracleConvLayer(sd, hw, 3, 1, wrp)
+    orc.init_state(B)
+    orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape)
+    orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape)
+    orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+    eps0, eps1, arp = [cu(s.copy(), dev) for s in orc.state]
+    x = (rng.uniform(size=(T, B, 32, H * Wd)) < 0.08).astype(np.float32)
+    d = ops.make_conv_desc(32, 32, hw, 7, 3, 1, 24, False, True, wrp)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    spk, pv, _ = ops.conv_lif_sequence(d, ops.pack_spikes(cu(x, dev)), cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp, T, B)
+    spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T, B, 32, H, Wd)
+    for t in range(T):
+        os_ = orc.forward(x[t].reshape(B, 32, H, Wd), want_v=False)[4]
+        assert np.array_equal(spk_d[t], os_), (t, np.argwhere(spk_d[t] != os_)[:5])
+    for got, want in zip((eps0, eps1, arp), orc.state):
+        assert bits_equal(got.cpu().numpy(), want)
+    # first layer (k_lif_seq_c1t), 8 samples x 16 tiles x ... : same protocol
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 1, 32, gain=3.0)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    B1, T1 = 96, 3
+    orc = C.OracleConvLayer(sd, hw, 3, 1, wrp)
+    orc.init_state(B1)
+    orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape)
+    orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape)
+    eps0, eps1, arp = [cu(s.copy(), dev) for s in orc.state]
+    cells = rng.randint(0, H * Wd, size=(T1, B1)).astype(np.int32)
+    d = ops.make_conv_desc(1, 32, hw, 7, 3, 1, 24, False, True, wrp)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    spk, pv, _ = ops.conv_lif_sequence_cells(d, cu(cells, dev), cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp, T1, B1)
+    spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T1, B1, 32, H, Wd)
+    for t in range(T1):
+        xx = np.zeros((B1, 1, H * Wd), np.float32)
+        xx[np.arange(B1), 0, cells[t]] = 1
+        os_ = orc.forward(xx.reshape(B1, 1, H, Wd), want_v=False)[4]
+        assert np.array_equal(spk_d[t], os_), t
+    for got, want in zip((eps0, eps1, arp), orc.state):
+        assert bits_equal(got.cpu().numpy(), want)
+    # the scratch is part of the ABI contract on these planes: a NULL pointer is refused, not dereferenced
+    from snn_modulation_classification_amd import _lib
+    import ctypes
+    rc = _lib.get().dcll_conv_lif_sequence_cells(ctypes.byref(d), _lib.ptr(cu(cells, dev)), _lib.ptr(cu(W, dev)),
+                                                 _lib.ptr(cu(b, dev)), _lib.ptr(tau4), _lib.ptr(eps0), _lib.ptr(eps1),
+                                                 _lib.ptr(arp), None, None, None, None, None, 0, T1, B1, None)
+    assert rc == _lib.DCLL_ERR_INVALID and b"state_scratch" in _lib.get().dcll_last_error()
+
+
+@pytest.mark.parametrize("per_step,T,iter0", [(32 * 256 * 3, 45, 0), (1001, 61, 17), (8, 20, 0), (4096, 19, 0),
+                                              (12345, 1, 39), (64, 1, 38)])
+def test_pv_lowhigh_counts_match_numpy_histogram(dev, per_step, T, iter0):
+    """dcll_pv_lowhigh == bins 0 and 18 of np.histogram(pv, np.linspace(0, 1, 20)) on the steps whose 1-based iteration
+    count is a multiple of 20 (DCLLBase.forward, reference :658-661), incl. values exactly on / next to the bin edges."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(3)
+    pv = rng.uniform(0, 1, size=(T, per_step)).astype(np.float32)
+    edges = np.linspace(0, 1, 20)
+    special = np.array([0.0, 1.0, edges[1], edges[18], np.float32(edges[1]), np.float32(edges[18]),
+                        np.nextafter(np.float32(edges[1]), np.float32(0)), np.nextafter(np.float32(edges[1]), np.float32(1)),
+                        np.nextafter(np.float32(edges[18]), np.float32(0)), np.nextafter(np.float32(edges[18]), np.float32(1))],
+                       dtype=np.float32)
+    pv[:, :min(per_step, special.size)] = special[:min(per_step, special.size)]
+    got = ops.pv_lowhigh(cu(pv, dev), T, iter0).cpu().numpy()
+    steps = [t for t in range(T) if (iter0 + t + 1) % 20 == 0]
+    assert got.shape == (len(steps), 2) and ops.pv_lowhigh_steps(iter0, T) == len(steps)
+    for k, t in enumerate(steps):
+        h = np.histogram(pv[t], bins=edges)[0]
+        assert (int(got[k, 0]), int(got[k, 1])) == (int(h[0]), int(h[-1])), (k, t)
