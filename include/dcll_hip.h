@@ -190,6 +190,20 @@ int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out
                  int64_t rows, int32_t K, int32_t N, void *stream);
 
 /*
+ * The same readout with the kernel form chosen by the caller:
+ *   DCLL_READOUT_AUTO        what dcll_readout does;
+ *   DCLL_READOUT_CORESIDENT  the LDS-free, <= 64-VGPR form of the 16x16x4 kernel (K % 64 == 0, K <= 16384, N <= 48,
+ *                            16-byte aligned rows; other shapes fall back to AUTO): a workgroup of it fits on a CU beside a
+ *                            resident sequence-kernel workgroup, so a readout launched on a second stream runs in the gaps
+ *                            of the next layer's kernel instead of after it;
+ *   DCLL_READOUT_LDS         the LDS-staged 32x32x2 kernels only (measurements).
+ * Logits of different modes differ by summation order only (within the 1e-4 contract).
+ */
+enum { DCLL_READOUT_AUTO = 0, DCLL_READOUT_CORESIDENT = 1, DCLL_READOUT_LDS = 2 };
+int dcll_readout_mode(const float *pv, const float *Wt, const float *bias, float *out,
+                      int64_t rows, int32_t K, int32_t N, int32_t mode, void *stream);
+
+/*
  * The same readout for FEW rows of a LONG K (per-step calls on a large plane: rows = batch, K = c_out*128*128): K is
  * split into slices of 4096 over the workgroups, the partial tiles go to caller-provided scratch and are added in slice
  * order (deterministic).  Needs K >= 65536, K % 4096 == 0, N <= 64, 16-byte aligned pv / Wt;

@@ -58,6 +58,7 @@ SIGNATURES = {
     "dcll_pv_lowhigh": (_I32, [_P, _I64, _I32, _I32, _P, _P]),
     "dcll_pv_lowhigh_steps": (_I32, [_I32, _I32]),
     "dcll_readout": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "dcll_readout_mode": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "dcll_readout_splitk_scratch": (_I64, [_I64, _I32, _I32]),
     "dcll_readout_splitk": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "dcll_argmax_vote": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),

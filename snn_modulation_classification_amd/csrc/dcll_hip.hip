@@ -902,19 +902,23 @@ __global__ void k_pack(const float *__restrict__ dense, uint32_t *__restrict__ p
 // ------------------------------------------------------------------------------------------------------------
 constexpr int C1_MAXT = 4096;       // longest window the fused IQ encoder of k_lif_seq_c1 keeps in LDS
 
-// Input either as cell indices (cells != NULL) or as raw IQ (iq != NULL): then the quantisation of iq2spiketrain
+// Input either as cell indices (IQ = false) or as raw IQ (IQ = true): then the quantisation of iq2spiketrain
 // (data/utils.py:60-82, threshold form as in k_iq_encode) is fused here: thread t quantises sample t0+t (coalesced
 // loads of the I and the Q row of this window) and parks the cell index of step t in LDS.
 //
-// Conv as fp32 MFMA, weight-stationary: K = 49 taps, padded per kernel row to 8 = 4 MFMA k-pairs (kx 0|1, 2|3, 4|5,
-// 6|pad) with a ZERO weight on the pad tap: fmaf(x, 0, acc) == acc, so every channel still sees the pinned chain
-// bias, tap(0,0), tap(0,1), ... in order.  A = weights (lane: co = lane&31, kx parity = lane>>5; 28 VGPRs for the
-// whole sequence), B = eps1 from a zero-padded 22x24 LDS plane (per-lane base + immediate), D[co][pixel].
-// 4 waves = 8 pixel tiles of 32 (wave w: image rows 4w..4w+3); a thread also owns pixel `tid` of the traces.
+// Conv as fp32 MFMA, weight-stationary: the K = 49 taps in their pinned linear order (ky, kx) are paired two by two over
+// the MFMA's k lanes — pair p = taps (2p, 2p+1), 25 MFMAs per tile, only tap 49 is padding (ZERO weight:
+// fmaf(x, 0, acc) == acc, so every channel still sees the chain bias, tap 0, tap 1, ... tap 48).  A = weights (lane: co =
+// lane&31, tap parity = lane>>5; 25 VGPRs for the whole sequence), B = eps1 from a zero-padded 22x24 LDS plane: lane h = 1
+// reads one float behind lane h = 0, except for the three pairs whose second tap starts the next kernel row (p = 3, 10,
+// 17: PS - 6 floats behind) — two per-lane bases + immediates.  (Round 1 padded every kernel row to 4 pairs: 28 MFMAs.)
+// D[co][pixel]; 4 waves = 8 pixel tiles of 32 (wave w: image rows 4w..4w+3); a thread also owns pixel `tid` of the traces.
+// Spike words: the ballot of accumulator register r IS the two spike words of channels (r, h = 0 / 1) of this tile; they
+// are parked in lanes r and 32 + r of one VGPR with v_writelane (immediate lane, SGPR source: two VALU instructions per
+// value, no select masks — the select chain of round 1 kept 16 64-bit masks and spilled ~100 SGPRs).
 // FAST: c_out == 32 and exactly the outputs spk_out + pv_out — the benchmark's configuration: no per-value channel /
-// pointer guards, and stores as uniform base + 32-bit lane offset (the generic form needs 64-bit address arithmetic and
-// exec-mask branches per value: ~210 address VALU and 160 SGPR reloads per step).
-template <bool REFRACTORY, bool FAST = false>
+// pointer guards, and stores as uniform base + 32-bit lane offset.
+template <bool REFRACTORY, bool FAST, bool IQ>
 __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
                                                     const float *__restrict__ iq, const float *__restrict__ thr_i,
                                                     const float *__restrict__ thr_q, int L, int t0,
@@ -927,13 +931,13 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
     constexpr int PS = 24;                      // plane row stride: 16 + 2*3 padding + the pad tap's column
     __shared__ float plane[22 * PS + 8];
     __shared__ float sbias[32];
-    __shared__ int scell[C1_MAXT];
+    __shared__ int scell[IQ ? C1_MAXT : 1];
     const int b = blockIdx.x, pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63;
     const int w = __builtin_amdgcn_readfirstlane(pix >> 6);
     const int h = lane >> 5, j = lane & 31;
     const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];
     for (int i = pix; i < 22 * PS + 8; i += 256) plane[i] = 0.0f;
-    if (iq) {
+    if (IQ) {
         for (int t = pix; t < T; t += 256) {
             const float vi = iq[((long)b * 2 + 0) * L + t0 + t], vq = iq[((long)b * 2 + 1) * L + t0 + t];
             int ci = 0, cq = 0;
@@ -942,15 +946,13 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
         }
     }
     float e0 = eps0_g[(long)b * 256 + pix], e1 = eps1_g[(long)b * 256 + pix];
-    // weight fragments: (ky, i): lane (co = j, kx = 2i + h); pad tap and channels >= c_out carry 0
-    float wf[7][4];
+    // weight fragments: pair p: lane (co = j, tap = 2p + h); the pad tap and channels >= c_out carry 0
+    float wf[25];
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kx = 2 * i + h;
-            wf[ky][i] = (kx < 7 && j < c_out) ? W[j * 49 + ky * 7 + kx] : 0.0f;
-        }
+    for (int p = 0; p < 25; ++p) {
+        const int tap = 2 * p + h;
+        wf[p] = (tap < 49 && j < c_out) ? W[j * 49 + tap] : 0.0f;
+    }
     // refractory trace of my two tiles: arp[tl][r] <-> channel (r&3)+8(r>>2)+4h, pixel 32*(2w+tl) + j
     float arp[2][16];
     if (pix < 32) sbias[pix] = pix < c_out ? bias[pix] : 0.0f;
@@ -962,8 +964,11 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
             arp[tl][r] = (REFRACTORY && co < c_out) ? arp_g[((long)b * c_out + co) * 256 + 32 * (2 * w + tl) + j] : 0.0f;
     }
     __syncthreads();
+    int cell = IQ ? scell[0] : cells[b];
     for (int t = 0; t < T; ++t) {
-        const int cell = iq ? scell[t] : cells[(long)t * B + b];
+        // next step's cell index: requested now, needed after the barrier at the end of this step
+        const int tn = t + 1 < T ? t + 1 : t;
+        const int cell_next = IQ ? scell[tn] : cells[(long)tn * B + b];
         trace_update(cell == pix ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0, e1);
         plane[(y + 3) * PS + x + 3] = e1;
         lds_barrier();      // LDS-only: does not wait for this step's pv stores
@@ -971,42 +976,46 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
             const int m = 2 * w + tl;
-            const float *bp = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h;
+            const float *bn = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h;               // second tap: + 1
+            const float *bx = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h * (PS - 6);    // ... or the next row's first
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ky][i], bp[ky * PS + 2 * i], acc, 0, 0, 0);
-            uint32_t myword = 0;
+            for (int p = 0; p < 25; ++p) {
+                const int tap = 2 * p, off = (tap / 7) * PS + tap % 7;
+                const bool cross = (tap % 7 == 6) && p < 24;        // p = 24: the partner is the pad tap (weight 0)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[p], cross ? bx[off] : bn[off], acc, 0, 0, 0);
+            }
+            int myword = 0;
             float *pvb = pv_out + obase * 256;                      // wave-uniform base of this step's pv planes
             const unsigned loff = 4 * h * 256 + 32 * m + j;         // + ((r&3) + 8(r>>2)) * 256 per value
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
                 const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = acc[r];
                 bool s;
                 if (REFRACTORY) v = refractory(acc[r], arp[tl][r], alpharp, wrp, s);
                 else s = v > 0.0f;
-                unsigned long long mk = __ballot(s);
-                uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-                myword = (j == r) ? mine : myword;
+                const unsigned long long mk = __ballot(s);
+                // (SGPR data operand + immediate lane: none of the v_writelane hazards — those concern an SGPR lane select)
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mk), "n"(r));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mk >> 32)), "n"(32 + r));
                 if (FAST) {
                     (pvb + ((r & 3) + 8 * (r >> 2)) * 256)[loff] = sigmoidf_dev(v);
                 } else if (co < c_out) {
                     if (pv_out) pv_out[(obase + co) * 256 + 32 * m + j] = sigmoidf_dev(v);
                     if (v_out) v_out[(obase + co) * 256 + 32 * m + j] = v;
                 }
-            }
+            });
             const int cow = (j & 3) + 8 * (j >> 2) + 4 * h;
             if (FAST) {
-                if (j < 16) (spk_out + obase * 8)[cow * 8 + m] = myword;
+                if (j < 16) (spk_out + obase * 8)[cow * 8 + m] = (uint32_t)myword;
             } else if (spk_out && j < 16 && cow < c_out) {
-                spk_out[(obase + cow) * 8 + m] = myword;
+                spk_out[(obase + cow) * 8 + m] = (uint32_t)myword;
             }
         }
+        cell = cell_next;
         lds_barrier();      // LDS-only: does not wait for this step's pv stores
     }
     eps0_g[(long)b * 256 + pix] = e0;
@@ -1673,11 +1682,16 @@ __global__ void k_permute_readout(const float *__restrict__ Wt, float *__restric
 // ------------------------------------------------------------------------------------------------------------
 static inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// mode: DCLL_READOUT_AUTO, _CORESIDENT (k_readout_direct in its <= 64 VGPR, LDS-free form whenever the shape allows), _LDS
+// (never k_readout_direct: the LDS-staged 32x32x2 kernels; kept for measurements)
 static int launch_readout(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
-                          hipStream_t st)
+                          hipStream_t st, int mode = DCLL_READOUT_AUTO)
 {
     if (rows == 0 || N == 0) return DCLL_OK;
     const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0;
+    const bool direct_ok = fast && K % 64 == 0 && N <= 48 && K <= 16384 && mode != DCLL_READOUT_LDS;
+    if (direct_ok && (rows > 2048 || mode == DCLL_READOUT_CORESIDENT))
+        return dcll_launch_readout_direct(pv, Wt, bias, out, rows, K, N, mode == DCLL_READOUT_CORESIDENT ? 1 : 0, st);
     if (rows <= 2048) {
         hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)((rows + RS_RB - 1) / RS_RB), (N + RS_NG - 1) / RS_NG), dim3(256),
                            0, st, pv, Wt, bias, out, rows, K, N);
@@ -1707,6 +1721,15 @@ extern "C" int dcll_readout(const float *pv, const float *Wt, const float *bias,
     if (rows == 0) return DCLL_OK;
     if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1) return fail(DCLL_ERR_INVALID, "dcll_readout: bad argument");
     return launch_readout(pv, Wt, bias, out, rows, K, N, (hipStream_t)stream);
+}
+
+extern "C" int dcll_readout_mode(const float *pv, const float *Wt, const float *bias, float *out, int64_t rows,
+                                 int32_t K, int32_t N, int32_t mode, void *stream)
+{
+    if (rows == 0) return DCLL_OK;
+    if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1 || mode < DCLL_READOUT_AUTO || mode > DCLL_READOUT_LDS)
+        return fail(DCLL_ERR_INVALID, "dcll_readout_mode: bad argument");
+    return launch_readout(pv, Wt, bias, out, rows, K, N, (hipStream_t)stream, mode);
 }
 
 __global__ void k_readout_sum(const float *__restrict__ part, const float *__restrict__ bias, float *__restrict__ out,
@@ -2191,8 +2214,9 @@ static int launch_pv_lowhigh(const float *pv, long per_step, int T, int iter0, u
 extern "C" int dcll_pv_lowhigh(const float *pv, int64_t per_step, int32_t T, int32_t iter0, uint64_t *counts,
                                void *stream)
 {
-    if (T == 0 || per_step == 0) return DCLL_OK;
-    if (!counts || T < 0 || per_step < 0) return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: bad argument");
+    if (T < 0 || per_step < 0 || iter0 < 0) return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: bad argument");
+    if (T == 0 || per_step == 0 || n_sampled_steps(iter0, T) == 0) return DCLL_OK;     // no histogram step: counts may be NULL
+    if (!counts) return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: null counters");
     return launch_pv_lowhigh(pv, per_step, T, iter0, (unsigned long long *)counts, (hipStream_t)stream, "dcll_pv_lowhigh");
 }
 
@@ -2334,16 +2358,19 @@ static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float 
         return dcll_launch_seq_c1t(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
                                    state_scratch, T, B, st);
     const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out;
-#define DCLL_LAUNCH_C1(R, F)                                                                                            \
-    hipLaunchKernelGGL((k_lif_seq_c1<R, F>), dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W, b,  \
-                       tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp)
+#define DCLL_LAUNCH_C1(R, F, Q)                                                                                         \
+    hipLaunchKernelGGL((k_lif_seq_c1<R, F, Q>), dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W,  \
+                       b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp)
+#define DCLL_LAUNCH_C1Q(R, F)                                                                                           \
+    do { if (iq) DCLL_LAUNCH_C1(R, F, true); else DCLL_LAUNCH_C1(R, F, false); } while (0)
     if (d->refractory) {
-        if (fastpath) DCLL_LAUNCH_C1(true, true);
-        else DCLL_LAUNCH_C1(true, false);
+        if (fastpath) DCLL_LAUNCH_C1Q(true, true);
+        else DCLL_LAUNCH_C1Q(true, false);
     } else {
-        if (fastpath) DCLL_LAUNCH_C1(false, true);
-        else DCLL_LAUNCH_C1(false, false);
+        if (fastpath) DCLL_LAUNCH_C1Q(false, true);
+        else DCLL_LAUNCH_C1Q(false, false);
     }
+#undef DCLL_LAUNCH_C1Q
 #undef DCLL_LAUNCH_C1
     HIP_CHECK_LAUNCH("k_lif_seq_c1");
     return DCLL_OK;

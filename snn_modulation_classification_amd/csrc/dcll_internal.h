@@ -53,6 +53,11 @@ int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const flo
                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
                         float *state_scratch, int T, int B, hipStream_t st);
 
+// k_readout_direct (dcll_readout.hip): LDS-free 16x16x4 readout GEMM; mode 0 standalone, 1 co-resident (<= 64 VGPRs)
+__attribute__((visibility("hidden")))
+int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
+                               int mode, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------------------
 // shared device helpers
 // ------------------------------------------------------------------------------------------------------------
@@ -80,6 +85,16 @@ __device__ __forceinline__ float refractory(float pvmem, float &arp, float alpha
     float sw = s ? wrp : 0.0f;      // s*wrp, exact
     arp = a - sw;
     return v;
+}
+
+// compile-time loop: f(std::integral_constant<int, R0>{}), ..., f(std::integral_constant<int, R1 - 1>{})
+template <int R0, int R1, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (R0 < R1) {
+        f(std::integral_constant<int, R0>{});
+        static_for<R0 + 1, R1>(f);
+    }
 }
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS (and scalar) operations, then

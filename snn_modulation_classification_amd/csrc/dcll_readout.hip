@@ -1,0 +1,129 @@
+// dcll_readout.hip — k_readout_direct, the readout GEMM of the whole-sequence path (third translation unit of
+// libdcll_hip.so):   out[r, n] = sum_k pv[r, k] * Wt[n, k] + bias[n]      (i2o / output_, dcll/pytorch_libdcll.py:602-606)
+// for rows = T*B (hundreds of thousands), K = c_out*h*w = 8192 on the 16x16 plane, N = 24 readout rows (48 on the output
+// layer, where i2o and output_ share ONE pass over pv).
+//
+// The operation is a stream over pv (32 KB per row, 17.2 GB per layer at B = 4096) against a 0.8 / 1.5 MB matrix that
+// stays in L2: HBM-bound if the matrix pipe keeps up.  v_mfma_f32_16x16x4_f32 tiles make 48 readout rows 3 x 16 with no
+// padding (the 32-column tiles of k_readout_v4<2> pad 48 to 64: 25 % wasted matrix time, 0.42 of the HBM roofline).
+//
+// No LDS at all: both MFMA operands are loaded straight from global memory in fragment layout.  The k index inside a
+// 32-float chunk may be permuted freely as long as A and B agree, so lane (i = lane & 15, kq = lane >> 4) loads the 8
+// consecutive floats k0 + 8 kq .. + 7 of its row (two dwordx4; the 4 kq-lanes of a row cover one 128-byte line) and
+// MFMA e of the chunk contracts k in {k0 + 8 kq + e}.  A wave owns RT x 16 rows and all NT x 16 readout rows; latency is
+// hidden by occupancy (<= 80 VGPRs: 6 waves per SIMD), or — WPE = 8: <= 64 VGPRs, no LDS — the kernel fits beside a
+// resident k_lif_seq_c32d workgroup (which leaves 64 VGPRs per SIMD lane, 6 wave slots and no LDS) and fills the gaps
+// of its matrix pipe from a second stream (networks/__init__.py, test_sequence(overlap_readout=True)).
+// Summation order: per output one chain over the chunks in k order, inside a chunk e = 0..7, inside an MFMA kq = 0..3
+// (not bit-pinned, like every readout: |err| <= 1e-4); independent of rows / launch splitting.
+#include "dcll_internal.h"
+
+typedef __attribute__((address_space(1))) const float gfloat;
+typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+
+// F4 = float4 loads per fragment and chunk: 2 -> 32-float chunks (the 4 kq-lanes of a row cover a 128-byte line), 1 ->
+// 16-float chunks (half the registers: the co-resident form).  The fragments of chunk c+1 are requested before the MFMAs of
+// chunk c are issued (explicit register double buffer, order pinned with sched_barrier): a wave always has one chunk of
+// loads in flight under RT*NT*4*F4 MFMAs (1536 cycles for <2,3,2>).
+template <int RT, int NT, int F4, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+void k_readout_direct(const float *__restrict__ pv, const float *__restrict__ Wt, const float *__restrict__ bias,
+                      float *__restrict__ out, long rows, int K, int N)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long row0 = ((long)blockIdx.x * 4 + wave) * (16 * RT);
+    if (row0 >= rows) return;                       // no barriers in this kernel: a wave may leave alone
+    // addressing: wave-uniform base (SGPRs, advanced per chunk) + one 32-bit lane offset per fragment row
+    const float *abase = pv + row0 * K;
+    unsigned aoff[RT], boff[NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        long r = rt * 16 + i;
+        if (row0 + r >= rows) r = rows - 1 - row0;  // clamped rows are computed and not stored
+        aoff[rt] = (unsigned)(r * K) + 4 * F4 * kq;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int n = nt * 16 + i;
+        if (n >= N) n = N - 1;                      // idem for padded readout rows
+        boff[nt] = (unsigned)n * (unsigned)K + 4 * F4 * kq;
+    }
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nchunk = K / (16 * F4);               // a multiple of 2 (K % 32 == 0 for F4 = 1, K % 64 == 0 for F4 = 2)
+    f32x4 a[2][RT][F4], b[2][NT][F4];
+    auto fetch = [&](int buf, int c) {
+        // the chunk's bases stay in SGPRs (opaque to the optimiser, which would otherwise fold them into 64-bit
+        // per-lane addresses: 2 VGPRs + a 64-bit add per fragment row and chunk)
+        gfloat *ab = (gfloat *)abase + 16 * F4 * c, *wb = (gfloat *)Wt + 16 * F4 * c;      // global address space kept
+        asm volatile("" : "+s"(ab), "+s"(wb));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int f = 0; f < F4; ++f)                // pv is read exactly once: streamed (nontemporal)
+                a[buf][rt][f] = __builtin_nontemporal_load((gf32x4 *)(ab + aoff[rt]) + f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int f = 0; f < F4; ++f) b[buf][nt][f] = ((gf32x4 *)(wb + boff[nt]))[f];
+    };
+    auto mfmas = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4 * F4; ++e)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][rt][e >> 2][e & 3], b[buf][nt][e >> 2][e & 3],
+                                                                       acc[rt][nt], 0, 0, 0);
+    };
+    fetch(0, 0);
+    for (int c = 0; c < nchunk; c += 2) {
+        fetch(1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nchunk) fetch(0, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // D layout of the 16x16 tile: column (readout row n) = lane & 15, row = 4 (lane >> 4) + register
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + i;
+        if (n < N) {
+            const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long r = row0 + rt * 16 + 4 * kq + q;
+                    if (r < rows) out[r * N + n] = acc[rt][nt][q] + bn;
+                }
+        }
+    }
+}
+
+// mode 0: standalone (two row tiles per wave, occupancy hides the latency); mode 1: the co-resident form (one row tile
+// per wave, <= 64 VGPRs).  Requires K % 64 == 0, N <= 48, 16-byte aligned pv / Wt rows (the caller checked).
+int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
+                               int mode, hipStream_t st)
+{
+    const unsigned g2 = (unsigned)((rows + 127) / 128), g1 = (unsigned)((rows + 63) / 64);
+    if (mode == 0) {
+        if (N <= 16) hipLaunchKernelGGL((k_readout_direct<2, 1, 2, 4>), dim3(g2), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+        else if (N <= 32) hipLaunchKernelGGL((k_readout_direct<2, 2, 2, 4>), dim3(g2), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+        else hipLaunchKernelGGL((k_readout_direct<2, 3, 2, 3>), dim3(g2), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    } else {
+        if (N <= 16) hipLaunchKernelGGL((k_readout_direct<1, 1, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+        else if (N <= 32) hipLaunchKernelGGL((k_readout_direct<1, 2, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+        else hipLaunchKernelGGL((k_readout_direct<1, 3, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    }
+    HIP_CHECK_LAUNCH("k_readout_direct");
+    return DCLL_OK;
+}

@@ -292,8 +292,12 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
     return spk, pv, v
 
 
-def readout(pv2d, Wt, bias, out=None):
-    """out[r,n] = sum_k pv2d[r,k] Wt[n,k] + bias[n]  (i2o / output_), fp32 MFMA."""
+READOUT_AUTO, READOUT_CORESIDENT, READOUT_LDS = 0, 1, 2       # dcll_readout_mode (include/dcll_hip.h)
+
+
+def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO):
+    """out[r,n] = sum_k pv2d[r,k] Wt[n,k] + bias[n]  (i2o / output_), fp32 MFMA.  `mode`: kernel form, see
+    dcll_readout_mode — READOUT_CORESIDENT is the LDS-free <= 64-VGPR form that fits beside a resident sequence kernel."""
     rows, K = pv2d.shape
     N = Wt.shape[0]
     if Wt.shape[1] != K:
@@ -305,12 +309,16 @@ def readout(pv2d, Wt, bias, out=None):
         out = torch.empty((rows, N), device=pv2d.device, dtype=torch.float32)
     _expect(out, "out", torch.float32, (rows, N))
     lib = _lib.get()
-    need = lib.dcll_readout_splitk_scratch(rows, K, N) if rows <= 2048 else 0
+    need = lib.dcll_readout_splitk_scratch(rows, K, N) if (rows <= 2048 and mode == READOUT_AUTO) else 0
     if need > 0 and pv2d.data_ptr() % 16 == 0 and Wt.data_ptr() % 16 == 0:
         # few rows of a long K (per-step calls on a large plane): K split over the workgroups, partials in scratch
         scratch = torch.empty((need,), device=pv2d.device, dtype=torch.float32)
         check(lib.dcll_readout_splitk(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), ptr(scratch), need, rows, K, N,
                                       stream_ptr()), "dcll_readout_splitk")
+        return out
+    if mode != READOUT_AUTO:
+        check(lib.dcll_readout_mode(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), rows, K, N, int(mode), stream_ptr()),
+              "dcll_readout_mode")
         return out
     check(lib.dcll_readout(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), rows, K, N, stream_ptr()), "dcll_readout")
     return out

@@ -714,3 +714,31 @@ def test_pv_lowhigh_counts_match_numpy_histogram(dev, per_step, T, iter0):
     for k, t in enumerate(steps):
         h = np.histogram(pv[t], bins=edges)[0]
         assert (int(got[k, 0]), int(got[k, 1])) == (int(h[0]), int(h[-1])), (k, t)
+
+
+@pytest.mark.parametrize("rows,K,N", [(2049, 8192, 24), (5000, 8192, 48), (2111, 8192, 10), (4096, 2048, 33),
+                                      (2300, 64, 48), (130, 8192, 24)])
+def test_readout_direct_forms(dev, rows, K, N):
+    """k_readout_direct (LDS-free 16x16x4 MFMA tiles, operands straight from global memory): its standalone form
+    (what dcll_readout picks for rows > 2048, K % 64 == 0, N <= 48) and its co-resident <= 64-VGPR form, against
+    float64 and against the LDS-staged kernels; ragged row / column tiles; a row's result does not depend on how many
+    rows the launch has."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(7)
+    pv = rng.uniform(0, 1, size=(rows, K)).astype(np.float32)
+    W = rng.uniform(-.0055, .0055, size=(N, K)).astype(np.float32)
+    b = rng.uniform(-.0055, .0055, size=(N,)).astype(np.float32)
+    ref = pv.astype(np.float64) @ W.astype(np.float64).T + b
+    dpv, dW, db = cu(pv, dev), cu(W, dev), cu(b, dev)
+    outs = {}
+    for mode in (ops.READOUT_AUTO, ops.READOUT_CORESIDENT, ops.READOUT_LDS):
+        guard = torch.full((rows + 8, N), 7.0, device=dev)          # rows behind the output must stay untouched
+        out = ops.readout(dpv, dW, db, out=guard[:rows], mode=mode)
+        assert float(guard[rows:].min()) == 7.0 and float(guard[rows:].max()) == 7.0
+        outs[mode] = out.cpu().numpy()
+        np.testing.assert_allclose(outs[mode], ref, atol=2e-5, rtol=0)
+    if rows > 2100:
+        part = ops.readout(dpv[:2100].contiguous(), dW, db, mode=ops.READOUT_CORESIDENT).cpu().numpy()
+        assert np.array_equal(part, outs[ops.READOUT_CORESIDENT][:2100])
+        part = ops.readout(dpv[:2100].contiguous(), dW, db).cpu().numpy()
+        assert np.array_equal(part, outs[ops.READOUT_AUTO][:2100])
