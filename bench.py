@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--fuse-readout", type=int, default=0, help="1: readouts in the layer kernel's epilogue")
     ap.add_argument("--output-only", type=int, default=0,
                     help="1: serving mode — hidden layers skip pv and their local readouts (NOT the headline workload)")
+    ap.add_argument("--overlap-readout", type=int, default=None,
+                    help="1: readouts / statistics / votes on a second stream under the next layer's kernel "
+                         "(default: DCLL_OVERLAP_READOUT)")
     a = ap.parse_args()
     if a.gpus > 1 and not parallel.under_launcher():
         # started plainly (`python bench.py --gpus N`): this process becomes the launcher of N fresh rank processes and
@@ -164,7 +167,8 @@ def main():
         net.zero_states()
         net.reset()
         res = net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False, profile=profile,
-                                fuse_readout=bool(a.fuse_readout), output_only=bool(a.output_only))
+                                fuse_readout=bool(a.fuse_readout), output_only=bool(a.output_only),
+                                overlap_readout=None if a.overlap_readout is None else bool(a.overlap_readout))
         votes = [v if v is not None else res["vote"][-1] for v in res["vote"]]      # output_only: hidden layers have none
         tal = parallel.allreduce_tallies(parallel.tallies(votes, labels, N_CLASSES))
         return res, tal

@@ -998,9 +998,11 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
                 if (REFRACTORY) v = refractory(acc[r], arp[tl][r], alpharp, wrp, s);
                 else s = v > 0.0f;
                 const unsigned long long mk = __ballot(s);
-                // (SGPR data operand + immediate lane: none of the v_writelane hazards — those concern an SGPR lane select)
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)mk), "n"(r));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(myword) : "s"((uint32_t)(mk >> 32)), "n"(32 + r));
+                // wait states as the compiler places them around its own v_writelane (SGPR spills): two after the VALU
+                // write of the source SGPRs (v_cmp), two between writes of the same VGPR.  (Without them lane r received
+                // the stale content of the SGPR: measured, wrong spike words with a bit-exact v.)
+                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
+                    : "+v"(myword) : "s"((uint32_t)mk), "s"((uint32_t)(mk >> 32)), "n"(r), "n"(32 + r));
                 if (FAST) {
                     (pvb + ((r & 3) + 8 * (r >> 2)) * 256)[loff] = sigmoidf_dev(v);
                 } else if (co < c_out) {
@@ -1690,8 +1692,11 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
     if (rows == 0 || N == 0) return DCLL_OK;
     const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0;
     const bool direct_ok = fast && K % 64 == 0 && N <= 48 && K <= 16384 && mode != DCLL_READOUT_LDS;
-    if (direct_ok && (rows > 2048 || mode == DCLL_READOUT_CORESIDENT))
-        return dcll_launch_readout_direct(pv, Wt, bias, out, rows, K, N, mode == DCLL_READOUT_CORESIDENT ? 1 : 0, st);
+    // (standalone the LDS-free kernel is slower than the LDS-staged ones — 4.6 vs 3.5 ms for 24 rows, 6.9 vs 5.3 ms for 48
+    //  at B = 4096: its fragment-layout loads give the texture addresser one 16-byte piece per lane — so it only serves
+    //  the co-resident mode)
+    if (direct_ok && mode == DCLL_READOUT_CORESIDENT)
+        return dcll_launch_readout_direct(pv, Wt, bias, out, rows, K, N, st);
     if (rows <= 2048) {
         hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)((rows + RS_RB - 1) / RS_RB), (N + RS_NG - 1) / RS_NG), dim3(256),
                            0, st, pv, Wt, bias, out, rows, K, N);

@@ -53,10 +53,10 @@ int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const flo
                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
                         float *state_scratch, int T, int B, hipStream_t st);
 
-// k_readout_direct (dcll_readout.hip): LDS-free 16x16x4 readout GEMM; mode 0 standalone, 1 co-resident (<= 64 VGPRs)
+// k_readout_direct (dcll_readout.hip): LDS-free 16x16x4 readout GEMM in <= 64 VGPRs (fits beside a sequence kernel)
 __attribute__((visibility("hidden")))
 int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
-                               int mode, hipStream_t st);
+                               hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------------------
 // shared device helpers

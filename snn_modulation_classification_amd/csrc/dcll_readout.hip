@@ -109,21 +109,15 @@ void k_readout_direct(const float *__restrict__ pv, const float *__restrict__ Wt
     }
 }
 
-// mode 0: standalone (two row tiles per wave, occupancy hides the latency); mode 1: the co-resident form (one row tile
-// per wave, <= 64 VGPRs).  Requires K % 64 == 0, N <= 48, 16-byte aligned pv / Wt rows (the caller checked).
+// One row tile per wave, 16-float chunks: <= 64 VGPRs, no LDS.  Requires K % 64 == 0, N <= 48, 16-byte aligned pv / Wt
+// rows (the caller checked).
 int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
-                               int mode, hipStream_t st)
+                               hipStream_t st)
 {
-    const unsigned g2 = (unsigned)((rows + 127) / 128), g1 = (unsigned)((rows + 63) / 64);
-    if (mode == 0) {
-        if (N <= 16) hipLaunchKernelGGL((k_readout_direct<2, 1, 2, 4>), dim3(g2), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-        else if (N <= 32) hipLaunchKernelGGL((k_readout_direct<2, 2, 2, 4>), dim3(g2), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-        else hipLaunchKernelGGL((k_readout_direct<2, 3, 2, 3>), dim3(g2), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-    } else {
-        if (N <= 16) hipLaunchKernelGGL((k_readout_direct<1, 1, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-        else if (N <= 32) hipLaunchKernelGGL((k_readout_direct<1, 2, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-        else hipLaunchKernelGGL((k_readout_direct<1, 3, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-    }
+    const unsigned g1 = (unsigned)((rows + 63) / 64);
+    if (N <= 16) hipLaunchKernelGGL((k_readout_direct<1, 1, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    else if (N <= 32) hipLaunchKernelGGL((k_readout_direct<1, 2, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    else hipLaunchKernelGGL((k_readout_direct<1, 3, 1, 8>), dim3(g1), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     HIP_CHECK_LAUNCH("k_readout_direct");
     return DCLL_OK;
 }

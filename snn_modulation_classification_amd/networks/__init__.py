@@ -98,27 +98,32 @@ class ConvNetwork(torch.nn.Module):
         kinds = [s.dclllayer.sequence_kind() for s in self.dcll_slices]
         return kinds[0] == 'cells' and all(k == 'packed' for k in kinds[1:])
 
-    def _sequence_buffers(self, T, B, dev):
+    def _sequence_buffers(self, T, B, dev, n_pv=1):
         """Inter-layer spike, pv and logit buffers of one chunk, cached: flat allocations sized for the largest batch
-        seen so far at this T, handed out as (T, B, ...) views (a smaller last chunk reuses them)."""
+        seen so far at this T, handed out as (T, B, ...) views (a smaller last chunk reuses them).  n_pv = number of pv
+        buffers: 1 (every layer's readout runs before the next layer's kernel overwrites it) or one per layer (the
+        readouts run on a second stream under the next layer's kernel)."""
         key = (T, str(dev))
         L = self.dcll_slices[0].dclllayer
         C, (H, W) = L.out_channels, L.output_shape
         cache = self._seq_buffers.get(key)
+        if cache is not None and cache['cap'] >= B:
+            while len(cache['pv']) < n_pv:
+                cache['pv'].append(torch.empty(T * cache['cap'] * C * H * W, device=dev, dtype=torch.float32))
         if cache is None or cache['cap'] < B:
             self._seq_buffers.clear()
             n_ro = [self.target_size * (2 if i == self.num_layers - 1 else 1) for i in range(self.num_layers)]
             cmax = max(s.dclllayer.in_channels for s in self.dcll_slices)
             cache = dict(cap=B,
                          spk=[torch.empty(T * B * C * (H * W // 32), device=dev, dtype=torch.int32) for _ in range(2)],
-                         pv=torch.empty(T * B * C * H * W, device=dev, dtype=torch.float32),
+                         pv=[torch.empty(T * B * C * H * W, device=dev, dtype=torch.float32) for _ in range(n_pv)],
                          ro=[torch.empty(T * B * n, device=dev, dtype=torch.float32) for n in n_ro],
                          # snapshot area of the tiled kernels (planes other than 16x16): initial eps0 / eps1 of a layer
                          state_scratch=(torch.empty(2 * B * cmax * H * W, device=dev, dtype=torch.float32)
                                         if (H, W) != (16, 16) else None))
             self._seq_buffers[key] = cache
         return dict(spk=[t[:T * B * C * (H * W // 32)].view(T, B, C, H * W // 32) for t in cache['spk']],
-                    pv=cache['pv'][:T * B * C * H * W].view(T, B, C, H, W),
+                    pv=[t[:T * B * C * H * W].view(T, B, C, H, W) for t in cache['pv']],
                     ro=[t[:T * B * (t.numel() // (T * cache['cap']))].view(T, B, -1) for t in cache['ro']],
                     state_scratch=cache['state_scratch'])
 
@@ -130,7 +135,7 @@ class ConvNetwork(torch.nn.Module):
 
     @torch.no_grad()
     def test_sequence(self, cells=None, collect=True, profile=None, fuse_readout=False, iq=None, encoder=None,
-                      T=None, t0=None, output_only=False):
+                      T=None, t0=None, output_only=False, overlap_readout=None):
         """Equivalent of `for t in range(T): net.test(x[t])` for input given as cell indices (T,B) int32 on device
         (one input spike per sample per step, what iq2spiketrain produces), or as the raw IQ batch `iq` (B,2,L) with an
         `IQEncoder` — then the quantisation runs inside the first layer's kernel (T steps from sample t0; t0 drawn
@@ -146,8 +151,15 @@ class ConvNetwork(torch.nn.Module):
         hidden layers neither materialise pv nor run their local readouts (their entries in the result are None and
         their `clout` is left untouched) — the spike trains and the output layer's logits / votes are unchanged.
 
+        `overlap_readout` (default: DCLL_OVERLAP_READOUT, off): the layer kernels run on a high-priority stream and
+        the HBM-bound work behind each of them — pv statistics, readout GEMM (in its LDS-free <= 64-VGPR form), argmax /
+        vote — on the caller's stream, so that it executes in the gaps of the NEXT layer's matrix-bound kernel instead
+        of after it; one pv buffer per layer instead of one.  Results are identical up to the readout's summation order.
+
         Returns a dict with device tensors: 'logits' (per layer, (T,B,target); last entry = output_ layer),
         'clout' (per layer (T,B) int32) and 'vote' (per layer (B) int32)."""
+        if overlap_readout is None:
+            overlap_readout = os.environ.get('DCLL_OVERLAP_READOUT', '0') != '0'
         if not self.sequence_supported():
             raise ops._lib.DCLLUnsupported('no fused sequence kernel for this network geometry; use net.test(x[t])')
         if iq is not None:
@@ -176,7 +188,7 @@ class ConvNetwork(torch.nn.Module):
                     (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None
                     else cells[:, b0:b1].contiguous(),
                     'iq' if iq is not None else 'cells', T, b1 - b0, dev, profile, fuse_readout, batch_slice=b0,
-                    output_only=output_only))
+                    output_only=output_only, overlap=overlap_readout))
             cat = lambda key, dim: [None if parts[0][key][i] is None else torch.cat([p[key][i] for p in parts], dim)
                                     for i in range(self.num_layers)]
             res = dict(logits=cat('logits', 1), clout=cat('clout', 1), vote=cat('vote', 0),
@@ -187,7 +199,7 @@ class ConvNetwork(torch.nn.Module):
         else:
             res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None else cells,
                                        'iq' if iq is not None else 'cells', T, B, dev, profile, fuse_readout,
-                                       output_only=output_only)
+                                       output_only=output_only, overlap=overlap_readout)
         if collect:
             for i, s in enumerate(self.dcll_slices):
                 if res['clout'][i] is not None:
@@ -197,13 +209,23 @@ class ConvNetwork(torch.nn.Module):
         return res
 
     def _sequence_chunk(self, first_input, first_kind, T, B, dev, profile, fuse_readout, batch_slice=None,
-                        output_only=False):
+                        output_only=False, overlap=False):
         """All layers over all T steps for B samples (the whole batch, or rows batch_slice.. of every layer's state)."""
         for s in self.dcll_slices:
             i2h = s.dclllayer.i2h
             if batch_slice is None and (i2h.state is None or i2h.state.eps0.shape[0] != B):
                 i2h.init_state(B, s.dclllayer.im_dims)
-        buf = self._sequence_buffers(T, B, dev)
+        overlap = overlap and not fuse_readout
+        buf = self._sequence_buffers(T, B, dev, n_pv=self.num_layers if overlap else 1)
+        main = torch.cuda.current_stream(dev)
+        hot = None
+        if overlap:
+            # layer kernels on a high-priority stream of their own; the caller's stream keeps everything behind them
+            if getattr(self, '_hot_stream', None) is None or self._hot_stream.device != torch.device(dev):
+                self._hot_stream = torch.cuda.Stream(device=dev, priority=-1)
+                self._ro_done = {}
+            hot = self._hot_stream
+            hot.wait_stream(main)                   # inputs and neuron state were prepared on the caller's stream
 
         def timed(key, fn, *a, **kw):
             if profile is None:
@@ -222,13 +244,28 @@ class ConvNetwork(torch.nn.Module):
             last = (i == self.num_layers - 1)
             fused = fuse_readout and i > 0
             hidden_skip = output_only and not last
-            lbuf = dict(spk=buf['spk'][i & 1], pv=buf['pv'], ro=buf['ro'][i], state_scratch=buf['state_scratch'])
+            lbuf = dict(spk=buf['spk'][i & 1], pv=buf['pv'][i if overlap else 0], ro=buf['ro'][i],
+                        state_scratch=buf['state_scratch'])
             # pv statistics of the reference's histogram steps (:658-661) for slices that collect them; counted from
             # the slice's iteration count as T calls of forward() would
-            spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B,
-                                first_kind if i == 0 else 'packed', want_spikes=not last, buffers=lbuf,
-                                fuse_readout=fused and not hidden_skip, batch_slice=batch_slice,
-                                want_pv=not hidden_skip, lowhigh_iter0=s.iter if s.collect_stats else None)
+            stats_iter0 = s.iter if (s.collect_stats and not hidden_skip) else None
+            kind = first_kind if i == 0 else 'packed'
+            if overlap:
+                if i in self._ro_done:
+                    hot.wait_event(self._ro_done[i])    # the previous readout of this layer's pv buffer has finished
+                with torch.cuda.stream(hot):
+                    spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B, kind,
+                                        want_spikes=not last, buffers=lbuf, fuse_readout=False, batch_slice=batch_slice,
+                                        want_pv=not hidden_skip, lowhigh_iter0=None)
+                    done = torch.cuda.Event()
+                    done.record(hot)
+                main.wait_event(done)
+                if stats_iter0 is not None:
+                    lbuf['lowhigh'] = ops.pv_lowhigh(pv.reshape(T, -1), T, stats_iter0)
+            else:
+                spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B, kind,
+                                    want_spikes=not last, buffers=lbuf, fuse_readout=fused and not hidden_skip,
+                                    batch_slice=batch_slice, want_pv=not hidden_skip, lowhigh_iter0=stats_iter0)
             res['lowhigh'].append(lbuf.get('lowhigh'))
             if hidden_skip:
                 res['logits'].append(None)
@@ -247,7 +284,11 @@ class ConvNetwork(torch.nn.Module):
                 # readout GEMM over all (t, b) rows; on the output layer i2o and output_ share ONE pass over pv
                 pv2d = pv.reshape(T * B, -1)
                 Wt, bias = L.stacked_readout()
-                ro = timed('readout', ops.readout, pv2d, Wt, bias, out=buf['ro'][i].reshape(T * B, -1))
+                ro = timed('readout', ops.readout, pv2d, Wt, bias, out=buf['ro'][i].reshape(T * B, -1),
+                           mode=ops.READOUT_CORESIDENT if overlap else ops.READOUT_AUTO)
+                if overlap:
+                    self._ro_done[i] = torch.cuda.Event()
+                    self._ro_done[i].record(main)
                 ro = ro.reshape(T, B, -1)
                 p = ro[..., :self.target_size]
                 logits = p
@@ -260,6 +301,8 @@ class ConvNetwork(torch.nn.Module):
             res['clout'].append(clout)
             res['vote'].append(vote)
             cur = spk
+        if overlap:
+            main.wait_stream(hot)                   # the neuron state written back by the last layer kernel
         if batch_slice is not None and 'o' in res:
             res['o'] = res['o'].clone()
         return res

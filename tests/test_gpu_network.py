@@ -728,3 +728,37 @@ def test_fused_path_fills_pv_activity_statistics(R_, T, B, capsys):
     out_b = capsys.readouterr().out
     assert out_a == out_b and out_a.count(" low:") == 3
     assert wa.scalars == wb.scalars and any("low_pv" in k for k in wa.scalars)
+
+
+@pytest.mark.parametrize("R_,T,B,chunked", [(16, 40, 70, False), (16, 24, 90, True), (32, 21, 3, False)])
+def test_overlapped_readout_equals_serial_path(R_, T, B, chunked):
+    """test_sequence(overlap_readout=True): layer kernels on a high-priority stream, statistics / readout (co-resident
+    form) / votes on the caller's stream under the next layer's kernel, one pv buffer per layer.  Same spikes (final
+    state bit-equal), same statistics, logits equal up to the readout's summation order, also when the batch runs in
+    chunks (each chunk's buffers are reused while the previous chunk's readouts may still be running)."""
+    rng = np.random.RandomState(9)
+    cells = torch.from_numpy(rng.randint(0, R_ * R_, size=(T, B)).astype(np.int32)).cuda()
+    nets = [_radio_net(B, R_), _radio_net(B, R_)]
+    res = []
+    for net, ov in zip(nets, (False, True)):
+        if chunked:
+            net.pv_budget_bytes = 4 * T * 32 * R_ * R_ * 32          # 32 windows per chunk -> 3 chunks
+        for rep in range(2):                                         # second pass: buffers and events are reused
+            net.zero_states()
+            net.reset()
+            r = net.test_sequence(cells, overlap_readout=ov)
+        torch.cuda.synchronize()
+        res.append(r)
+    a, b = res
+    for i in range(3):
+        assert torch.equal(a["vote"][i], b["vote"][i])
+        np.testing.assert_allclose(b["logits"][i].cpu().numpy(), a["logits"][i].cpu().numpy(), atol=2e-5, rtol=0)
+        tie = (a["logits"][i] if i < 2 else a["o"]).topk(2, dim=-1).values
+        ok = (a["clout"][i] == b["clout"][i]) | ((tie[..., 0] - tie[..., 1]) < 1e-4)
+        assert bool(ok.all())
+        assert torch.equal(a["lowhigh"][i], b["lowhigh"][i]) and a["lowhigh"][i].shape == (T // 20, 2)
+        for name in ("eps0", "eps1", "arp"):
+            assert torch.equal(getattr(nets[0].dcll_slices[i].dclllayer.i2h.state, name),
+                               getattr(nets[1].dcll_slices[i].dclllayer.i2h.state, name)), (i, name)
+        assert len(nets[1].dcll_slices[i].activity_hist) == T // 20
+    np.testing.assert_allclose(b["o"].cpu().numpy(), a["o"].cpu().numpy(), atol=2e-5, rtol=0)
