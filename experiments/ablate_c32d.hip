@@ -1,8 +1,13 @@
 // Stage-phase timing of k_lif_seq_c32d (diagnostic, not product).
+//   ./ablate_c32d            the kernel alone
+//   ./ablate_c32d co         with the co-resident readout (k_readout_direct, <= 64 VGPRs, no LDS) running on a second,
+//                            lower-priority stream over the previous pv buffer — what test_sequence(overlap_readout=True)
+//                            does: how much does a stage of the layer kernel stretch?
 #include "../snn_modulation_classification_amd/csrc/dcll_hip.hip"
 #include <vector>
-int main()
+int main(int argc, char **argv)
 {
+    const bool co = argc > 1;
     const int B = 1024, T = 128;
     size_t nin = (size_t)T * B * 32 * 8;
     uint32_t *spk_in, *spk_out; float *W, *bias, *tau4, *e0, *e1, *arp, *pv; unsigned long long *dbg;
@@ -16,14 +21,41 @@ int main()
     hipMemset(e0, 0, ns * 4); hipMemset(e1, 0, ns * 4); hipMemset(arp, 0, ns * 4);
     hipMalloc(&pv, (size_t)T * ns * 4); hipMalloc(&dbg, 4096); hipMemset(dbg, 0, 4096);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int rep = 0; rep < 3; ++rep) {
+    // co-resident readout: 24 rows over a second pv buffer (T*B rows of 8192), launched back to back on its own stream so
+    // that it runs for the whole duration of the layer kernel
+    float *pv2 = nullptr, *Wro = nullptr, *ro = nullptr;
+    hipStream_t side = nullptr;
+    int lo, hi;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipStream_t hot;
+    hipStreamCreateWithPriority(&hot, hipStreamNonBlocking, hi);
+    if (co) {
+        hipMalloc(&pv2, (size_t)T * ns * 4); hipMemset(pv2, 0, (size_t)T * ns * 4);
+        hipMalloc(&Wro, 24 * 8192 * 4); hipMemset(Wro, 0, 24 * 8192 * 4); hipMalloc(&ro, (size_t)T * B * 24 * 4);
+        hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo);
+    }
+    auto launch_side = [&](int n) {
+        for (int i = 0; i < n; ++i) dcll_launch_readout_direct(pv2, Wro, nullptr, ro, (long)T * B, 8192, 24, side);
+    };
+    for (int rep = 0; rep < 3 && !co; ++rep) {
         hipEventRecord(a);
         hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("k_lif_seq_c32d B=%d T=%d: %.2f ms (ideal at 157.3 TF: %.2f)\n", B, T, ms, 2.0 * 32 * 1568 * 256 * (double)T * B / 157.3e12 * 1e3);
     }
-    hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 1>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
+    if (co) {
+        hipDeviceSynchronize();
+        launch_side(40);                            // far longer than the layer kernel
+        hipEventRecord(a, hot);
+    }
+    hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 1>), dim3(B), dim3(512), 0, hot, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
+    if (co) {
+        hipEventRecord(b, hot); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("k_lif_seq_c32d B=%d T=%d with the co-resident readout running: %.2f ms\n", B, T, ms);
+    }
+    hipDeviceSynchronize();
     unsigned long long h[64];
     hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
     const double nst = 4.0 * T + 8;

@@ -17,7 +17,7 @@ for N in (24, 48):
     W = (torch.rand(N, K, device=dev) - 0.5) * 0.011
     b = (torch.rand(N, device=dev) - 0.5) * 0.011
     outs = {}
-    for name, mode in (("lds_32x32x2", ops.READOUT_LDS), ("direct_16x16x4", ops.READOUT_AUTO),
+    for name, mode in (("lds_32x32x2", ops.READOUT_LDS), ("lds_16x16x4", ops.READOUT_T16), ("auto", ops.READOUT_AUTO),
                        ("direct_coresident", ops.READOUT_CORESIDENT)):
         out = torch.empty(rows, N, device=dev)
         for _ in range(2):

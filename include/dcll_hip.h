@@ -196,10 +196,11 @@ int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out
  *                            16-byte aligned rows; other shapes fall back to AUTO): a workgroup of it fits on a CU beside a
  *                            resident sequence-kernel workgroup, so a readout launched on a second stream runs in the gaps
  *                            of the next layer's kernel instead of after it;
- *   DCLL_READOUT_LDS         the LDS-staged 32x32x2 kernels only (measurements).
+ *   DCLL_READOUT_LDS         the LDS-staged 32x32x2 kernels only (measurements);
+ *   DCLL_READOUT_T16         the LDS-staged 16x16x4 kernel (K % 32 == 0, N <= 64, aligned rows; else AUTO).
  * Logits of different modes differ by summation order only (within the 1e-4 contract).
  */
-enum { DCLL_READOUT_AUTO = 0, DCLL_READOUT_CORESIDENT = 1, DCLL_READOUT_LDS = 2 };
+enum { DCLL_READOUT_AUTO = 0, DCLL_READOUT_CORESIDENT = 1, DCLL_READOUT_LDS = 2, DCLL_READOUT_T16 = 3 };
 int dcll_readout_mode(const float *pv, const float *Wt, const float *bias, float *out,
                       int64_t rows, int32_t K, int32_t N, int32_t mode, void *stream);
 

@@ -1426,6 +1426,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = w & 3, wpar = w >> 2;        // my epilogue share: quad wq of the pair's tile wpar
     const long b = blockIdx.x;
+    // Highest wave priority for the whole kernel: all eight waves carry it, so nothing changes among them, but the waves
+    // of ANOTHER kernel resident on the same SIMDs (the co-resident readout of test_sequence(overlap_readout=True),
+    // priority 0) only get the issue slots these waves leave idle.
+    __builtin_amdgcn_s_setprio(3);
 
     for (int i = tid; i < 2 * IMG_FLOATS; i += 512) lds[i] = 0.0f;
     // slot layout: float4 c of lane l = accumulator registers 4c..4c+3 = channels (r&3) + 8c + 4(l>>5)
@@ -1697,6 +1701,7 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
     //  the co-resident mode)
     if (direct_ok && mode == DCLL_READOUT_CORESIDENT)
         return dcll_launch_readout_direct(pv, Wt, bias, out, rows, K, N, st);
+    if (fast && mode == DCLL_READOUT_T16) return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, st);     // any row count
     if (rows <= 2048) {
         hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)((rows + RS_RB - 1) / RS_RB), (N + RS_NG - 1) / RS_NG), dim3(256),
                            0, st, pv, Wt, bias, out, rows, K, N);
@@ -1708,6 +1713,10 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
             hipLaunchKernelGGL(k_readout_ks<1>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, 0);
         else
             hipLaunchKernelGGL(k_readout_ks<2>, dim3(nblk(rows, RK_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, 0);
+    } else if (fast && mode != DCLL_READOUT_LDS) {
+        // 16x16x4 tiles: 24 rows = 2 tiles, 48 stacked rows = 3 tiles without padding (2.9 / 3.9 ms at B = 4096 vs 3.5 / 5.3 ms
+        // for the 32-column tiles of k_readout_v4 below, which stay for DCLL_READOUT_LDS)
+        return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, st);
     } else if (fast && N <= 32) {
         hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast) {
@@ -1732,7 +1741,7 @@ extern "C" int dcll_readout_mode(const float *pv, const float *Wt, const float *
                                  int32_t K, int32_t N, int32_t mode, void *stream)
 {
     if (rows == 0) return DCLL_OK;
-    if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1 || mode < DCLL_READOUT_AUTO || mode > DCLL_READOUT_LDS)
+    if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1 || mode < DCLL_READOUT_AUTO || mode > DCLL_READOUT_T16)
         return fail(DCLL_ERR_INVALID, "dcll_readout_mode: bad argument");
     return launch_readout(pv, Wt, bias, out, rows, K, N, (hipStream_t)stream, mode);
 }

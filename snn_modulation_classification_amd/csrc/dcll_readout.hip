@@ -121,3 +121,102 @@ int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bi
     HIP_CHECK_LAUNCH("k_readout_direct");
     return DCLL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// k_readout_t16 — the standalone readout GEMM on 16x16x4 tiles: 128 rows x (NT x 16) readout rows per workgroup, K in
+// chunks of 32 staged through LDS (the fragment-layout problem of k_readout_direct does not arise: global loads are
+// plain coalesced float4 rows).  48 stacked readout rows are 3 x 16 — no padding (k_readout_v4<2> pads them to 64 and
+// is matrix-bound: 5.3 ms at B = 4096 vs 3.5 ms for 24 rows).
+// LDS rows have stride 36 floats: 16-byte aligned, so staging is one ds_write_b128 per float4 and a fragment is one
+// ds_read_b128 — lane (i = lane & 15, kq = lane >> 4) reads k = 16 g + 4 kq .. + 3 of row i, its operands of the 4 MFMAs
+// of k-group g (the k order inside a group is permuted identically for A and B) — and 36 = 4 mod 32 makes the eight
+// lanes of a b128 phase cover the 32 banks exactly once.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int T16_ROWS = 128, T16_KC = 32, T16_LD = 36;
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ pv, const float *__restrict__ Wt,
+                                                      const float *__restrict__ bias, float *__restrict__ out,
+                                                      long rows, int K, int N)
+{
+    __shared__ __attribute__((aligned(16))) float sA[T16_ROWS * T16_LD];
+    __shared__ __attribute__((aligned(16))) float sB[NT * 16 * T16_LD];
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * T16_ROWS;
+    const int kc = (tid & 7) * 4, rsub = tid >> 3;          // 8 threads x float4 = one 32-float K-chunk of a row
+    constexpr int NBF = (NT * 16 * 8 + 255) / 256;          // float4 loads of the weight chunk per thread
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[4], rb[NBF];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long gr = row0 + rsub + 32 * q;
+            ra[q] = gr < rows ? __builtin_nontemporal_load((const f32x4 *)(pv + gr * K + k0 + kc))
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < NBF; ++q) {
+            const int nn = rsub + 32 * q;
+            rb[q] = (nn < N && nn < NT * 16) ? *(const f32x4 *)(Wt + (long)nn * K + k0 + kc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += T16_KC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4 *)(sA + (rsub + 32 * q) * T16_LD + kc) = ra[q];
+#pragma unroll
+        for (int q = 0; q < NBF; ++q)
+            if (rsub + 32 * q < NT * 16) *(f32x4 *)(sB + (rsub + 32 * q) * T16_LD + kc) = rb[q];
+        __syncthreads();
+        if (k0 + T16_KC < K) fetch(k0 + T16_KC);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 a[2], b[NT];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) a[rt] = *(const f32x4 *)(sA + (wave * 32 + rt * 16 + i) * T16_LD + 16 * g + 4 * kq);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4 *)(sB + (nt * 16 + i) * T16_LD + 16 * g + 4 * kq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][e], b[nt][e], acc[rt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D layout of a 16x16 tile: column (readout row n) = lane & 15, row = 4 (lane >> 4) + register
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + i;
+        if (n < N) {
+            const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long r = row0 + wave * 32 + rt * 16 + 4 * kq + q;
+                    if (r < rows) out[r * N + n] = acc[rt][nt][q] + bn;
+                }
+        }
+    }
+}
+
+// Requires K % 32 == 0, N <= 64, 16-byte aligned pv / Wt rows (the caller checked).
+int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
+                            hipStream_t st)
+{
+    const unsigned g = (unsigned)((rows + T16_ROWS - 1) / T16_ROWS);
+    if (N <= 16) hipLaunchKernelGGL(k_readout_t16<1>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    else if (N <= 32) hipLaunchKernelGGL(k_readout_t16<2>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    else if (N <= 48) hipLaunchKernelGGL(k_readout_t16<3>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    else hipLaunchKernelGGL(k_readout_t16<4>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    HIP_CHECK_LAUNCH("k_readout_t16");
+    return DCLL_OK;
+}

@@ -292,7 +292,7 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
     return spk, pv, v
 
 
-READOUT_AUTO, READOUT_CORESIDENT, READOUT_LDS = 0, 1, 2       # dcll_readout_mode (include/dcll_hip.h)
+READOUT_AUTO, READOUT_CORESIDENT, READOUT_LDS, READOUT_T16 = 0, 1, 2, 3       # dcll_readout_mode (include/dcll_hip.h)
 
 
 def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO):

@@ -731,7 +731,7 @@ def test_readout_direct_forms(dev, rows, K, N):
     ref = pv.astype(np.float64) @ W.astype(np.float64).T + b
     dpv, dW, db = cu(pv, dev), cu(W, dev), cu(b, dev)
     outs = {}
-    for mode in (ops.READOUT_AUTO, ops.READOUT_CORESIDENT, ops.READOUT_LDS):
+    for mode in (ops.READOUT_AUTO, ops.READOUT_CORESIDENT, ops.READOUT_LDS, ops.READOUT_T16):
         guard = torch.full((rows + 8, N), 7.0, device=dev)          # rows behind the output must stay untouched
         out = ops.readout(dpv, dW, db, out=guard[:rows], mode=mode)
         assert float(guard[rows:].min()) == 7.0 and float(guard[rows:].max()) == 7.0
