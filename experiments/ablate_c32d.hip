@@ -44,6 +44,26 @@ int main(int argc, char **argv)
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("k_lif_seq_c32d B=%d T=%d: %.2f ms (ideal at 157.3 TF: %.2f)\n", B, T, ms, 2.0 * 32 * 1568 * 256 * (double)T * B / 157.3e12 * 1e3);
     }
+    if (!co) {
+        // what do the LDS bank conflicts of the B-fragment reads cost?  Same kernel with the tile's second image row read
+        // 16 instead of 19 floats behind the first (conflict free, WRONG data — timing only), same stamps.
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 2>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("k_lif_seq_c32d, conflict-free B reads (wrong data): %.2f ms\n", ms);
+        }
+        hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 3>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
+        unsigned long long h2[64];
+        hipMemcpy(h2, dbg, 512, hipMemcpyDeviceToHost);
+        const double nst2 = 4.0 * T + 8;
+        printf("conflict-free variant: cycles per stage | non-MFMA phase | barrier 2 | chains + slot write | barrier 1\n");
+        for (int w = 0; w < 8; ++w)
+            printf("  w%d: %8.0f | %7.0f | %7.0f | %7.0f | %7.0f\n", w, h2[w * 8] / nst2, h2[w * 8 + 1] / nst2, h2[w * 8 + 2] / nst2,
+                   h2[w * 8 + 3] / nst2, h2[w * 8 + 4] / nst2);
+        hipMemset(dbg, 0, 4096);
+    }
     if (co) {
         hipDeviceSynchronize();
         launch_side(40);                            // far longer than the layer kernel

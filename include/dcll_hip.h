@@ -110,6 +110,41 @@ int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const flo
                            const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
                            float *scratch, int64_t scratch_floats, int32_t B, void *stream);
 
+/*
+ * The rest of a local-learning step (DCLLBase.train_dcll :690-718) around dcll_conv_lif_step / dcll_conv_lif_backward, so
+ * that the per-timestep loop needs no torch op:
+ *
+ * dcll_local_loss_grad — gradient and value of the local losses with mean reduction (what loss.backward() hands to the
+ *   readouts): loss = crit(p, target) [+ crit(o, target) when o != NULL], g_p = d loss / d p, g_o = d loss / d o.
+ *   p, o, target, g_p, g_o (B,N) fp32; loss: 1 float, may be NULL.  kind: DCLL_LOSS_SMOOTH_L1 (torch.nn.SmoothL1Loss,
+ *   beta 1 — train.py's default --loss_type) or DCLL_LOSS_MSE (torch.nn.MSELoss).
+ *
+ * dcll_adam_step — torch.optim.Adam's update (amsgrad False; L2 weight decay added to the gradient; bias correction by
+ *   `step`) over up to DCLL_ADAM_MAX_TENSORS parameter tensors — of one or of several optimizers — in one launch.  train.py
+ *   (:164-168) builds the optimizers with betas (0, beta) and weight_decay 10; exp_avg / exp_avg_sq are the optimizer's
+ *   own state tensors, so optimizer.state_dict() stays what torch would have produced.  `tensors` is a HOST array.
+ *
+ * dcll_cells_to_planes — iq2spiketrain's dense spike planes (data/utils.py:81-82) from cell indices on the device:
+ *   planes (n_samples, hw) fp32 = one-hot of cells (n_samples) int32; hw % 4 == 0.
+ */
+enum { DCLL_LOSS_SMOOTH_L1 = 0, DCLL_LOSS_MSE = 1 };
+int dcll_local_loss_grad(const float *p, const float *o, const float *target, float *g_p, float *g_o, float *loss,
+                         int32_t B, int32_t N, int32_t kind, void *stream);
+
+#define DCLL_ADAM_MAX_TENSORS 8
+typedef struct dcll_adam_tensor {
+    float *param;               /* updated in place                                                       */
+    const float *grad;
+    float *exp_avg, *exp_avg_sq; /* optimizer state, updated in place                                     */
+    int64_t n;                  /* elements                                                               */
+    int64_t step;               /* 1-based count of this update (bias correction)                         */
+    float lr, weight_decay, beta1, beta2, eps;  /* of the tensor's param group (the slices' optimizers differ: */
+                                /* optimizer2 of the output layer runs torch's default betas, :637-638)  */
+} dcll_adam_tensor;
+int dcll_adam_step(const dcll_adam_tensor *tensors, int32_t n_tensors, void *stream);
+
+int dcll_cells_to_planes(const int32_t *cells, float *planes, int64_t n_samples, int32_t hw, void *stream);
+
 /* One timestep of DenseDCLLlayer.forward — drop-in for dcll/pytorch_libdcll.py:250-255 (dropout = identity). */
 int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W, const float *b,
                         const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,

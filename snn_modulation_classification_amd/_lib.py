@@ -38,7 +38,19 @@ class DenseDesc(ctypes.Structure):
                [("alpharp", ctypes.c_float), ("wrp", ctypes.c_float)]
 
 
+class AdamTensor(ctypes.Structure):
+    """dcll_adam_tensor"""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_int64), ("step", ctypes.c_int64),
+                ("lr", ctypes.c_float), ("weight_decay", ctypes.c_float), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
+ADAM_MAX_TENSORS = 8
+LOSS_SMOOTH_L1, LOSS_MSE = 0, 1
+
 _P, _I32, _I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+_F32 = ctypes.c_float
 _DP = ctypes.POINTER(ConvDesc)
 _DDP = ctypes.POINTER(DenseDesc)
 _IP = ctypes.POINTER(ctypes.c_int32)
@@ -50,6 +62,9 @@ SIGNATURES = {
     "dcll_conv_out_shape": (_I32, [_DP, _IP, _IP, _IP, _IP]),
     "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_I32, _P]),
     "dcll_conv_lif_backward": (_I32, [_DP] + [_P] * 13 + [_I64, _I32, _P]),
+    "dcll_local_loss_grad": (_I32, [_P] * 6 + [_I32, _I32, _I32, _P]),
+    "dcll_adam_step": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P]),
+    "dcll_cells_to_planes": (_I32, [_P, _P, _I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
     "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _P, _P, _I32, _I32, _I32, _P]),
     "dcll_permute_readout": (_I32, [_P, _P, _I32, _P]),

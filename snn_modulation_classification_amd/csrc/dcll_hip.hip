@@ -1473,7 +1473,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         for (int rr = 0; rr < 4; ++rr)
             arp[k][rr] = REFRACTORY ? arp_g[(b * 32 + rr + 8 * wq + 4 * h) * 256 + 32 * (2 * k + wpar) + j] : 0.0f;
 
-    const int bbase = (4 * w + h) * CHF + (j >> 4) * ROWF + (j & 15);
+    // DBG & 2 (experiments/ablate_c32d.hip only, WRONG results): the second image row of a tile is read 16 instead of
+    // ROWF = 19 floats behind the first, which makes the B-fragment reads bank-conflict free — isolates what the 2-way
+    // conflicts on three banks of the real layout cost.
+    const int bbase = (4 * w + h) * CHF + (j >> 4) * ((DBG & 2) ? 16 : ROWF) + (j & 15);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -1489,7 +1492,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
     __syncthreads();
 
     unsigned long long dbg[4] = {0, 0, 0, 0}, dbg_t0 = 0;       // DBG only: non-MFMA phase, barrier 2, chains, barrier 1
-    if (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
+    if (DBG & 1) dbg_t0 = __builtin_amdgcn_s_memtime();
     // inputs of a wave's trace share of stage g (wave-uniform scalars + 4 eps1 values), fetched one stage ahead
     float sv[4] = {0.f, 0.f, 0.f, 0.f}, ta = 0.f, tm = 0.f, tas = 0.f, ts = 0.f;
     unsigned long long wm[4] = {0, 0, 0, 0};
@@ -1512,7 +1515,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
     auto stage = [&](const int g, auto UC) {
         constexpr int U = decltype(UC)::value;
         unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
-        if (DBG) st0 = __builtin_amdgcn_s_memtime();
+        if (DBG & 1) st0 = __builtin_amdgcn_s_memtime();
         const int q = g - w;
         const bool active = q >= 0 && q < 4 * T;
         const int p = q & 3, t = q >> 2;
@@ -1583,10 +1586,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
             }
             if (spk_out && j < 4) (spk_out + (ubase >> 5))[(4 * h + j) * 8 + me] = myword;
         }
-        if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
+        if (DBG & 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
         // every slot read of this stage has completed before any wave writes its slots again
         lds_barrier();
-        if (DBG) st2 = __builtin_amdgcn_s_memtime();
+        if (DBG & 1) st2 = __builtin_amdgcn_s_memtime();
         // inputs of the NEXT stage's trace share: they land while the chains run (the eps1 values it reads were
         // written by my own trace share four stages ago; nobody else touches my channels).  Issued before the first
         // MFMA: in the middle of the chains the same loads cost 1.5 % (24.65 vs 24.27 ms at B=1024).
@@ -1625,10 +1628,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
             for (int c = 0; c < 4; ++c)
                 dp[c * 64] = f32x4{accB[4 * c + 0], accB[4 * c + 1], accB[4 * c + 2], accB[4 * c + 3]};
         }
-        if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st3 = __builtin_amdgcn_s_memtime(); }
+        if (DBG & 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st3 = __builtin_amdgcn_s_memtime(); }
         // stage barrier: only the LDS traffic has to be complete, not the pv / spike stores of the epilogue
         lds_barrier();
-        if (DBG) {
+        if (DBG & 1) {
             const unsigned long long st4 = __builtin_amdgcn_s_memtime();
             dbg[0] += st1 - st0; dbg[1] += st2 - st1; dbg[2] += st3 - st2; dbg[3] += st4 - st3;
         }
@@ -1642,7 +1645,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         stage(g + 3, std::integral_constant<int, 3>{});
     }
 
-    if (DBG && lane == 0 && b == 0) {
+    if ((DBG & 1) && lane == 0 && b == 0) {
         unsigned long long *dp = (unsigned long long *)v_out + w * 8;       // v_out doubles as the debug buffer
         dp[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
         dp[1] = dbg[0]; dp[2] = dbg[1]; dp[3] = dbg[2]; dp[4] = dbg[3];

@@ -187,8 +187,9 @@ class ContinuousConv2D(nn.Module):
                 rows.append(flat[:, 0])
         return torch.stack(rows).contiguous()
 
-    def _step(self, input, pooling=(1, 1), i2o=None, output_=None):
-        """Run one step through dcll_conv_lif_step; returns (s_pooled, p, o, pv_pooled, v)."""
+    def _step(self, input, pooling=(1, 1), i2o=None, output_=None, out=None):
+        """Run one step through dcll_conv_lif_step; returns (s_pooled, p, o, pv_pooled, v).  `out`: optional dict of
+        reusable output buffers (ops.conv_lif_step)."""
         if not self.spiking:
             raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
         self._check_batch(input)
@@ -203,7 +204,7 @@ class ContinuousConv2D(nn.Module):
                 desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt,
                 st.eps0, st.eps1, arp,
                 None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
-                None if output_ is None else output_.weight, None if output_ is None else output_.bias)
+                None if output_ is None else output_.weight, None if output_ is None else output_.bias, out=out)
 
     def _fast_step_ok(self, input, pooling):
         """32->32, 7x7 pad 3, pool 1, per-channel time constants, on a plane with H % 8 == 0 and W % 32 == 0: the tiled
@@ -684,24 +685,132 @@ class DCLLBase(nn.Module):
 
     @staticmethod
     def _make_optimizer(optimizer, params, kwargs):
-        """optimizer(params, **kwargs) as in the reference (:634-638).  torch's Adam family runs as ONE fused
-        multi-tensor kernel per step on device parameters instead of ~10 (a local-learning step is launch- and
-        small-kernel-bound); same update rule, set DCLL_FUSED_OPTIMIZER=0 to get torch's default implementation."""
+        """optimizer(params, **kwargs) as in the reference (:634-638).  With DCLL_NATIVE_LEARNING=0 (the autograd
+        fallback) torch's Adam family is asked for its fused multi-tensor form; the native learning step below applies
+        Adam itself (dcll_adam_step) on the state tensors of this very optimizer object."""
         params = list(params)
-        if (os.environ.get('DCLL_FUSED_OPTIMIZER', '1') != '0' and optimizer in (optim.Adam, optim.AdamW) and
-                'fused' not in kwargs and 'foreach' not in kwargs and params and all(p.is_cuda for p in params)):
+        if (os.environ.get('DCLL_NATIVE_LEARNING', '1') == '0' and os.environ.get('DCLL_FUSED_OPTIMIZER', '1') != '0' and
+                optimizer in (optim.Adam, optim.AdamW) and 'fused' not in kwargs and 'foreach' not in kwargs and params
+                and all(p.is_cuda for p in params)):
             try:
                 return optimizer(params, fused=True, **kwargs)
             except (TypeError, RuntimeError, ValueError):
                 pass
         return optimizer(params, **kwargs)
 
+    # -- native local-learning step: HIP kernels only, no autograd graph, no torch op per timestep ---------------------
+    def _native_learning(self):
+        """The loss kind (ops.LOSS_KINDS) if this slice's learning step runs without torch ops — forward, loss gradient,
+        backward and Adam as C-ABI calls — else None (then train_dcll builds the autograd graph around the same HIP
+        forward / backward).  Served: Conv2dDCLLlayer; crit = SmoothL1Loss (beta 1) or MSELoss with mean reduction;
+        optimizer(s) = torch.optim.Adam without amsgrad / maximize / capturable / fused; DCLL_NATIVE_LEARNING != 0."""
+        cached = getattr(self, '_native_kind', 0)
+        if cached != 0:
+            return cached
+        kind = None
+        crit, opt = getattr(self, 'crit', None), getattr(self, 'optimizer', None)
+        ok = (os.environ.get('DCLL_NATIVE_LEARNING', '1') != '0' and isinstance(self.dclllayer, Conv2dDCLLlayer) and
+              crit is not None and opt is not None and getattr(crit, 'reduction', None) == 'mean')
+        if ok and type(crit) is nn.SmoothL1Loss and getattr(crit, 'beta', 1.0) == 1.0:
+            kind = ops.LOSS_KINDS['SmoothL1Loss']
+        elif ok and type(crit) is nn.MSELoss:
+            kind = ops.LOSS_KINDS['MSELoss']
+        if kind is not None and self.dclllayer.output_layer:
+            if type(self.output_crit) is not type(crit) or getattr(self.output_crit, 'reduction', None) != 'mean':
+                kind = None
+        opts = [opt] + ([getattr(self, 'optimizer2', None)] if (kind is not None and self.dclllayer.output_layer) else [])
+        for o in opts:
+            if kind is None:
+                break
+            if type(o) is not optim.Adam:
+                kind = None
+                break
+            for g in o.param_groups:
+                if g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('fused') or \
+                        g.get('differentiable') or isinstance(g['lr'], torch.Tensor):
+                    kind = None
+        self._native_kind = kind
+        return kind
+
+    def _learn_forward_backward(self, input, target):
+        """Forward of one step plus — once iter >= burnin (reference :691) — the gradients of the local loss(es) in the
+        .grad of i2h.weight / i2h.bias (and output_.weight / output_.bias): dcll_conv_lif_step -> dcll_local_loss_grad
+        -> dcll_conv_lif_backward, all on preallocated buffers.  No optimizer step.
+        -> (output, pvoutput, pv, pvmem, loss (1,) device tensor or None, learned)"""
+        L = self.dclllayer
+        i2h = L.i2h
+        bufs = self.__dict__.setdefault('_learn_bufs', {})
+        self.iter += 1
+        with torch.no_grad():
+            s, p, o, pv, v = i2h._step(input, L.pooling, L.i2o, L.output_ if L.output_layer else None, out=bufs)
+            if self.collect_stats and (self.iter % 20) == 0:
+                self.activity_hist.append((ops.pv_lowhigh(pv, 1, self.iter - 1)[0], pv.numel()))
+            learned = self.iter >= self.burnin
+            if learned:
+                # (DCLLClassification records the per-step argmax once the burn-in is over, :724-728)
+                if isinstance(self, DCLLClassification):
+                    self._clout.append(ops.argmax_vote((o if L.output_layer else p).unsqueeze(0), want_vote=False)[0][0])
+                g_p, g_o, loss = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(),
+                                                     out=bufs)
+                prm = [i2h.weight, i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
+                for q in prm:
+                    if q.grad is None:
+                        q.grad = torch.zeros_like(q)
+                desc = i2h.make_desc(input.shape[2:4], L.pooling, L.i2o.weight.shape[0], L.output_layer)
+                gb = bufs.setdefault('grads', {})
+                gb.update(dW=prm[0].grad, db=prm[1].grad)
+                if L.output_layer:
+                    gb.update(d_outW=prm[2].grad, d_outb=prm[3].grad)
+                ops.conv_lif_backward(desc, i2h.state.eps1, v, pv, g_p, g_o, None, None, L.i2o.weight,
+                                      want_out=L.output_layer, out=gb)
+            else:
+                loss = None
+        return (o if L.output_layer else s), p, pv, v, loss, learned
+
+    def _grad_tensors(self):
+        L = self.dclllayer
+        prm = [L.i2h.weight, L.i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
+        return [q.grad for q in prm]
+
+    def _adam_tensors(self):
+        """This slice's parameters as dcll_adam_step entries, on the state tensors of its torch optimizer objects (created
+        here, in torch's own layout, on first use): optimizer.state_dict() stays loadable by torch.optim.Adam."""
+        out = []
+        opts = [self.optimizer] + ([self.optimizer2] if self.dclllayer.output_layer else [])
+        for opt in opts:
+            for g in opt.param_groups:
+                for q in g['params']:
+                    if q.grad is None:
+                        continue
+                    st = opt.state[q]
+                    if len(st) == 0:
+                        st['step'] = torch.tensor(0.0)
+                        st['exp_avg'] = torch.zeros_like(q, memory_format=torch.preserve_format)
+                        st['exp_avg_sq'] = torch.zeros_like(q, memory_format=torch.preserve_format)
+                    st['step'] += 1
+                    out.append(dict(param=q.data, grad=q.grad, exp_avg=st['exp_avg'], exp_avg_sq=st['exp_avg_sq'],
+                                    lr=g['lr'], weight_decay=g['weight_decay'], beta1=g['betas'][0], beta2=g['betas'][1],
+                                    eps=g['eps'], step=int(st['step'])))
+        return out
+
     def train_dcll(self, input, target, do_train=True, regularize=0.05):
         """One local-learning step (reference :690-718): forward; after burn-in the local loss on pvoutput (+ the loss
-        on the output_ logits for the output layer), backward through the HIP backward kernels, optimizer step(s).
-        With torch.distributed initialised the gradients are averaged over the ranks (RCCL) before the step."""
+        on the output_ logits for the output layer), its gradients through the HIP backward kernels, optimizer step(s).
+        With torch.distributed initialised the gradients are averaged over the ranks (RCCL) before the step.
+        Without regularisers and with SmoothL1 / MSE losses and Adam (what train.py runs) the whole step is C-ABI calls
+        (`_native_learning`); otherwise the same HIP forward / backward run inside an autograd node and torch supplies the
+        loss module and the optimizer."""
         if not isinstance(self.dclllayer, Conv2dDCLLlayer):
             raise NotImplementedError('local learning is implemented for Conv2dDCLLlayer slices')
+        from .. import parallel
+        if not regularize and self._native_learning() is not None:
+            output, pvoutput, pv, pvmem, loss, learned = self._learn_forward_backward(input, target)
+            if learned:
+                parallel.allreduce_mean_tensors(self._grad_tensors(), local_n=input.shape[0])
+                if do_train:
+                    ops.adam_step(self._adam_tensors())
+            # (the loss value lives in a reused one-element device buffer: valid until the next step of this slice)
+            return output, pvoutput, pv, pvmem, (loss.reshape(()) if learned else torch.Tensor([0]))
         learn_now = (self.iter + 1) >= self.burnin
         self.dclllayer.build_graph = learn_now
         try:
@@ -720,7 +829,6 @@ class DCLLBase(nn.Module):
             else:
                 loss = tgt_loss
             loss.backward()
-            from .. import parallel
             parallel.allreduce_mean_grads([p for p in self.dclllayer.parameters() if p.grad is not None],
                                           local_n=input.shape[0])
             if do_train:
@@ -747,7 +855,8 @@ class DCLLClassification(DCLLBase):
         device counters of the histogram steps, `numel` pv values per step — the pv statistics appended to
         `activity_hist` (reference :658-661)."""
         self.iter += n_steps
-        self._clout.extend(clout_dev.to(torch.int64))       # like n_steps calls of forward(): appended, not replaced
+        if clout_dev is not None:       # (None: steps whose argmax is not recorded — the burn-in of a learning sequence)
+            self._clout.extend(clout_dev.to(torch.int64))   # like n_steps calls of forward(): appended, not replaced
         if lowhigh is not None and self.collect_stats:
             self.activity_hist.extend((row, numel) for row in lowhigh)
 

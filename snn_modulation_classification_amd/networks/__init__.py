@@ -67,9 +67,54 @@ class ConvNetwork(torch.nn.Module):
 
     # -- reference protocol (per step) ----------------------------------------------------------------------------
     def learn(self, x, labels):
-        spikes = x
+        """One timestep of local learning in every slice (reference :175-180).  When every slice's step is native
+        (DCLLBase._native_learning) the three phases are batched over the slices: all forwards + backwards (a slice's
+        weight update only matters from the NEXT timestep on, and slice l+1 consumes slice l's spikes, not its
+        weights), then ONE bucketed all-reduce of all gradients (multi-rank), then ONE Adam launch for all tensors."""
+        if not all(s._native_learning() is not None for s in self.dcll_slices):
+            spikes = x
+            for s in self.dcll_slices:
+                spikes, _, _, _, _ = s.train_dcll(spikes, labels, regularize=False)
+            return
+        spikes, learned = x, []
         for s in self.dcll_slices:
-            spikes, _, _, _, _ = s.train_dcll(spikes, labels, regularize=False)
+            spikes, _, _, _, _, l = s._learn_forward_backward(spikes, labels)
+            if l:
+                learned.append(s)
+        if learned:
+            from .. import parallel
+            parallel.allreduce_mean_tensors([g for s in learned for g in s._grad_tensors()], local_n=x.shape[0])
+            ops.adam_step([t for s in learned for t in s._adam_tensors()])
+
+    @torch.no_grad()
+    def learn_sequence(self, cells, labels):
+        """train.py's inner loop `for t in range(T): net.learn(x[t], labels[t])` (reference train.py:249-251) for input
+        given as cell indices (T,B) int32 ON THE DEVICE (IQEncoder: iq2spiketrain's quantisation as a kernel) and one
+        one-hot label row per sample (B, target) — iq2spiketrain repeats the labels over t.  No host spike encoding, no
+        dense (T,B,1,H,W) upload:
+          - the burn-in steps (no slice learns before its iter reaches burnin, :691, so the weights are frozen) run on
+            the fused all-T sequence kernels when the geometry has them; their argmax is not recorded, exactly like
+            DCLLClassification.forward without ignore_burnin (:724);
+          - the learning steps run per timestep (the weights change every step) on one-hot planes built on the device,
+            a block of timesteps at a time."""
+        T, B = cells.shape
+        L0 = self.dcll_slices[0].dclllayer
+        H, W = L0.im_dims
+        # steps during which NO slice learns yet: slice s learns in the step that takes its iter to >= burnin
+        nb = max(0, min(T, min(s.burnin - 1 - s.iter for s in self.dcll_slices)))
+        if nb > 0 and self.sequence_supported():
+            res = self.test_sequence(cells[:nb].contiguous(), collect=False)
+            for i, s in enumerate(self.dcll_slices):
+                Li = s.dclllayer
+                s.set_sequence_result(None, nb, lowhigh=res['lowhigh'][i],
+                                      numel=B * Li.out_channels * int(np.prod(Li.output_shape)))
+        else:
+            nb = 0
+        block = max(1, int((1 << 28) // max(1, B * H * W)))        # <= 1 GiB of planes at a time
+        for t0 in range(nb, T, block):
+            planes = ops.cells_to_planes(cells[t0:t0 + block].contiguous(), H * W)
+            for k in range(planes.shape[0]):
+                self.learn(planes[k].reshape(B, 1, H, W), labels)
 
     def test(self, x):
         spikes = x

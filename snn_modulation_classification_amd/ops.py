@@ -66,11 +66,14 @@ def _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=None, tau4=None):
 
 
 def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None,
-                  out_W=None, out_b=None, want_v=True):
+                  out_W=None, out_b=None, want_v=True, out=None):
     """One Conv2dDCLLlayer.forward step (dcll/pytorch_libdcll.py:599-608); state tensors are updated in place.
 
     Returns (s_pooled, p, o, pv_pooled, v) — p / o are None when the corresponding weights are None.
+    `out`: optional dict of preallocated outputs ('s', 'pv', 'v', 'p', 'o', 'scratch'; filled in when absent) — the
+    learning loop reuses one set per layer instead of allocating five tensors per step.
     """
+    out = {} if out is None else out
     B = x.shape[0]
     ch, cw, ph, pw = conv_out_shape(desc)
     dev = x.device
@@ -84,13 +87,20 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     if desc.output_layer:
         _expect(out_W, "out_W", torch.float32, (desc.target, K_ro))
         _expect(out_b, "out_b", torch.float32, (desc.target,))
-    s = torch.empty((B, desc.c_out, ph, pw), device=dev, dtype=torch.float32)
-    pv = torch.empty_like(s)
-    v = torch.empty((B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if want_v else None
-    p = torch.empty((B, desc.target), device=dev, dtype=torch.float32) if i2o_W is not None else None
-    o = torch.empty((B, desc.target), device=dev, dtype=torch.float32) if desc.output_layer else None
+    def buf(key, shape, want=True):
+        if not want:
+            return None
+        t = out.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = out[key] = torch.empty(shape, device=dev, dtype=torch.float32)
+        return t
     pooled = not (desc.pool_h == 1 and desc.pool_w == 1)
-    scratch = torch.empty((2, B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if pooled else None
+    s = buf('s', (B, desc.c_out, ph, pw))
+    pv = buf('pv', (B, desc.c_out, ph, pw))
+    v = buf('v', (B, desc.c_out, ch, cw), want_v)
+    p = buf('p', (B, desc.target), i2o_W is not None)
+    o = buf('o', (B, desc.target), bool(desc.output_layer))
+    scratch = buf('scratch', (2, B, desc.c_out, ch, cw), pooled)
     if K_ro >= 65536 and not desc.output_layer and i2o_W is not None:
         # a few rows of a very long K (large plane): the readout goes through readout() below, which can split K
         # over the chip (dcll_readout_splitk) — inside the step call it would run on rows/4 x N/4 workgroups
@@ -109,16 +119,27 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     return s, p, o, pv, v
 
 
-def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want_out):
-    """Gradients of one layer step (dcll_conv_lif_backward) -> (dW, db, d_outW, d_outb)."""
+def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want_out, out=None):
+    """Gradients of one layer step (dcll_conv_lif_backward) -> (dW, db, d_outW, d_outb).  `out`: optional dict with
+    preallocated 'dW', 'db', 'd_outW', 'd_outb', 'bwd_scratch' (the learning loop writes into the parameters' .grad)."""
     B = eps1.shape[0]
     dev = eps1.device
+    out = {} if out is None else out
     ch, cw, ph, pw = conv_out_shape(desc)
-    dW = torch.empty((desc.c_out, desc.c_in, desc.kh, desc.kw), device=dev, dtype=torch.float32)
-    db = torch.empty((desc.c_out,), device=dev, dtype=torch.float32)
     K = desc.c_out * ph * pw
-    d_outW = torch.empty((desc.target, K), device=dev, dtype=torch.float32) if want_out else None
-    d_outb = torch.empty((desc.target,), device=dev, dtype=torch.float32) if want_out else None
+
+    def buf(key, shape, want=True):
+        if not want:
+            return None
+        t = out.get(key)
+        if t is None:
+            t = out[key] = torch.empty(shape, device=dev, dtype=torch.float32)
+        _expect(t, key, torch.float32, shape)
+        return t
+    dW = buf('dW', (desc.c_out, desc.c_in, desc.kh, desc.kw))
+    db = buf('db', (desc.c_out,))
+    d_outW = buf('d_outW', (desc.target, K), want_out)
+    d_outb = buf('d_outb', (desc.target,), want_out)
     # partial-sum rows for the weight gradient: one per workgroup, up to 256 (a sample of a large plane is many 16x16
     # tile jobs, so small batches still fill the chip); the same area then holds the batch chunks of the output_ gradient
     jobs = B * max(1, (desc.h // 16) * (desc.w // 16))
@@ -128,7 +149,9 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
     if want_out:
         part = max(part, min(B, 8) * desc.target * (K + 1))
     n_scratch = B * desc.c_out * ch * cw + part
-    scratch = torch.empty((n_scratch,), device=dev, dtype=torch.float32)
+    scratch = out.get('bwd_scratch')
+    if scratch is None or scratch.numel() != n_scratch:
+        scratch = out['bwd_scratch'] = torch.empty((n_scratch,), device=dev, dtype=torch.float32)
     c = lambda t: None if t is None else _f32(t, "grad").contiguous()
     rc = _lib.get().dcll_conv_lif_backward(
         ctypes.byref(desc), ptr(eps1), ptr(v), ptr(pv_pooled), ptr(c(g_p)), ptr(c(g_o) if want_out else None),
@@ -364,3 +387,62 @@ def pack_spikes(dense):
     packed = torch.empty(dense.shape[:-1] + (dense.shape[-1] // 32,), device=dense.device, dtype=torch.int32)
     check(_lib.get().dcll_pack_spikes(ptr(dense), ptr(packed), packed.numel(), stream_ptr()), "dcll_pack_spikes")
     return packed
+
+
+LOSS_KINDS = {"SmoothL1Loss": _lib.LOSS_SMOOTH_L1, "MSELoss": _lib.LOSS_MSE}
+
+
+def local_loss_grad(p, o, target, kind, out=None):
+    """Gradient and value of the local losses with mean reduction (dcll_local_loss_grad): crit(p, target) [+
+    crit(o, target)] -> (g_p, g_o or None, loss (1,)).  kind: LOSS_KINDS[...]."""
+    out = {} if out is None else out
+    B, N = p.shape
+    _expect(p, "p", torch.float32)
+    _expect(target, "target", torch.float32, (B, N))
+    _expect(o, "o", torch.float32, (B, N))
+
+    def buf(key, shape, want=True):
+        if not want:
+            return None
+        t = out.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = out[key] = torch.empty(shape, device=p.device, dtype=torch.float32)
+        return t
+    g_p, g_o, loss = buf('g_p', (B, N)), buf('g_o', (B, N), o is not None), buf('loss', (1,))
+    check(_lib.get().dcll_local_loss_grad(ptr(p.contiguous()), ptr(None if o is None else o.contiguous()),
+                                          ptr(target.contiguous()), ptr(g_p), ptr(g_o), ptr(loss), B, N, int(kind),
+                                          stream_ptr()), "dcll_local_loss_grad")
+    return g_p, g_o, loss
+
+
+def adam_step(tensors):
+    """torch.optim.Adam's update over several tensors — of one or several optimizers — in one launch (dcll_adam_step).
+    tensors: list of dicts with param, grad, exp_avg, exp_avg_sq (tensors) and lr, weight_decay, beta1, beta2, eps, step
+    (1-based count of this update).  More than 8 tensors are split into several launches."""
+    lib = _lib.get()
+    for k0 in range(0, len(tensors), _lib.ADAM_MAX_TENSORS):
+        part = tensors[k0:k0 + _lib.ADAM_MAX_TENSORS]
+        arr = (_lib.AdamTensor * len(part))()
+        for a, t in zip(arr, part):
+            prm = t["param"]
+            if not prm.is_cuda or not prm.is_contiguous():
+                raise _lib.DCLLHipError("adam_step: parameters must be contiguous device tensors")
+            for key in ("param", "grad", "exp_avg", "exp_avg_sq"):
+                _expect(t[key], key, torch.float32, numel=prm.numel())
+            a.param, a.grad = prm.data_ptr(), ptr(t["grad"]).value
+            a.exp_avg, a.exp_avg_sq = ptr(t["exp_avg"]).value, ptr(t["exp_avg_sq"]).value
+            a.n, a.step = prm.numel(), int(t["step"])
+            a.lr, a.weight_decay = float(t["lr"]), float(t["weight_decay"])
+            a.beta1, a.beta2, a.eps = float(t["beta1"]), float(t["beta2"]), float(t["eps"])
+        check(lib.dcll_adam_step(arr, len(part), stream_ptr()), "dcll_adam_step")
+
+
+def cells_to_planes(cells, hw):
+    """cells (...) int32 on device -> one-hot planes (..., hw) fp32 (dcll_cells_to_planes): the dense per-step input that
+    iq2spiketrain builds on the host (data/utils.py:81-82)."""
+    _expect(cells, "cells", torch.int32)
+    cells = cells.contiguous()
+    planes = torch.empty(tuple(cells.shape) + (hw,), device=cells.device, dtype=torch.float32)
+    check(_lib.get().dcll_cells_to_planes(ptr(cells), ptr(planes), cells.numel(), int(hw), stream_ptr()),
+          "dcll_cells_to_planes")
+    return planes

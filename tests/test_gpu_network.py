@@ -335,11 +335,15 @@ def test_entry_point_test_radio_ml_synthetic(tmp_path):
         assert np.load(tmp_path / d / 'confusion_matrix_snr_30.npy').sum() == 64
 
 
-def test_local_learning_matches_reference_train_steps(golden):
+@pytest.mark.parametrize("native", [True, False])
+def test_local_learning_matches_reference_train_steps(golden, native, monkeypatch):
     """net.learn (DCLLBase.train_dcll): SmoothL1 local losses, Adam(betas=(0,.95), weight_decay=10) per step after
     burn-in, on the reduced radio net — gradients of every post-burn-in step and the final parameters against the
-    reference's (fixture G6).  Gradients are fp32 sums in a different order: relative tolerance."""
+    reference's (fixture G6).  Gradients are fp32 sums in a different order: relative tolerance.
+    native: the whole step as C-ABI calls (loss gradient, backward, Adam: no torch op per timestep); else the autograd
+    fallback (same HIP forward / backward inside an autograd node, torch's loss modules and optimizers)."""
     from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    monkeypatch.setenv("DCLL_NATIVE_LEARNING", "1" if native else "0")
     g = golden("g6_train_steps.npz")
     convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
     torch.manual_seed(1)
@@ -349,6 +353,7 @@ def test_local_learning_matches_reference_train_steps(golden):
                       loss=torch.nn.SmoothL1Loss, opt=torch.optim.Adam,
                       opt_param={"betas": [0.0, .95], "weight_decay": 10.0}, learning_rates=[1e-6], burnin=3)
     net.reset(True)
+    assert all((s._native_learning() is not None) == native for s in net.dcll_slices)
     for i in range(3):       # same seeds => same initial parameters as the reference run
         for k, v in g.sub("sd0/%d/" % i).items():
             assert np.array_equal(net.state_dict()["dcll_slices.%d.dclllayer.%s" % (i, k)].cpu().numpy(), v), (i, k)
@@ -762,3 +767,90 @@ def test_overlapped_readout_equals_serial_path(R_, T, B, chunked):
                                getattr(nets[1].dcll_slices[i].dclllayer.i2h.state, name)), (i, name)
         assert len(nets[1].dcll_slices[i].activity_hist) == T // 20
     np.testing.assert_allclose(b["o"].cpu().numpy(), a["o"].cpu().numpy(), atol=2e-5, rtol=0)
+
+
+def test_learn_sequence_equals_per_step_learning_on_host_encoded_planes():
+    """ConvNetwork.learn_sequence (device-side cells, burn-in on the fused sequence kernels, learning steps on planes
+    built on the device — what train.py runs) == the reference's loop `for t: net.learn(x[t], labels[t])` on
+    iq2spiketrain-style dense planes: same weights bit for bit, same clout, iteration count and pv statistics; the
+    optimizer objects hold torch-format Adam state."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    B, R_, T, burnin = 8, 16, 27, 23
+
+    def make():
+        torch.manual_seed(1)
+        np.random.seed(1)
+        net = ConvNetwork(_args(), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                          opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0},
+                          learning_rates=[1e-7], burnin=burnin)
+        net.reset(True)
+        return net
+    rng = np.random.RandomState(3)
+    cells = rng.randint(0, R_ * R_, size=(T, B)).astype(np.int32)
+    lab = rng.randint(0, 24, size=B)
+    y = torch.zeros(B, 24)
+    y[np.arange(B), lab] = 1
+    y = y.cuda()
+    a, b = make(), make()
+    a.reset(); a.train()
+    a.learn_sequence(torch.from_numpy(cells).cuda(), y)
+    b.reset(); b.train()
+    x = np.zeros((T, B, R_ * R_), np.float32)
+    x[np.arange(T)[:, None], np.arange(B)[None, :], cells] = 1
+    x = torch.from_numpy(x.reshape(T, B, 1, R_, R_)).cuda()
+    for t in range(T):
+        b.learn(x[t], y)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert not torch.equal(sa["dcll_slices.1.dclllayer.i2h.weight"], make().state_dict()["dcll_slices.1.dclllayer.i2h.weight"])
+    for sl_a, sl_b in zip(a.dcll_slices, b.dcll_slices):
+        assert sl_a.iter == sl_b.iter == T
+        assert np.array_equal(np.asarray(sl_a.clout), np.asarray(sl_b.clout)) and len(sl_a.clout) == T - burnin + 1
+        assert np.array_equal(sl_a._activity_rows(), sl_b._activity_rows()) and len(sl_a.activity_hist) == 1
+        st = sl_a.optimizer.state[sl_a.dclllayer.i2h.weight]
+        assert float(st["step"]) == T - burnin + 1 and st["exp_avg"].shape == sl_a.dclllayer.i2h.weight.shape
+        torch.optim.Adam(sl_a.dclllayer.i2h.parameters()).load_state_dict(sl_a.optimizer.state_dict())
+    y3 = y.unsqueeze(0).expand(T, -1, -1)
+    assert a.accuracy(y3) == b.accuracy(y3)
+
+
+def test_native_learning_pieces_vs_torch():
+    """dcll_local_loss_grad == autograd of torch's SmoothL1Loss / MSELoss (mean), dcll_adam_step == torch.optim.Adam over
+    several steps with per-tensor hyper-parameters (the slices' optimizer and optimizer2), dcll_cells_to_planes == one-hot."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(0)
+    Bn, N = 37, 24
+    for name, crit in (("SmoothL1Loss", torch.nn.SmoothL1Loss()), ("MSELoss", torch.nn.MSELoss())):
+        p = torch.tensor(rng.uniform(-2.5, 2.5, size=(Bn, N)).astype(np.float32), requires_grad=True)
+        o = torch.tensor(rng.uniform(-2.5, 2.5, size=(Bn, N)).astype(np.float32), requires_grad=True)
+        tgt = torch.tensor((rng.uniform(size=(Bn, N)) < 0.1).astype(np.float32))
+        loss = crit(p, tgt) + crit(o, tgt)
+        loss.backward()
+        g_p, g_o, l = ops.local_loss_grad(p.detach().cuda(), o.detach().cuda(), tgt.cuda(), ops.LOSS_KINDS[name])
+        np.testing.assert_allclose(g_p.cpu().numpy(), p.grad.numpy(), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(g_o.cpu().numpy(), o.grad.numpy(), rtol=1e-6, atol=1e-9)
+        assert abs(float(l) - float(loss)) <= 1e-6 * abs(float(loss))
+        g_p1, g_o1, l1 = ops.local_loss_grad(p.detach().cuda(), None, tgt.cuda(), ops.LOSS_KINDS[name])
+        assert g_o1 is None and abs(float(l1) - float(crit(p, tgt))) <= 1e-6
+    shapes = [(32, 32, 7, 7), (32,), (24, 8192), (24,)]
+    hp = [dict(lr=1e-6, betas=(0.0, .95), weight_decay=10.0, eps=1e-8)] * 2 + [dict(lr=1e-4, betas=(.9, .999), weight_decay=0.0, eps=1e-8)] * 2
+    prm_t = [torch.nn.Parameter(torch.tensor(rng.uniform(-1e-5, 1e-5, size=s).astype(np.float32))) for s in shapes]
+    prm_m = [q.detach().clone().cuda() for q in prm_t]
+    opts = [torch.optim.Adam([q], **h) for q, h in zip(prm_t, hp)]
+    m = [torch.zeros_like(q) for q in prm_m]
+    v = [torch.zeros_like(q) for q in prm_m]
+    for step in range(1, 6):
+        grads = [torch.tensor(rng.uniform(-1e-3, 1e-3, size=s).astype(np.float32)) for s in shapes]
+        for q, g_, o_ in zip(prm_t, grads, opts):
+            q.grad = g_.clone()
+            o_.step()
+        ops.adam_step([dict(param=q, grad=g_.cuda(), exp_avg=mm, exp_avg_sq=vv, lr=h["lr"], weight_decay=h["weight_decay"],
+                            beta1=h["betas"][0], beta2=h["betas"][1], eps=h["eps"], step=step)
+                       for q, g_, mm, vv, h in zip(prm_m, grads, m, v, hp)])
+        for q, r in zip(prm_m, prm_t):
+            np.testing.assert_allclose(q.cpu().numpy(), r.detach().numpy(), rtol=2e-5, atol=1e-11)
+    cells = torch.tensor(rng.randint(0, 256, size=(5, 7)).astype(np.int32)).cuda()
+    planes = ops.cells_to_planes(cells, 256)
+    assert planes.shape == (5, 7, 256) and torch.equal(planes, torch.nn.functional.one_hot(cells.long(), 256).float())

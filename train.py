@@ -18,6 +18,7 @@ import sys
 import numpy as np
 import torch
 
+from snn_modulation_classification_amd import parallel
 from snn_modulation_classification_amd.data.utils import to_one_hot
 from snn_modulation_classification_amd.dcll import pytorch_libdcll
 from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
@@ -70,11 +71,25 @@ def parse_args(argv=None):
     # additions of this build
     p.add_argument('--synthetic', type=int, default=0, metavar='N', help='use N synthetic test windows')
     p.add_argument('--eval_only', action='store_true', help='run the periodic evaluation once and save parameters')
+    p.add_argument('--host_encoding', action='store_true',
+                   help='encode the training batches with the host iq2spiketrain loop (the reference\'s way) instead of on '
+                        'the device')
+    p.add_argument('--gpus', type=int, default=1, metavar='N',
+                   help='ranks (one process per GPU): every batch is sharded over them, the local-learning gradients are '
+                        'averaged over the ranks every timestep (one bucketed all-reduce)')
     return p.parse_args(argv)
 
 
 def main(argv=None):
     args = parse_args(argv)
+    if args.gpus > 1 and not parallel.under_launcher():
+        # plain start: become the launcher of one fresh process per rank (never touches the GPU itself)
+        return sys.exit(parallel.spawn_local_ranks(args.gpus, argv=[os.path.abspath(__file__)] +
+                                                   (sys.argv[1:] if argv is None else list(argv))))
+    rank, local_rank, world = parallel.init_process_group()
+    if world > 1 and torch.cuda.is_available():
+        pytorch_libdcll.device = 'cuda:%d' % parallel.local_device(local_rank)
+        torch.cuda.set_device(parallel.local_device(local_rank))
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     if args.data == 'MNIST':
@@ -83,8 +98,15 @@ def main(argv=None):
         sys.exit('ReferenceConvNetwork (plain CNN baseline) is outside the DCLL hot path and not part of this build.')
     stamp = datetime.datetime.now().strftime('%b%d_%H-%M-%S')
     out_dir = os.path.join(args.output, args.data, stamp)
-    os.makedirs(out_dir)
-    print('out dir: {}'.format(out_dir))
+    if world > 1:                                  # one results directory for the job: rank 0 names it
+        names = [out_dir]
+        torch.distributed.broadcast_object_list(names, src=0)
+        out_dir = names[0]
+    os.makedirs(out_dir, exist_ok=world > 1)
+    if rank == 0:
+        print('out dir: {}'.format(out_dir))
+    if rank != 0:
+        args.no_save = True                        # every rank trains its shard; rank 0 alone writes files
 
     im_dims = (1, args.Q_resolution, args.I_resolution)
     target_size = evaluation.TARGET_SIZE
@@ -92,7 +114,10 @@ def main(argv=None):
     opt_param = {'betas': [0.0, args.beta], 'weight_decay': 10.0}
     loss = getattr(torch.nn, args.loss_type)
     convs = load_network_spec(args.network_spec)
-    net = ConvNetwork(args, im_dims, args.batch_size_test if args.eval_only else args.batch_size, convs, target_size,
+    # sized for this rank's shard of a batch (identical initial weights / time constants on every rank: their RNG draws
+    # do not depend on the batch size)
+    lo, hi = parallel.shard_range(args.batch_size_test if args.eval_only else args.batch_size, rank, world)
+    net = ConvNetwork(args, im_dims, max(hi - lo, 1), convs, target_size,
                       act=torch.nn.Sigmoid(), loss=loss, opt=opt, opt_param=opt_param,
                       learning_rates=args.learning_rates, burnin=args.burnin)
     if args.restore_path:
@@ -131,17 +156,21 @@ def main(argv=None):
         test_batches = [next(gen_test) for _ in range(n_test)]
         n_test = len(test_batches)
     use_sequence = net.sequence_supported()
+    device_encoding = not args.host_encoding
     encoder = IQEncoder(args.I_resolution, args.Q_resolution, args.I_bounds, args.Q_bounds,
-                        device=pytorch_libdcll.device) if use_sequence else None
+                        device=pytorch_libdcll.device) if (use_sequence or device_encoding) else None
+    import time
+    t_train, n_train = 0.0, 0
 
     def run_tests(step):
-        net.batch_size = args.batch_size_test
+        net.batch_size = max(1, np.diff(parallel.shard_range(args.batch_size_test, rank, world))[0])
         acc = np.empty([len(test_batches), len(net.dcll_slices)])
         for i, (samples, labels) in enumerate(test_batches):
             acc[i, :], _ = evaluation.evaluate_batch(net, args, samples, to_one_hot(labels, target_size), encoder,
                                                      use_sequence)
-        net.batch_size = args.batch_size
-        print('[TEST]  Step {} \t Accuracy {} \t Ref {}'.format(str(step).zfill(5), np.mean(acc, axis=0), 'N/A'))
+        net.batch_size = max(1, np.diff(parallel.shard_range(args.batch_size, rank, world))[0])
+        if rank == 0:
+            print('[TEST]  Step {} \t Accuracy {} \t Ref {}'.format(str(step).zfill(5), np.mean(acc, axis=0), 'N/A'))
         return acc
 
     if args.eval_only:
@@ -170,14 +199,33 @@ def main(argv=None):
                 if samples.shape[0] != args.batch_size:       # ragged last batch: the state is sized for batch_size
                     gen_train = iter(train_data)
                     samples, labels = next(gen_train)
-            spikes, targets = iq2spiketrain(samples, to_one_hot(labels, target_size), **st_kw)
-            input_spikes = torch.Tensor(spikes).to(pytorch_libdcll.device)
-            labels_spikes = torch.as_tensor(np.asarray(targets), dtype=torch.float32).to(pytorch_libdcll.device)
+            if world > 1:                                     # my contiguous shard of the batch
+                a, b = parallel.shard_range(samples.shape[0], rank, world)
+                samples, labels = samples[a:b], labels[a:b]
+            t_step = time.perf_counter()
+            labels1h = to_one_hot(labels, target_size)
             net.reset()
             net.train()
-            for t in range(args.n_iters):
-                net.learn(x=input_spikes[t], labels=labels_spikes[t])
-            print('[TRAIN] Step {} \t Accuracy {}'.format(str(step).zfill(5), net.accuracy(labels_spikes)))
+            if device_encoding:
+                # raw IQ to the GPU, iq2spiketrain's quantisation as a kernel (same random crop draw), burn-in steps on
+                # the fused sequence kernels, learning steps on device-built planes
+                dev = pytorch_libdcll.device
+                cells = encoder(samples.to(dev), args.n_iters)
+                y = torch.as_tensor(np.asarray(labels1h), dtype=torch.float32).to(dev)
+                net.learn_sequence(cells, y)
+                labels_spikes = y.unsqueeze(0).expand(args.n_iters, -1, -1)
+            else:
+                spikes, targets = iq2spiketrain(samples, labels1h, **st_kw)
+                input_spikes = torch.Tensor(spikes).to(pytorch_libdcll.device)
+                labels_spikes = torch.as_tensor(np.asarray(targets), dtype=torch.float32).to(pytorch_libdcll.device)
+                for t in range(args.n_iters):
+                    net.learn(x=input_spikes[t], labels=labels_spikes[t])
+            acc_train = net.accuracy(labels_spikes)           # (reads the per-step argmax back: ends the step's GPU work)
+            t_train += time.perf_counter() - t_step
+            n_train += samples.shape[0] * world
+            if rank == 0:
+                print('[TRAIN] Step {} \t Accuracy {} \t {:.0f} windows/s incl. encoding'.format(
+                    str(step).zfill(5), acc_train, n_train / t_train))
             if (step % args.n_test_interval) == 0:
                 acc_test[step // args.n_test_interval] = run_tests(step)
                 if not args.no_save:
@@ -188,6 +236,9 @@ def main(argv=None):
                     print('-' * 80)
                     print('Saved network parameters to `%s`.' % save_path)
                     print('-' * 80)
+        if world > 1:
+            parallel.barrier()
+            torch.distributed.destroy_process_group()
         return out_dir
 
     # --eval_only: the periodic evaluation block of the reference (train.py:263-303) once, then save
