@@ -483,6 +483,54 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
     if ((lane & 15) == 0) pw[(long)(4 * w + (lane >> 4)) * 1569 + 1568] = bsum;
 }
 
+// Weight gradient of the FIRST layer (c_in = 1 -> 32 channels, 7x7, 16x16 plane) as fp32 MFMA, the one-channel sibling
+// of k_bwd_wgrad_c32: dW[co][tap] = sum_{b,pix} g[b,co,pix] * E[b][pix + tap] — 49 columns = two 32-column tiles, one per
+// wave of a 128-thread workgroup; per sample g (32 x 256, row stride 257) and the zero-padded plane (row stride ROWF) are
+// staged in LDS.  Partial sums go to part[workgroup][co][49 + 1] (k_bwd_reduce adds them in order).  (The generic
+// k_bwd_wgrad needs 78 us for this layer at B = 512: 0.4 GFLOP spread over 2048 workgroups with a 49-value tree each.)
+constexpr int WG1_IMG = 432;        // >= (15 + 6) * ROWF + 15 + 6 + 1 + 1
+__global__ __launch_bounds__(128) void k_bwd_wgrad_c1(const float *__restrict__ gvf, const float *__restrict__ eps1,
+                                                       float *__restrict__ part, int B)
+{
+    __shared__ __attribute__((aligned(16))) float lds[WG1_IMG + 32 * WG32_GLD];
+    float *img = lds, *gl = lds + WG1_IMG;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < WG1_IMG; i += 128) img[i] = 0.0f;
+    const int n = w * 32 + j;                                   // my column = tap index (valid below 49)
+    const int tap = n < 49 ? n : 0;
+    const int bbase = (tap / 7) * ROWF + (tap % 7) + h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float bsum = 0.0f;                                          // wave w: co = 16 w + lane / 4, pixels lane % 4 + 4 k
+    for (long b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < 32 * 256; i += 128) gl[(i >> 8) * WG32_GLD + (i & 255)] = gvf[b * 8192 + i];
+        for (int p = tid; p < 256; p += 128) img[((p >> 4) + 3) * ROWF + (p & 15) + 3] = eps1[b * 256 + p];
+        __syncthreads();
+        {
+            const float *gr = gl + (16 * w + (lane >> 2)) * WG32_GLD + (lane & 3);
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) bsum += gr[4 * k];
+        }
+        const float *ga = gl + j * WG32_GLD + h;                // A: co = j, pixel p + h
+#pragma unroll 8
+        for (int pp = 0; pp < 128; ++pp) {
+            const int p = 2 * pp;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[p], img[bbase + (p >> 4) * ROWF + (p & 15)], acc, 0, 0, 0);
+        }
+    }
+    float *pw = part + (long)blockIdx.x * 32 * 50;
+    if (n < 49) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * 50 + n] = acc[r];
+    }
+    bsum += __shfl_xor(bsum, 1);
+    bsum += __shfl_xor(bsum, 2);
+    if ((lane & 3) == 0) pw[(long)(16 * w + (lane >> 2)) * 50 + 49] = bsum;
+}
+
 // dW / db = fixed-order sum of the partial rows part[chunk][co][rowlen] (rowlen = c_in*ntap + 1, last = bias gradient)
 // k_bwd_dv for layers without pooling: thread = one position k = (co, y, x) of the map, the (<= 32) readout weights of
 // that position in registers, a chunk of samples looped over (g_p is wave-uniform -> scalar loads): i2o_W is read once
@@ -1704,7 +1752,7 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
     //  the co-resident mode)
     if (direct_ok && mode == DCLL_READOUT_CORESIDENT)
         return dcll_launch_readout_direct(pv, Wt, bias, out, rows, K, N, st);
-    if (fast && mode == DCLL_READOUT_T16) return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, st);     // any row count
+    if (fast && mode == DCLL_READOUT_T16) return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, 0, st);     // any row count
     if (rows <= 2048) {
         hipLaunchKernelGGL(k_readout_rows, dim3((unsigned)((rows + RS_RB - 1) / RS_RB), (N + RS_NG - 1) / RS_NG), dim3(256),
                            0, st, pv, Wt, bias, out, rows, K, N);
@@ -1719,7 +1767,7 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
     } else if (fast && mode != DCLL_READOUT_LDS) {
         // 16x16x4 tiles: 24 rows = 2 tiles, 48 stacked rows = 3 tiles without padding (2.9 / 3.9 ms at B = 4096 vs 3.5 / 5.3 ms
         // for the 32-column tiles of k_readout_v4 below, which stay for DCLL_READOUT_LDS)
-        return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, st);
+        return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, 0, st);
     } else if (fast && N <= 32) {
         hipLaunchKernelGGL(k_readout_v4<1>, dim3(nblk(rows, RO_ROWS)), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
     } else if (fast) {
@@ -1749,20 +1797,42 @@ extern "C" int dcll_readout_mode(const float *pv, const float *Wt, const float *
     return launch_readout(pv, Wt, bias, out, rows, K, N, (hipStream_t)stream, mode);
 }
 
-__global__ void k_readout_sum(const float *__restrict__ part, const float *__restrict__ bias, float *__restrict__ out,
-                              long n_out, int N, int nslice)
+// out[i] = bias + the slices' partial values added in slice order.  Four threads per output (each its quarter of the
+// slices, the four sub-sums combined in fixed order through LDS): a quarter of the dependent-load latency.
+__global__ __launch_bounds__(256) void k_readout_sum(const float *__restrict__ part, const float *__restrict__ bias,
+                                                      float *__restrict__ out, long n_out, int N, int nslice)
 {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
-    float tot = bias ? bias[i % N] : 0.0f;
-    for (int sl = 0; sl < nslice; ++sl) tot += part[(long)sl * n_out + i];
-    out[i] = tot;
+    __shared__ float red[4][64];
+    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    float acc = 0.0f;
+    if (i < n_out) {
+        const int per = (nslice + 3) / 4, s0 = grp * per, s1 = min(nslice, s0 + per);
+        for (int sl = s0; sl < s1; ++sl) acc += part[(long)sl * n_out + i];
+    }
+    red[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && i < n_out) {
+        const int l = threadIdx.x & 63;
+        out[i] = (bias ? bias[i % N] : 0.0f) + (((red[0][l] + red[1][l]) + red[2][l]) + red[3][l]);
+    }
+}
+
+// K slice of a split-K readout: 4096 for very long rows (large planes: k_readout_ks), 256 for the per-step calls on the
+// 16x16 plane (rows = batch <= 2048, K = 8192: 32 slices x rows/128 workgroups of k_readout_t16 instead of rows/4 x N/4
+// workgroups of k_readout_rows that re-read every pv row N/4 times); 0 = shape not supported
+static int splitk_slice(int64_t rows, int32_t K, int32_t N)
+{
+    if (rows < 1 || N < 1 || N > 64) return 0;
+    if (K >= 65536 && K % 4096 == 0) return 4096;
+    if (rows <= 2048 && K >= 2048 && K < 65536 && K % 256 == 0) return 256;
+    return 0;
 }
 
 extern "C" int64_t dcll_readout_splitk_scratch(int64_t rows, int32_t K, int32_t N)
 {
-    if (rows < 1 || N < 1 || N > 64 || K < 65536 || K % 4096 != 0) return 0;
-    return (int64_t)(K / 4096) * rows * N;
+    const int ks = splitk_slice(rows, K, N);
+    return ks ? (int64_t)(K / ks) * rows * N : 0;
 }
 
 extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float *bias, float *out, float *scratch,
@@ -1771,17 +1841,24 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
     if (rows == 0 || N == 0) return DCLL_OK;
     if (!pv || !Wt || !out || !scratch || rows < 0 || K < 1 || N < 1)
         return fail(DCLL_ERR_INVALID, "dcll_readout_splitk: bad argument");
-    const int64_t need = dcll_readout_splitk_scratch(rows, K, N);
-    if (need == 0 || ((((uintptr_t)pv | (uintptr_t)Wt)) & 15) != 0)
-        return fail(DCLL_ERR_UNSUPPORTED, "dcll_readout_splitk: needs K >= 65536, K % 4096 == 0, N <= 64, 16-byte aligned operands");
-    if (scratch_floats < need) return fail(DCLL_ERR_INVALID, "dcll_readout_splitk: scratch too small (dcll_readout_splitk_scratch)");
+    const int ks = splitk_slice(rows, K, N);
+    if (ks == 0 || ((((uintptr_t)pv | (uintptr_t)Wt)) & 15) != 0)
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_readout_splitk: needs N <= 64, 16-byte aligned operands and K >= 65536 with "
+                                          "K % 4096 == 0, or rows <= 2048 with 2048 <= K < 65536, K % 256 == 0");
+    if (scratch_floats < dcll_readout_splitk_scratch(rows, K, N))
+        return fail(DCLL_ERR_INVALID, "dcll_readout_splitk: scratch too small (dcll_readout_splitk_scratch)");
     hipStream_t st = (hipStream_t)stream;
-    const int nslice = K / 4096;
-    dim3 grid(nblk(rows, RK_ROWS), nslice);
-    if (N <= 32) hipLaunchKernelGGL(k_readout_ks<1>, grid, dim3(256), 0, st, pv, Wt, bias, scratch, rows, K, N, 4096);
-    else hipLaunchKernelGGL(k_readout_ks<2>, grid, dim3(256), 0, st, pv, Wt, bias, scratch, rows, K, N, 4096);
-    HIP_CHECK_LAUNCH("k_readout_ks (split K)");
-    hipLaunchKernelGGL(k_readout_sum, dim3(nblk(rows * N, 256)), dim3(256), 0, st, scratch, bias, out, rows * N, N, nslice);
+    const int nslice = K / ks;
+    if (ks == 256) {
+        int rc = dcll_launch_readout_t16(pv, Wt, nullptr, scratch, rows, K, N, ks, st);
+        if (rc) return rc;
+    } else {
+        dim3 grid(nblk(rows, RK_ROWS), nslice);
+        if (N <= 32) hipLaunchKernelGGL(k_readout_ks<1>, grid, dim3(256), 0, st, pv, Wt, bias, scratch, rows, K, N, 4096);
+        else hipLaunchKernelGGL(k_readout_ks<2>, grid, dim3(256), 0, st, pv, Wt, bias, scratch, rows, K, N, 4096);
+        HIP_CHECK_LAUNCH("k_readout_ks (split K)");
+    }
+    hipLaunchKernelGGL(k_readout_sum, dim3(nblk(rows * N, 64)), dim3(256), 0, st, scratch, bias, out, rows * N, N, nslice);
     HIP_CHECK_LAUNCH("k_readout_sum");
     return DCLL_OK;
 }
@@ -2064,6 +2141,57 @@ __global__ void k_bwd_outgrad_reduce(const float *__restrict__ part, float *__re
     else db[n] = tot;
 }
 
+// The output_ gradient as fp32 MFMA for N <= 32 readout rows and K % 32 == 0: d_outW[n][k] = sum_b g_o[b][n] * pv[b][k] is
+// a (N x B) . (B x K) GEMM; a workgroup takes 32 columns of K, its four waves a quarter of the batch each (the MFMA's two k
+// lanes = two consecutive samples; the B operand is a coalesced 128-byte piece of a pv row), the four partial tiles are
+// added in wave order through LDS.  pv is read once, nothing is written but the result (the partial-sum version above
+// moves 12 MB of partials per call: 46 + 6 us at B = 512 against ~8 us).  Workgroup 0 also sums the bias gradient.
+__global__ __launch_bounds__(256) void k_bwd_outgrad_mfma(const float *__restrict__ g_o, const float *__restrict__ pvp,
+                                                           float *__restrict__ dW, float *__restrict__ db, int B, int N,
+                                                           int K)
+{
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k0 = blockIdx.x * 32;
+    const int per = (((B + 3) / 4) + 1) & ~1;                   // samples per wave, even
+    const int b0 = w * per, b1 = min(B, b0 + per);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int b = b0; b < b1; b += 2) {
+        const int bb = b + h;
+        const bool ok = bb < b1;
+        const float a = (ok && j < N) ? g_o[(long)bb * N + j] : 0.0f;
+        const float bv = ok ? pvp[(long)bb * K + k0 + j] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][r][lane] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += 256) {
+        const int l = e & 63, r = e >> 6;
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (n < N) dW[(long)n * K + k0 + (l & 31)] = ((red[0][r][l] + red[1][r][l]) + red[2][r][l]) + red[3][r][l];
+    }
+    if (blockIdx.x == 0) {                                      // d_outb[n] = sum_b g_o[b][n]: 8 strided parts per row
+        __syncthreads();
+        float *rb = &red[0][0][0];
+        const int n = tid & 31, part = tid >> 5;
+        float sum = 0.0f;
+        if (n < N)
+            for (int b = part; b < B; b += 8) sum += g_o[(long)b * N + n];
+        rb[part * 32 + n] = sum;
+        __syncthreads();
+        if (tid < N) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tot += rb[q * 32 + tid];
+            db[tid] = tot;
+        }
+    }
+}
+
 extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
                                       const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
                                       const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
@@ -2102,6 +2230,12 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
         hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false>), dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1,
                            part, B, 16, 16);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c32");
+    } else if (d->c_in == 1 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->h == 16 &&
+               d->w == 16) {                                   // first layer of radio_ml_conv.yaml: MFMA, two column tiles
+        if (nchunk > 512) nchunk = 512;
+        if (nchunk > B) nchunk = B;
+        hipLaunchKernelGGL(k_bwd_wgrad_c1, dim3((unsigned)nchunk), dim3(128), 0, st, scratch, eps1, part, B);
+        HIP_CHECK_LAUNCH("k_bwd_wgrad_c1");
     } else if (c32 && d->h % 16 == 0 && d->w % 16 == 0) {     // large planes: one 16x16 tile of a sample per job
         const long njob = (long)B * (d->h / 16) * (d->w / 16);
         if (nchunk > 256) nchunk = 256;
@@ -2133,7 +2267,10 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
         long nsplit = (scratch_floats - nconv) / ((long)N * (K + 1));
         if (nsplit > 16) nsplit = 16;
         if (nsplit > B) nsplit = B;
-        if (N <= 32 && nsplit >= 1) {
+        if (N <= 32 && K % 32 == 0) {
+            hipLaunchKernelGGL(k_bwd_outgrad_mfma, dim3(K / 32), dim3(256), 0, st, g_o, pv_pooled, d_outW, d_outb, B, N, K);
+            HIP_CHECK_LAUNCH("k_bwd_outgrad_mfma");
+        } else if (N <= 32 && nsplit >= 1) {
             hipLaunchKernelGGL(k_bwd_outgrad_part, dim3(nblk((long)K + N, 256), (unsigned)nsplit), dim3(256), 0, st, g_o,
                                pv_pooled, part, B, N, K);
             HIP_CHECK_LAUNCH("k_bwd_outgrad_part");

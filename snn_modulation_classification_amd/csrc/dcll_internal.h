@@ -61,7 +61,7 @@ int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bi
 // k_readout_t16 (dcll_readout.hip): LDS-staged 16x16x4 readout GEMM, 128 rows x 16 NT readout rows per workgroup
 __attribute__((visibility("hidden")))
 int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
-                            hipStream_t st);
+                            int kslice, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------------------
 // shared device helpers

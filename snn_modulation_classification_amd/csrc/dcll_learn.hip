@@ -9,40 +9,55 @@
 //                      per-step input of the first layer without the host loop and the (T,B,1,H,W) upload.
 #include "dcll_internal.h"
 
-// one workgroup: the B*N gradient elements and the loss value (sum in a fixed order: per-thread strided partial sums,
-// DPP tree per wave, the four wave totals added in wave order)
+// local loss of one logit (value l, derivative g with respect to the logit)
+__device__ __forceinline__ void loss_elem(float d, int kind, float &l, float &g)
+{
+    if (kind == DCLL_LOSS_MSE) {
+        l = d * d;
+        g = 2.0f * d;
+    } else {                                // SmoothL1Loss, beta = 1
+        const float a = fabsf(d);
+        l = a < 1.0f ? 0.5f * d * d : a - 0.5f;
+        g = a < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f);
+    }
+}
+
+// gradients: one thread per logit over the whole grid.  The loss VALUE (only wanted by callers that look at it — the
+// network's learning loop discards it) is summed by workgroup 0 alone in a fixed order: per-thread strided partial sums,
+// DPP tree per wave, the four wave totals added in wave order.
 __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ p, const float *__restrict__ o,
                                                     const float *__restrict__ target, float *__restrict__ g_p,
                                                     float *__restrict__ g_o, float *__restrict__ loss, int n, int kind)
 {
     __shared__ float red[4];
     const float inv = 1.0f / (float)n;
-    float acc = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
         const float t = target[i];
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const float *src = which ? o : p;
-            float *dst = which ? g_o : g_p;
-            if (!src) continue;
-            const float d = src[i] - t;
-            float l, g;
-            if (kind == DCLL_LOSS_MSE) {
-                l = d * d;
-                g = 2.0f * d;
-            } else {                                // SmoothL1Loss, beta = 1
-                const float a = fabsf(d);
-                l = a < 1.0f ? 0.5f * d * d : a - 0.5f;
-                g = a < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f);
-            }
+        float l, g;
+        loss_elem(p[i] - t, kind, l, g);
+        g_p[i] = g * inv;
+        if (o) {
+            loss_elem(o[i] - t, kind, l, g);
+            g_o[i] = g * inv;
+        }
+    }
+    if (!loss || blockIdx.x != 0) return;
+    float acc = 0.0f;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float t = target[k];
+        float l, g;
+        loss_elem(p[k] - t, kind, l, g);
+        acc += l;
+        if (o) {
+            loss_elem(o[k] - t, kind, l, g);
             acc += l;
-            if (dst) dst[i] = g * inv;
         }
     }
     acc = wave_sum_to_lane63(acc);
     if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0 && loss) *loss = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
+    if (threadIdx.x == 0) *loss = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
 }
 
 extern "C" int dcll_local_loss_grad(const float *p, const float *o, const float *target, float *g_p, float *g_o,
@@ -54,7 +69,8 @@ extern "C" int dcll_local_loss_grad(const float *p, const float *o, const float 
     if (kind != DCLL_LOSS_SMOOTH_L1 && kind != DCLL_LOSS_MSE)
         return fail(DCLL_ERR_UNSUPPORTED, "dcll_local_loss_grad: SmoothL1Loss (beta 1) and MSELoss, mean reduction");
     if ((long)B * N > (1L << 24)) return fail(DCLL_ERR_UNSUPPORTED, "dcll_local_loss_grad: more than 2^24 logits");
-    hipLaunchKernelGGL(k_loss_grad, dim3(1), dim3(256), 0, (hipStream_t)stream, p, o, target, g_p, g_o, loss, B * N, kind);
+    hipLaunchKernelGGL(k_loss_grad, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, o, target, g_p, g_o,
+                       loss, B * N, kind);
     HIP_CHECK_LAUNCH("k_loss_grad");
     return DCLL_OK;
 }

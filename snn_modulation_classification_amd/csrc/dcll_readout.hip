@@ -134,10 +134,12 @@ int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bi
 // ------------------------------------------------------------------------------------------------------------
 constexpr int T16_ROWS = 128, T16_KC = 32, T16_LD = 36;
 
+// kslice > 0 (few rows: per-step calls, rows = batch): workgroup (x, y) handles only columns [y * kslice, (y+1) * kslice)
+// of K and writes its partial tile, without the bias, to out + y * rows * N; k_readout_sum adds the slices in order.
 template <int NT>
 __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ pv, const float *__restrict__ Wt,
                                                       const float *__restrict__ bias, float *__restrict__ out,
-                                                      long rows, int K, int N)
+                                                      long rows, int K, int N, int kslice)
 {
     __shared__ __attribute__((aligned(16))) float sA[T16_ROWS * T16_LD];
     __shared__ __attribute__((aligned(16))) float sB[NT * 16 * T16_LD];
@@ -165,15 +167,17 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
             rb[q] = (nn < N && nn < NT * 16) ? *(const f32x4 *)(Wt + (long)nn * K + k0 + kc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += T16_KC) {
+    const int kbeg = kslice > 0 ? blockIdx.y * kslice : 0, kend = kslice > 0 ? kbeg + kslice : K;
+    if (kslice > 0) { out += (long)blockIdx.y * rows * N; bias = nullptr; }
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += T16_KC) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(f32x4 *)(sA + (rsub + 32 * q) * T16_LD + kc) = ra[q];
 #pragma unroll
         for (int q = 0; q < NBF; ++q)
             if (rsub + 32 * q < NT * 16) *(f32x4 *)(sB + (rsub + 32 * q) * T16_LD + kc) = rb[q];
         __syncthreads();
-        if (k0 + T16_KC < K) fetch(k0 + T16_KC);
+        if (k0 + T16_KC < kend) fetch(k0 + T16_KC);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             f32x4 a[2], b[NT];
@@ -208,15 +212,16 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
     }
 }
 
-// Requires K % 32 == 0, N <= 64, 16-byte aligned pv / Wt rows (the caller checked).
+// Requires K % 32 == 0, N <= 64, 16-byte aligned pv / Wt rows (the caller checked).  kslice > 0: split-K launch (K %
+// kslice == 0, kslice % 32 == 0), `out` = the partial tiles (K / kslice) x rows x N.
 int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
-                            hipStream_t st)
+                            int kslice, hipStream_t st)
 {
-    const unsigned g = (unsigned)((rows + T16_ROWS - 1) / T16_ROWS);
-    if (N <= 16) hipLaunchKernelGGL(k_readout_t16<1>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-    else if (N <= 32) hipLaunchKernelGGL(k_readout_t16<2>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-    else if (N <= 48) hipLaunchKernelGGL(k_readout_t16<3>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
-    else hipLaunchKernelGGL(k_readout_t16<4>, dim3(g), dim3(256), 0, st, pv, Wt, bias, out, rows, K, N);
+    const dim3 g((unsigned)((rows + T16_ROWS - 1) / T16_ROWS), kslice > 0 ? K / kslice : 1);
+    if (N <= 16) hipLaunchKernelGGL(k_readout_t16<1>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
+    else if (N <= 32) hipLaunchKernelGGL(k_readout_t16<2>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
+    else if (N <= 48) hipLaunchKernelGGL(k_readout_t16<3>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
+    else hipLaunchKernelGGL(k_readout_t16<4>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
     HIP_CHECK_LAUNCH("k_readout_t16");
     return DCLL_OK;
 }

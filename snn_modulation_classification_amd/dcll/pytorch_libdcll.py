@@ -732,7 +732,7 @@ class DCLLBase(nn.Module):
         self._native_kind = kind
         return kind
 
-    def _learn_forward_backward(self, input, target):
+    def _learn_forward_backward(self, input, target, want_loss=True):
         """Forward of one step plus — once iter >= burnin (reference :691) — the gradients of the local loss(es) in the
         .grad of i2h.weight / i2h.bias (and output_.weight / output_.bias): dcll_conv_lif_step -> dcll_local_loss_grad
         -> dcll_conv_lif_backward, all on preallocated buffers.  No optimizer step.
@@ -751,7 +751,7 @@ class DCLLBase(nn.Module):
                 if isinstance(self, DCLLClassification):
                     self._clout.append(ops.argmax_vote((o if L.output_layer else p).unsqueeze(0), want_vote=False)[0][0])
                 g_p, g_o, loss = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(),
-                                                     out=bufs)
+                                                     out=bufs, want_loss=want_loss)
                 prm = [i2h.weight, i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
                 for q in prm:
                     if q.grad is None:

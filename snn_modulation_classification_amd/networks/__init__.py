@@ -78,7 +78,7 @@ class ConvNetwork(torch.nn.Module):
             return
         spikes, learned = x, []
         for s in self.dcll_slices:
-            spikes, _, _, _, _, l = s._learn_forward_backward(spikes, labels)
+            spikes, _, _, _, _, l = s._learn_forward_backward(spikes, labels, want_loss=False)   # nobody reads the value
             if l:
                 learned.append(s)
         if learned:

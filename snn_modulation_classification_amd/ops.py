@@ -101,15 +101,22 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     p = buf('p', (B, desc.target), i2o_W is not None)
     o = buf('o', (B, desc.target), bool(desc.output_layer))
     scratch = buf('scratch', (2, B, desc.c_out, ch, cw), pooled)
-    if K_ro >= 65536 and not desc.output_layer and i2o_W is not None:
-        # a few rows of a very long K (large plane): the readout goes through readout() below, which can split K
-        # over the chip (dcll_readout_splitk) — inside the step call it would run on rows/4 x N/4 workgroups
+    if (i2o_W is not None and B <= 2048 and _lib.get().dcll_readout_splitk_scratch(B, K_ro, desc.target) > 0 and
+            pv.data_ptr() % 16 == 0 and i2o_W.data_ptr() % 16 == 0 and
+            (not desc.output_layer or out_W.data_ptr() % 16 == 0)):
+        # few rows (rows = batch): the readouts go through readout() below, which splits K over the chip
+        # (dcll_readout_splitk: 32 x B/128 MFMA workgroups on the 16x16 plane) — inside the step call they would run on
+        # rows/4 x N/4 workgroups that re-read every pv row N/4 times
+        d2 = ConvDesc.from_buffer_copy(desc)
+        d2.output_layer = 0
         rc = _lib.get().dcll_conv_lif_step(
-            ctypes.byref(desc), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
+            ctypes.byref(d2), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
             ptr(eps0), ptr(eps1), ptr(arp), None, None, None, None,
             ptr(s), None, None, ptr(pv), ptr(v), ptr(scratch), B, stream_ptr())
         check(rc, "dcll_conv_lif_step")
-        readout(pv.reshape(B, -1), i2o_W, i2o_b, out=p)
+        readout(pv.reshape(B, -1), i2o_W, i2o_b, out=p, scratch=out)
+        if desc.output_layer:
+            readout(pv.reshape(B, -1), out_W, out_b, out=o, scratch=out)
         return s, p, o, pv, v
     rc = _lib.get().dcll_conv_lif_step(
         ctypes.byref(desc), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
@@ -318,9 +325,10 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
 READOUT_AUTO, READOUT_CORESIDENT, READOUT_LDS, READOUT_T16 = 0, 1, 2, 3       # dcll_readout_mode (include/dcll_hip.h)
 
 
-def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO):
+def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO, scratch=None):
     """out[r,n] = sum_k pv2d[r,k] Wt[n,k] + bias[n]  (i2o / output_), fp32 MFMA.  `mode`: kernel form, see
-    dcll_readout_mode — READOUT_CORESIDENT is the LDS-free <= 64-VGPR form that fits beside a resident sequence kernel."""
+    dcll_readout_mode — READOUT_CORESIDENT is the LDS-free <= 64-VGPR form that fits beside a resident sequence kernel.
+    `scratch`: optional dict in which the split-K partial-sum area of few-row calls is kept between calls."""
     rows, K = pv2d.shape
     N = Wt.shape[0]
     if Wt.shape[1] != K:
@@ -335,8 +343,12 @@ def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO):
     need = lib.dcll_readout_splitk_scratch(rows, K, N) if (rows <= 2048 and mode == READOUT_AUTO) else 0
     if need > 0 and pv2d.data_ptr() % 16 == 0 and Wt.data_ptr() % 16 == 0:
         # few rows of a long K (per-step calls on a large plane): K split over the workgroups, partials in scratch
-        scratch = torch.empty((need,), device=pv2d.device, dtype=torch.float32)
-        check(lib.dcll_readout_splitk(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), ptr(scratch), need, rows, K, N,
+        area = None if scratch is None else scratch.get('splitk')
+        if area is None or area.numel() < need:
+            area = torch.empty((need,), device=pv2d.device, dtype=torch.float32)
+            if scratch is not None:
+                scratch['splitk'] = area
+        check(lib.dcll_readout_splitk(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), ptr(area), need, rows, K, N,
                                       stream_ptr()), "dcll_readout_splitk")
         return out
     if mode != READOUT_AUTO:
@@ -392,9 +404,9 @@ def pack_spikes(dense):
 LOSS_KINDS = {"SmoothL1Loss": _lib.LOSS_SMOOTH_L1, "MSELoss": _lib.LOSS_MSE}
 
 
-def local_loss_grad(p, o, target, kind, out=None):
+def local_loss_grad(p, o, target, kind, out=None, want_loss=True):
     """Gradient and value of the local losses with mean reduction (dcll_local_loss_grad): crit(p, target) [+
-    crit(o, target)] -> (g_p, g_o or None, loss (1,)).  kind: LOSS_KINDS[...]."""
+    crit(o, target)] -> (g_p, g_o or None, loss (1,) or None).  kind: LOSS_KINDS[...]."""
     out = {} if out is None else out
     B, N = p.shape
     _expect(p, "p", torch.float32)
@@ -408,7 +420,7 @@ def local_loss_grad(p, o, target, kind, out=None):
         if t is None or tuple(t.shape) != tuple(shape):
             t = out[key] = torch.empty(shape, device=p.device, dtype=torch.float32)
         return t
-    g_p, g_o, loss = buf('g_p', (B, N)), buf('g_o', (B, N), o is not None), buf('loss', (1,))
+    g_p, g_o, loss = buf('g_p', (B, N)), buf('g_o', (B, N), o is not None), buf('loss', (1,), want_loss)
     check(_lib.get().dcll_local_loss_grad(ptr(p.contiguous()), ptr(None if o is None else o.contiguous()),
                                           ptr(target.contiguous()), ptr(g_p), ptr(g_o), ptr(loss), B, N, int(kind),
                                           stream_ptr()), "dcll_local_loss_grad")

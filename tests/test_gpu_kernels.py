@@ -441,13 +441,16 @@ def test_readout_gemm_long_rows(dev, rows, K, N):
     np.testing.assert_allclose(a1.cpu().numpy(), ref, atol=1e-4, rtol=0)
 
 
-@pytest.mark.parametrize("rows,K,N", [(64, 524288, 24), (5, 65536, 48), (700, 131072, 10)])
+@pytest.mark.parametrize("rows,K,N", [(64, 524288, 24), (5, 65536, 48), (700, 131072, 10), (512, 8192, 24), (37, 2048, 48),
+                                      (2048, 8192, 33)])
 def test_readout_few_rows_long_k(dev, rows, K, N):
-    """dcll_readout_splitk (through ops.readout): few rows of a very long K — the per-step readout on a 128x128 plane —
-    K split into 4096-column slices over the chip, partial tiles summed in slice order (run-to-run identical)."""
+    """dcll_readout_splitk (through ops.readout): few rows — the per-step readouts, rows = batch — with K split over the
+    chip: 4096-column slices of a very long K (128x128 plane), 256-column slices on the 16x16 plane (K = 8192); partial
+    tiles summed in slice order (run-to-run identical)."""
     from snn_modulation_classification_amd import ops, _lib
-    assert _lib.get().dcll_readout_splitk_scratch(rows, K, N) == (K // 4096) * rows * N
-    assert _lib.get().dcll_readout_splitk_scratch(rows, 8192, N) == 0
+    assert _lib.get().dcll_readout_splitk_scratch(rows, K, N) == (K // (4096 if K >= 65536 else 256)) * rows * N
+    assert _lib.get().dcll_readout_splitk_scratch(rows, 8192 + 32, N) == 0
+    assert _lib.get().dcll_readout_splitk_scratch(4096, 8192, N) == 0          # many rows: the plain GEMM
     rng = np.random.RandomState(4)
     pv = rng.uniform(0, 1, size=(rows, K)).astype(np.float32)
     Wt = rng.uniform(-.002, .002, size=(N, K)).astype(np.float32)
@@ -517,9 +520,10 @@ def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
         np.testing.assert_allclose(dob.cpu().numpy(), layer.out_b.grad.numpy(), **tol(layer.out_b.grad))
 
 
-@pytest.mark.parametrize("cin,cout,out_layer,hw", [(1, 8, False, (128, 128)), (3, 4, True, (128, 128)),
-                                                   (32, 32, False, (32, 48)), (32, 32, True, (128, 128))])
-def test_backward_on_large_planes(dev, cin, cout, out_layer, hw):
+@pytest.mark.parametrize("cin,cout,out_layer,hw,B", [(1, 8, False, (128, 128), 2), (3, 4, True, (128, 128), 2),
+                                                     (32, 32, False, (32, 48), 2), (32, 32, True, (128, 128), 2),
+                                                     (1, 32, False, (16, 16), 300), (32, 32, True, (16, 16), 5)])
+def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
     """dcll_conv_lif_backward on large planes incl. the argparse default 128x128 (train.py:40-41): the generic
     weight-gradient kernel stages the eps1 plane in LDS in row bands (two bands at 128 rows), the 32 -> 32 layers use the
     tiled MFMA kernel, the output_ gradient runs over K = c_out*h*w columns — against torch autograd through the CPU
@@ -527,7 +531,8 @@ def test_backward_on_large_planes(dev, cin, cout, out_layer, hw):
     from snn_modulation_classification_amd import ops
     from oracle import torch_ref as R
     rng = np.random.RandomState(17)
-    B = 2                       # 32 -> 32 layers: the MFMA weight-gradient kernel over 16x16 tiles with their real halo
+    # 32 -> 32 layers: the MFMA weight-gradient kernel over 16x16 tiles with their real halo; the two 16x16 cases: the
+    # first layer's two-tile MFMA kernel k_bwd_wgrad_c1 (300 samples over 256 workgroups) and k_bwd_wgrad_c32
     Wn, bn, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout, gain=3.0)
     sdn = _sd_from(Wn, bn, alpha, tau_m, alphas, tau_s, hw, rng=rng)
     K = cout * hw[0] * hw[1]

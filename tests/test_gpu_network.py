@@ -831,7 +831,7 @@ def test_native_learning_pieces_vs_torch():
         g_p, g_o, l = ops.local_loss_grad(p.detach().cuda(), o.detach().cuda(), tgt.cuda(), ops.LOSS_KINDS[name])
         np.testing.assert_allclose(g_p.cpu().numpy(), p.grad.numpy(), rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(g_o.cpu().numpy(), o.grad.numpy(), rtol=1e-6, atol=1e-9)
-        assert abs(float(l) - float(loss)) <= 1e-6 * abs(float(loss))
+        assert abs(float(l) - float(loss.detach())) <= 1e-6 * abs(float(loss.detach()))
         g_p1, g_o1, l1 = ops.local_loss_grad(p.detach().cuda(), None, tgt.cuda(), ops.LOSS_KINDS[name])
         assert g_o1 is None and abs(float(l1) - float(crit(p, tgt))) <= 1e-6
     shapes = [(32, 32, 7, 7), (32,), (24, 8192), (24,)]
@@ -849,8 +849,8 @@ def test_native_learning_pieces_vs_torch():
         ops.adam_step([dict(param=q, grad=g_.cuda(), exp_avg=mm, exp_avg_sq=vv, lr=h["lr"], weight_decay=h["weight_decay"],
                             beta1=h["betas"][0], beta2=h["betas"][1], eps=h["eps"], step=step)
                        for q, g_, mm, vv, h in zip(prm_m, grads, m, v, hp)])
-        for q, r in zip(prm_m, prm_t):
-            np.testing.assert_allclose(q.cpu().numpy(), r.detach().numpy(), rtol=2e-5, atol=1e-11)
+        for q, r, h in zip(prm_m, prm_t, hp):         # an update is at most ~lr per step: compare on that scale
+            np.testing.assert_allclose(q.cpu().numpy(), r.detach().numpy(), rtol=0, atol=1e-3 * h["lr"])
     cells = torch.tensor(rng.randint(0, 256, size=(5, 7)).astype(np.int32)).cuda()
     planes = ops.cells_to_planes(cells, 256)
     assert planes.shape == (5, 7, 256) and torch.equal(planes, torch.nn.functional.one_hot(cells.long(), 256).float())
