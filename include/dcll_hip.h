@@ -116,7 +116,8 @@ int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const flo
  *
  * dcll_local_loss_grad — gradient and value of the local losses with mean reduction (what loss.backward() hands to the
  *   readouts): loss = crit(p, target) [+ crit(o, target) when o != NULL], g_p = d loss / d p, g_o = d loss / d o.
- *   p, o, target, g_p, g_o (B,N) fp32; loss: 1 float, may be NULL.  kind: DCLL_LOSS_SMOOTH_L1 (torch.nn.SmoothL1Loss,
+ *   p, o, target, g_p, g_o (B,N) fp32; loss: 1 float, may be NULL; clout (B) int32, may be NULL: the per-sample argmax of
+ *   o (of p when o == NULL) that DCLLClassification.forward records (:724-728).  kind: DCLL_LOSS_SMOOTH_L1 (torch.nn.SmoothL1Loss,
  *   beta 1 — train.py's default --loss_type) or DCLL_LOSS_MSE (torch.nn.MSELoss).
  *
  * dcll_adam_step — torch.optim.Adam's update (amsgrad False; L2 weight decay added to the gradient; bias correction by
@@ -129,7 +130,7 @@ int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const flo
  */
 enum { DCLL_LOSS_SMOOTH_L1 = 0, DCLL_LOSS_MSE = 1 };
 int dcll_local_loss_grad(const float *p, const float *o, const float *target, float *g_p, float *g_o, float *loss,
-                         int32_t B, int32_t N, int32_t kind, void *stream);
+                         int32_t *clout, int32_t B, int32_t N, int32_t kind, void *stream);
 
 #define DCLL_ADAM_MAX_TENSORS 8
 typedef struct dcll_adam_tensor {

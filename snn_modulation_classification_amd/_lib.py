@@ -62,7 +62,7 @@ SIGNATURES = {
     "dcll_conv_out_shape": (_I32, [_DP, _IP, _IP, _IP, _IP]),
     "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_I32, _P]),
     "dcll_conv_lif_backward": (_I32, [_DP] + [_P] * 13 + [_I64, _I32, _P]),
-    "dcll_local_loss_grad": (_I32, [_P] * 6 + [_I32, _I32, _I32, _P]),
+    "dcll_local_loss_grad": (_I32, [_P] * 7 + [_I32, _I32, _I32, _P]),
     "dcll_adam_step": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P]),
     "dcll_cells_to_planes": (_I32, [_P, _P, _I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),

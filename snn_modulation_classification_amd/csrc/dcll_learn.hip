@@ -25,13 +25,26 @@ __device__ __forceinline__ void loss_elem(float d, int kind, float &l, float &g)
 // gradients: one thread per logit over the whole grid.  The loss VALUE (only wanted by callers that look at it — the
 // network's learning loop discards it) is summed by workgroup 0 alone in a fixed order: per-thread strided partial sums,
 // DPP tree per wave, the four wave totals added in wave order.
+// clout (optional): the per-sample argmax of the logits that DCLLClassification.forward records (:724-728: of o on the
+// output layer, else of p; first maximum like torch.argmax) — the rows are being read here anyway.
 __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ p, const float *__restrict__ o,
                                                     const float *__restrict__ target, float *__restrict__ g_p,
-                                                    float *__restrict__ g_o, float *__restrict__ loss, int n, int kind)
+                                                    float *__restrict__ g_o, float *__restrict__ loss,
+                                                    int32_t *__restrict__ clout, int n, int N, int kind)
 {
     __shared__ float red[4];
     const float inv = 1.0f / (float)n;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (clout && i < n / N) {
+        const float *l = (o ? o : p) + (long)i * N;
+        int best = 0;
+        float bv = l[0];
+        for (int k = 1; k < N; ++k) {
+            const float v = l[k];
+            if (v > bv) { bv = v; best = k; }
+        }
+        clout[i] = best;
+    }
     if (i < n) {
         const float t = target[i];
         float l, g;
@@ -61,7 +74,7 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ p, 
 }
 
 extern "C" int dcll_local_loss_grad(const float *p, const float *o, const float *target, float *g_p, float *g_o,
-                                    float *loss, int32_t B, int32_t N, int32_t kind, void *stream)
+                                    float *loss, int32_t *clout, int32_t B, int32_t N, int32_t kind, void *stream)
 {
     if (B == 0 || N == 0) return DCLL_OK;
     if (!p || !target || !g_p || B < 0 || N < 0 || (o && !g_o))
@@ -70,7 +83,7 @@ extern "C" int dcll_local_loss_grad(const float *p, const float *o, const float 
         return fail(DCLL_ERR_UNSUPPORTED, "dcll_local_loss_grad: SmoothL1Loss (beta 1) and MSELoss, mean reduction");
     if ((long)B * N > (1L << 24)) return fail(DCLL_ERR_UNSUPPORTED, "dcll_local_loss_grad: more than 2^24 logits");
     hipLaunchKernelGGL(k_loss_grad, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, o, target, g_p, g_o,
-                       loss, B * N, kind);
+                       loss, clout, B * N, N, kind);
     HIP_CHECK_LAUNCH("k_loss_grad");
     return DCLL_OK;
 }

@@ -747,11 +747,13 @@ class DCLLBase(nn.Module):
                 self.activity_hist.append((ops.pv_lowhigh(pv, 1, self.iter - 1)[0], pv.numel()))
             learned = self.iter >= self.burnin
             if learned:
-                # (DCLLClassification records the per-step argmax once the burn-in is over, :724-728)
-                if isinstance(self, DCLLClassification):
-                    self._clout.append(ops.argmax_vote((o if L.output_layer else p).unsqueeze(0), want_vote=False)[0][0])
-                g_p, g_o, loss = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(),
-                                                     out=bufs, want_loss=want_loss)
+                # (DCLLClassification records the per-step argmax once the burn-in is over, :724-728: same kernel)
+                rec = isinstance(self, DCLLClassification)
+                res = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(), out=bufs,
+                                          want_loss=want_loss, want_clout=rec)
+                g_p, g_o, loss = res[:3]
+                if rec:
+                    self._clout.append(res[3])
                 prm = [i2h.weight, i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
                 for q in prm:
                     if q.grad is None:

@@ -404,9 +404,10 @@ def pack_spikes(dense):
 LOSS_KINDS = {"SmoothL1Loss": _lib.LOSS_SMOOTH_L1, "MSELoss": _lib.LOSS_MSE}
 
 
-def local_loss_grad(p, o, target, kind, out=None, want_loss=True):
+def local_loss_grad(p, o, target, kind, out=None, want_loss=True, want_clout=False):
     """Gradient and value of the local losses with mean reduction (dcll_local_loss_grad): crit(p, target) [+
-    crit(o, target)] -> (g_p, g_o or None, loss (1,) or None).  kind: LOSS_KINDS[...]."""
+    crit(o, target)] -> (g_p, g_o or None, loss (1,) or None[, clout (B) int32 = argmax of o, or of p without o]).
+    kind: LOSS_KINDS[...]."""
     out = {} if out is None else out
     B, N = p.shape
     _expect(p, "p", torch.float32)
@@ -421,9 +422,12 @@ def local_loss_grad(p, o, target, kind, out=None, want_loss=True):
             t = out[key] = torch.empty(shape, device=p.device, dtype=torch.float32)
         return t
     g_p, g_o, loss = buf('g_p', (B, N)), buf('g_o', (B, N), o is not None), buf('loss', (1,), want_loss)
+    clout = torch.empty((B,), device=p.device, dtype=torch.int32) if want_clout else None   # kept by the caller: fresh
     check(_lib.get().dcll_local_loss_grad(ptr(p.contiguous()), ptr(None if o is None else o.contiguous()),
-                                          ptr(target.contiguous()), ptr(g_p), ptr(g_o), ptr(loss), B, N, int(kind),
-                                          stream_ptr()), "dcll_local_loss_grad")
+                                          ptr(target.contiguous()), ptr(g_p), ptr(g_o), ptr(loss), ptr(clout), B, N,
+                                          int(kind), stream_ptr()), "dcll_local_loss_grad")
+    if want_clout:
+        return g_p, g_o, loss, clout
     return g_p, g_o, loss
 
 

@@ -832,8 +832,11 @@ def test_native_learning_pieces_vs_torch():
         np.testing.assert_allclose(g_p.cpu().numpy(), p.grad.numpy(), rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(g_o.cpu().numpy(), o.grad.numpy(), rtol=1e-6, atol=1e-9)
         assert abs(float(l) - float(loss.detach())) <= 1e-6 * abs(float(loss.detach()))
-        g_p1, g_o1, l1 = ops.local_loss_grad(p.detach().cuda(), None, tgt.cuda(), ops.LOSS_KINDS[name])
-        assert g_o1 is None and abs(float(l1) - float(crit(p, tgt))) <= 1e-6
+        g_p1, g_o1, l1, cl = ops.local_loss_grad(p.detach().cuda(), None, tgt.cuda(), ops.LOSS_KINDS[name], want_clout=True)
+        assert g_o1 is None and abs(float(l1) - float(crit(p, tgt).detach())) <= 1e-6
+        assert torch.equal(cl.cpu().long(), p.detach().argmax(1))
+        cl2 = ops.local_loss_grad(p.detach().cuda(), o.detach().cuda(), tgt.cuda(), ops.LOSS_KINDS[name], want_clout=True)[3]
+        assert torch.equal(cl2.cpu().long(), o.detach().argmax(1))
     shapes = [(32, 32, 7, 7), (32,), (24, 8192), (24,)]
     hp = [dict(lr=1e-6, betas=(0.0, .95), weight_decay=10.0, eps=1e-8)] * 2 + [dict(lr=1e-4, betas=(.9, .999), weight_decay=0.0, eps=1e-8)] * 2
     prm_t = [torch.nn.Parameter(torch.tensor(rng.uniform(-1e-5, 1e-5, size=s).astype(np.float32))) for s in shapes]
