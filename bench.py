@@ -52,6 +52,63 @@ def build_net(batch, device):
     return net, convs
 
 
+def bench_ref_network(a):
+    """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code, so
+    parity is unpinned): radio_ml_conv_ref.yaml — 7 x (64 channels, (1,3) kernels, (1,2) pooling) — on a Q=16 x I=128 I/Q
+    plane, per-output-channel int8 conv weights (dequantised for the kernels), T=128, batch `--batch` (default 256).
+    Runs the fused sequence path when the geometry has one, else the per-step path (one C-ABI call per layer and step on
+    device-built spike planes).  One JSON line like the headline benchmark (no CPU leg: the torch-CPU port needs ~1 s per
+    window here)."""
+    from snn_modulation_classification_amd import ops, quant
+    assert a.gpus == 1, "--network ref is a single-GPU measurement"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    H, W, B = 16, 128, (a.batch or 256)
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks",
+                                           "radio_ml_conv_ref.yaml"))
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(args, (1, H, W), B, convs, N_CLASSES, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
+                      learning_rates=None, burnin=20)
+    net.reset(True)
+    quant.apply_int8_weights(net)
+    enc = IQEncoder(W, H, device=dev)
+    iq = (0.4 * torch.randn(B, 2, L_IQ, generator=torch.Generator().manual_seed(1))).to(dev)
+    fused = net.sequence_supported()
+
+    def step():
+        net.zero_states()
+        net.reset()
+        if fused:
+            return net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False)["vote"][-1]
+        cells = enc(iq, T_STEPS, t0=0)
+        planes = ops.cells_to_planes(cells, H * W)
+        for t in range(T_STEPS):
+            net.test(planes[t].reshape(B, 1, H, W))
+        return None
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flop = sum(2 * 64 * (1 if i == 0 else 64) * 3 * H * (W >> i) for i in range(7)) * T_STEPS * B
+    print(json.dumps({
+        "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": B * a.steps / dt, "unit": "IQ windows/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "radio_ml_conv_ref.yaml (7 x 64 ch, (1,3) kernels, (1,2) pooling), Q=16 x I=128 I/Q plane, "
+                               "T=128, int8 per-channel conv weights (dequantised) + 1-bit packed spikes, batch %d, %s; "
+                               "parity unpinned (no reference quantisation code)" %
+                               (B, "fused sequence kernels" if fused else "per-step path (7 layer calls per timestep)"),
+                   "batch_per_gpu": B, "T": T_STEPS, "plane": [H, W], "path": "sequence" if fused else "per-step"},
+        "conv_tflops": flop * a.steps / dt / 1e12}))
+
+
 def log(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -134,7 +191,11 @@ def main():
     ap.add_argument("--overlap-readout", type=int, default=None,
                     help="1: readouts / statistics / votes on a second stream under the next layer's kernel "
                          "(default: DCLL_OVERLAP_READOUT)")
+    ap.add_argument("--network", default="radio", choices=["radio", "ref"],
+                    help="radio = radio_ml_conv.yaml (headline); ref = radio_ml_conv_ref.yaml with int8 weights (config 5)")
     a = ap.parse_args()
+    if a.network == "ref":
+        return bench_ref_network(a)
     if a.gpus > 1 and not parallel.under_launcher():
         # started plainly (`python bench.py --gpus N`): this process becomes the launcher of N fresh rank processes and
         # never touches the GPU itself; rank 0's JSON line goes straight to our stdout.  Under torchrun the ranks
