@@ -2430,8 +2430,24 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
                                       float *ro_out, int32_t n_ro, float *state_scratch, uint64_t *pv_lowhigh,
                                       int32_t iter0, int32_t T, int32_t B, void *stream)
 {
-    int rc = check_seq_geometry(d, 32, "dcll_conv_lif_sequence");
+    int rc = check_desc(d);
     if (rc) return rc;
+    const bool w3 = dcll_seq_w3_geometry(d) && d->c_in == 64;
+    if (!w3) {
+        rc = check_seq_geometry(d, 32, "dcll_conv_lif_sequence");
+        if (rc) return rc;
+    }
+    if (w3) {       // radio_ml_conv_ref.yaml geometry: pooled outputs (dcll_seq_w3.hip)
+        if (T == 0 || B == 0) return DCLL_OK;
+        if (!spk_in || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: null pointer");
+        if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: refractory layer needs arp");
+        if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: negative size");
+        if (n_ro) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout only for the 7x7 layers on the 16x16 plane");
+        rc = dcll_launch_seq_w3(d, spk_in, nullptr, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (hipStream_t)stream);
+        if (rc || !pv_lowhigh) return rc;
+        return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * (d->w / 2), T, iter0, (unsigned long long *)pv_lowhigh,
+                                 (hipStream_t)stream, "dcll_conv_lif_sequence");
+    }
     rc = dcll_conv_lif_sequence_run(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out,
                                     n_ro, state_scratch, T, B, stream);
     if (rc || !pv_lowhigh || T <= 0 || B <= 0) return rc;
@@ -2535,12 +2551,23 @@ extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32
                                             float *pv_out, float *v_out, float *state_scratch, uint64_t *pv_lowhigh,
                                             int32_t iter0, int32_t T, int32_t B, void *stream)
 {
-    int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_cells");
+    int rc = check_desc(d);
     if (rc) return rc;
+    const bool w3 = dcll_seq_w3_geometry(d) && d->c_in == 1;
+    if (!w3) {
+        rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_cells");
+        if (rc) return rc;
+    }
     if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
     if (!cells || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: refractory layer needs arp");
     if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: negative size");
+    if (w3) {       // first layer of radio_ml_conv_ref.yaml: pooled outputs (dcll_seq_w3.hip)
+        rc = dcll_launch_seq_w3(d, nullptr, cells, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (hipStream_t)stream);
+        if (rc || !pv_lowhigh) return rc;
+        return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * (d->w / 2), T, iter0, (unsigned long long *)pv_lowhigh,
+                                 (hipStream_t)stream, "dcll_conv_lif_sequence_cells");
+    }
     return launch_c1(d, cells, nullptr, nullptr, nullptr, 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
                      state_scratch, pv_lowhigh, iter0, T, B, (hipStream_t)stream);
 }

@@ -53,6 +53,13 @@ int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const flo
                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
                         float *state_scratch, int T, int B, hipStream_t st);
 
+// k_lif_seq_w3 (dcll_seq_w3.hip): the (1,3)-kernel / 64-channel / (1,2)-pool layers of radio_ml_conv_ref.yaml, all T steps
+__attribute__((visibility("hidden"))) bool dcll_seq_w3_geometry(const dcll_conv_desc *d);
+__attribute__((visibility("hidden")))
+int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const int32_t *cells, const float *W, const float *b,
+                       const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
+                       float *v_out, int32_t T, int32_t B, hipStream_t st);
+
 // k_readout_direct (dcll_readout.hip): LDS-free 16x16x4 readout GEMM in <= 64 VGPRs (fits beside a sequence kernel)
 __attribute__((visibility("hidden")))
 int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,

@@ -1,0 +1,269 @@
+// dcll_seq_w3.hip — k_lif_seq_w3: the fused all-T layer kernel for the geometry of networks/radio_ml_conv_ref.yaml
+// (BASELINE config 5): 64 output channels, kernel (1,3), padding (0,1), max-pool (1,2), c_in = 1 (first layer, input =
+// one spike per step as a cell index) or 64 (bit-packed spikes in) — fifth translation unit of libdcll_hip.so.
+//
+// What the geometry gives: the kernel height is 1, so the rows of the plane are independent in every layer, and pooling
+// pairs are neighbours in the row-major flattening.  A layer's input is therefore handled as a stream of 32-pixel TILES
+// of the flattened (H x W) plane of each sample — a tile is 32/W rows when the layer has become narrow (W = 16 ... 2
+// after the poolings), so the MFMA lanes stay full in all seven layers.  One 512-thread workgroup owns W3_NT = 8
+// consecutive tiles (256 pixels: whole rows, of one sample or — narrow layers — of several) for all T steps:
+//   - eps0 of its 64 x 256 trace elements in registers (thread = (input channel, tile): the 32 pixels of ONE input
+//     spike word), eps1 in an LDS image with one shared zero column between rows (the conv's horizontal padding);
+//   - weights stationary in registers: wave (mt, g) holds the A fragments of output-channel tile mt (32 of the 64
+//     channels) for the whole chain K = 64 x 3 = 192 — 96 VGPRs — and runs the complete pinned fmaf chain
+//     (cp, kx, h: ci = 2cp + h) of its two pixel tiles 2g, 2g+1, one after the other: no hand-off between waves (unlike
+//     k_lif_seq_c32d, whose K = 1568 had to be split over the waves);
+//   - lane <-> pixel map of a tile: lanes 0..15 hold the EVEN pixels, lanes 16..31 the ODD ones, so a pooling pair sits
+//     in lanes j and j + 16: pooled pv = max with one ds_swizzle (xor 16), and the ballot of the spike compare carries
+//     the even pixels in bits 0..15 and the odd ones in bits 16..31: pooled spike half-word = (w & 0xffff) | (w >> 16);
+//     the half-words of a wave's two tiles are one 32-bit word of the next layer's input;
+//   - per step: trace update (all threads) | barrier | 2 x 96 MFMAs + epilogue per wave | barrier.
+// Outputs are the POOLED maps: spk_out (T,B,64,H*W/64) packed, pv_out (T,B,64,H,W/2); v_out (T,B,64,H,W) un-pooled.
+// Same pinned arithmetic as every other path (include/dcll_hip.h): bit-identical to the per-step kernels / the C oracle.
+#include "dcll_internal.h"
+
+constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
+constexpr int W3_CHS = 385;         // floats per channel image: 256 pixels + 256 / W shared pad columns + 1 <= 385 (W = 2)
+
+template <int CIN, bool REFRACTORY, int OUT>     // OUT bit0: pooled pv, bit1: un-pooled v
+__global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
+                                                     const float *__restrict__ W, const float *__restrict__ bias,
+                                                     const float *__restrict__ tau4, float *__restrict__ eps0_g,
+                                                     float *__restrict__ eps1_g, float *__restrict__ arp_g,
+                                                     uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
+                                                     float *__restrict__ v_out, int T, int B, int HW, int logW,
+                                                     float alpharp, float wrp)
+{
+    constexpr int NK = CIN == 1 ? 2 : 96;               // MFMA k-steps of a chain
+    constexpr int NE = CIN == 1 ? 1 : 32;               // trace elements per owning thread
+    __shared__ __attribute__((aligned(16))) float img[CIN * W3_CHS + 8];
+    __shared__ float sbias[64];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, jj = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = w & 1, g = w >> 1;
+    const int NTS = HW >> 5;                             // tiles per sample
+    const long ntot = (long)B * NTS;
+    const long G0 = (long)blockIdx.x * W3_NT;            // first tile of this workgroup
+
+    for (int i = tid; i < CIN * W3_CHS + 8; i += 512) img[i] = 0.0f;
+    if (tid < 64) sbias[tid] = bias[tid];
+
+    // ---- trace ownership -------------------------------------------------------------------------------------------
+    // CIN = 64: thread (ci = tid >> 3, wq = tid & 7) owns the 32 pixels of tile wq of channel ci (= one input word);
+    // CIN = 1:  threads 0..255 own one pixel each of the single channel
+    const int ci_t = CIN == 1 ? 0 : tid >> 3, wq = CIN == 1 ? tid >> 5 : tid & 7;
+    const long Gt = G0 + wq;
+    const bool tvalid = Gt < ntot && (CIN == 64 || tid < W3_PX);
+    const long bt = tvalid ? Gt / NTS : 0;
+    const int mtile = tvalid ? (int)(Gt % NTS) : 0;
+    const float ta = tau4[0 * CIN + ci_t], tm = tau4[1 * CIN + ci_t], tas = tau4[2 * CIN + ci_t], ts = tau4[3 * CIN + ci_t];
+    float e0[NE];
+    // LDS offset of my first pixel: block pixel p -> ci * CHS + p + (p >> logW) + 1
+    // (for my 32 consecutive pixels 32 wq + i the row term splits into a per-thread part and a wave-uniform one:
+    //  (32 wq + i) >> logW == ((32 wq) >> logW) + (i >> logW), W a power of two)
+    const int p0 = CIN == 1 ? tid & (W3_PX - 1) : 32 * wq;
+    const int loff0 = ci_t * W3_CHS + p0 + 1 + (p0 >> logW);
+    const long sbase = (bt * CIN + ci_t) * HW + 32L * mtile + (CIN == 1 ? (tid & 31) : 0);     // my first state element
+    __syncthreads();                                     // image zeroed
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        e0[i] = tvalid ? eps0_g[sbase + i] : 0.0f;
+        if (tvalid) img[loff0 + i + (i >> logW)] = eps1_g[sbase + i];
+    }
+
+    // ---- weights of my output-channel tile, stationary: A[co = 32 mt + jj][k] ----------------------------------------
+    float wf[NK];
+    if (CIN == 1) {         // k lanes = tap parity: step 0 = taps (0,1), step 1 = taps (2, zero-weight pad)
+        wf[0] = W[(32 * mt + jj) * 3 + h];
+        wf[NK - 1] = h == 0 ? W[(32 * mt + jj) * 3 + 2] : 0.0f;
+    } else {                // k lanes = input-channel pair: step s = cp * 3 + kx -> W[co][2 cp + h][kx]
+#pragma unroll
+        for (int s = 0; s < NK; ++s) wf[s] = W[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3];
+    }
+    // ---- my two pixel tiles (independent chains) ----------------------------------------------------------------------
+    const int perm = jj < 16 ? 2 * jj : 2 * (jj - 16) + 1;          // lane -> pixel of the tile (even | odd)
+    const long GA = G0 + 2 * g;
+    const bool validA = GA < ntot, validB = GA + 1 < ntot;
+    const long bA = validA ? GA / NTS : 0, bB = validB ? (GA + 1) / NTS : 0;
+    const int mA = validA ? (int)(GA % NTS) : 0, mB = validB ? (int)((GA + 1) % NTS) : 0;
+    const int pA = 64 * g + perm, pB = pA + 32;
+    // B-fragment lane base: CIN = 64: channel h of the pair; CIN = 1: tap h of the pair (tap kx reads x + kx - 1)
+    const int baseA = (CIN == 1 ? h : h * W3_CHS) + pA + (pA >> logW), baseB = (CIN == 1 ? h : h * W3_CHS) + pB + (pB >> logW);
+    float arpA[16], arpB[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        arpA[r] = (REFRACTORY && validA) ? arp_g[(bA * 64 + co) * HW + 32L * mA + perm] : 0.0f;
+        arpB[r] = (REFRACTORY && validB) ? arp_g[(bB * 64 + co) * HW + 32L * mB + perm] : 0.0f;
+    }
+    const int HW2 = HW >> 1, NW2 = NTS >> 1;             // pooled pixels / pooled words per channel plane
+    // input of step 0
+    uint32_t word = 0;
+    int cell = -1;
+    if (CIN == 1) cell = cells[bt];
+    else if (tvalid) word = spk_in[(bt * CIN + ci_t) * NTS + mtile];
+    const long in_step = (long)B * CIN * NTS;
+
+    for (int t = 0; t < T; ++t) {
+        // ---- (1) traces of step t (dcll/pytorch_libdcll.py:493-494, every op rounded separately); eight elements at a
+        //      time (all 32 in flight would hold 32 more registers on top of weights + accumulators + states) ----
+        {
+            const int pix0 = 32 * mtile + (CIN == 1 ? (tid & 31) : 0);          // my first pixel inside the sample plane
+            int lb = loff0, lw = logW;
+            // opaque per step: keeps the 32 element addresses (and their 32 wave-uniform row terms) out of loop-invariant
+            // registers — they are two instructions each to recompute
+            asm volatile("" : "+v"(lb), "+s"(lw));
+#pragma unroll
+            for (int i0 = 0; i0 < NE; i0 += 8) {
+                float e1[8];
+#pragma unroll
+                for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[lb + i + (i >> lw)];
+#pragma unroll
+                for (int i = i0; i < i0 + 8 && i < NE; ++i) {
+                    const float x = CIN == 1 ? (cell == pix0 ? 1.0f : 0.0f) : (float)((word >> i) & 1u);
+                    trace_update(x, ta, tm, tas, ts, e0[i], e1[i - i0]);
+                    if (tvalid) img[lb + i + (i >> lw)] = e1[i - i0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();
+        // next step's input: lands during the chains
+        if (t + 1 < T) {
+            if (CIN == 1) cell = cells[(long)(t + 1) * B + bt];
+            else if (tvalid) word = spk_in[(long)(t + 1) * in_step + (bt * CIN + ci_t) * NTS + mtile];
+        }
+        // ---- (2) + (3) per tile: the chain in the pinned order (cp, kx, h), then its epilogue.  One tile after the other
+        //      (two interleaved chains + a joint epilogue need 32 accumulator registers and twice the temporaries: with
+        //      96 weight and 64 state registers that spilled ~160 VGPRs) ----
+        int vwA = 0, vwB = 0;
+        auto do_tile = [&](const int base, float (&arp)[16], const bool valid, const long bb, const int mm, int &vw) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = sbias[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
+            if (CIN == 1) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0], img[base + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[NK - 1], img[base + 2], acc, 0, 0, 0);
+            } else {
+                // the 6 B fragments of channel pairs cp + 2, cp + 3 are fetched before the MFMAs of pairs cp, cp + 1
+                float bq[2][6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) bq[0][q] = img[base + (q / 3) * 2 * W3_CHS + q % 3];
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) {
+                    if (c2 + 1 < 16) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) bq[(c2 + 1) & 1][q] = img[base + (2 * (c2 + 1) + q / 3) * 2 * W3_CHS + q % 3];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(CIN == 1) ? 0 : c2 * 6 + q], bq[c2 & 1][q], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // epilogue: refractory trace, threshold, sigmoid, (1,2) max-pool, pooled spike half-word.
+            // stores as wave-uniform base (per value) + 32-bit lane offset: no 64-bit address VALU
+            const long row = ((long)t * B + bb) * 64 + 32 * mt;
+            float *pvb = pv_out + row * HW2, *vb = v_out + row * HW;
+            unsigned lp = 4 * h * HW2 + 16 * mm + jj, lv = 4 * h * HW + 32 * mm + perm;       // + cr * HW2 / + cr * HW
+            int hw2 = HW2, hw1 = HW;
+            // opaque per step: otherwise the per-value store addresses derived from them are hoisted out of the time loop
+            asm volatile("" : "+v"(lp), "+v"(lv), "+s"(hw2), "+s"(hw1));
+            static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int cr = (r & 3) + 8 * (r >> 2);              // + 32 mt + 4 h = output channel
+                float v = acc[r];
+                bool sp;
+                if (REFRACTORY) v = refractory(acc[r], arp[r], alpharp, wrp, sp);
+                else sp = v > 0.0f;
+                const unsigned long long mk = __ballot(sp);
+                // per half h: even pixels in bits 0..15, odd in 16..31 -> 16 pooled bits
+                const uint32_t a0 = (uint32_t)mk, a1 = (uint32_t)(mk >> 32);
+                const uint32_t w0 = (a0 & 0xffffu) | (a0 >> 16), w1 = (a1 & 0xffffu) | (a1 >> 16);
+                // (wait states as the compiler places them around its own v_writelane, see k_lif_seq_c1)
+                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
+                    : "+v"(vw) : "s"(w0), "s"(w1), "n"(r), "n"(32 + r));
+                if (OUT & 1) {
+                    const float q = sigmoidf_dev(v);
+                    const float o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(q), 0x401F));       // lane ^ 16
+                    if (jj < 16 && valid) (pvb + (long)cr * hw2)[lp] = fmaxf(q, o);
+                }
+                if ((OUT & 2) && valid) (vb + (long)cr * hw1)[lv] = v;
+                __builtin_amdgcn_sched_barrier(0);      // one value at a time: keeps the temporaries few
+            });
+        };
+        do_tile(baseA, arpA, validA, bA, mA, vwA);
+        do_tile(baseB, arpB, validB, bB, mB, vwB);
+        // lanes 0..15 / 32..47 hold the pooled half-words of channel (lane & 3) + 8 ((lane & 15) >> 2) + 4 h of my two
+        // tiles: together one 32-bit word of the next layer's input
+        if (spk_out && jj < 16 && validA) {
+            const long row = ((long)t * B + bA) * 64 + 32 * mt;
+            (spk_out + row * NW2)[(unsigned)((jj & 3) + 8 * (jj >> 2) + 4 * h) * (unsigned)NW2 + (unsigned)(mA >> 1)] =
+                (uint32_t)vwA | ((uint32_t)vwB << 16);
+        }
+        lds_barrier();
+    }
+    // ---- state back to HBM ----
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        if (tvalid) {
+            eps0_g[sbase + i] = e0[i];
+            eps1_g[sbase + i] = img[loff0 + i + (i >> logW)];
+        }
+    }
+    if (REFRACTORY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (validA) arp_g[(bA * 64 + co) * HW + 32L * mA + perm] = arpA[r];
+            if (validB) arp_g[(bB * 64 + co) * HW + 32L * mB + perm] = arpB[r];
+        }
+    }
+}
+
+// geometry served: c_in 1 or 64, c_out 64, kernel (1,3), padding (0,1), pooling (1,2), w a power of two <= 256,
+// h * w a multiple of 32 (64 when packed spikes are wanted), time constants per input channel
+bool dcll_seq_w3_geometry(const dcll_conv_desc *d)
+{
+    const bool pow2 = d->w >= 2 && d->w <= 256 && (d->w & (d->w - 1)) == 0;
+    return (d->c_in == 1 || d->c_in == 64) && d->c_out == 64 && d->kh == 1 && d->kw == 3 && d->pad_h == 0 && d->pad_w == 1 &&
+           d->pool_h == 1 && d->pool_w == 2 && pow2 && ((long)d->h * d->w) % 32 == 0 && (256 % d->w == 0 || d->w == 256);
+}
+
+int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const int32_t *cells, const float *W, const float *b,
+                       const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
+                       float *v_out, int32_t T, int32_t B, hipStream_t st)
+{
+    const long HW = (long)d->h * d->w;
+    if (HW >= (1L << 24)) return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3): plane larger than 2^24 pixels");
+    if (spk_out && HW % 64 != 0)
+        return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3): packed pooled spikes need h * w % 64 == 0");
+    if (d->c_in == 1 && (HW / 32) % W3_NT != 0)
+        return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3), first layer: h * w must be a multiple of 256");
+    int logW = 0;
+    while ((1 << logW) < d->w) ++logW;
+    const long ntile = (long)B * (HW / 32);
+    const long nwg = (ntile + W3_NT - 1) / W3_NT;
+    if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x tiles exceeds the grid limit");
+    const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
+#define DCLL_LAUNCH_W3(C, R, O)                                                                                         \
+    hipLaunchKernelGGL((k_lif_seq_w3<C, R, O>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, b, tau4, eps0,   \
+                       eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp)
+#define DCLL_LAUNCH_W3O(C, R)                                                                                           \
+    switch (out) {                                                                                                      \
+    case 0: DCLL_LAUNCH_W3(C, R, 0); break;                                                                              \
+    case 1: DCLL_LAUNCH_W3(C, R, 1); break;                                                                              \
+    case 2: DCLL_LAUNCH_W3(C, R, 2); break;                                                                              \
+    default: DCLL_LAUNCH_W3(C, R, 3); break;                                                                             \
+    }
+    if (d->c_in == 1) {
+        if (d->refractory) { DCLL_LAUNCH_W3O(1, true) } else { DCLL_LAUNCH_W3O(1, false) }
+    } else {
+        if (d->refractory) { DCLL_LAUNCH_W3O(64, true) } else { DCLL_LAUNCH_W3O(64, false) }
+    }
+#undef DCLL_LAUNCH_W3O
+#undef DCLL_LAUNCH_W3
+    HIP_CHECK_LAUNCH("k_lif_seq_w3");
+    return DCLL_OK;
+}

@@ -382,19 +382,27 @@ class Conv2dDCLLlayer(nn.Module):
 
     # -- whole-sequence fast path ---------------------------------------------------------------------------------
     def sequence_kind(self):
-        """'cells' / 'packed' if a fused all-T kernel exists for this geometry (include/dcll_hip.h), else None."""
+        """'cells' / 'packed' if a fused all-T kernel exists for this geometry (include/dcll_hip.h), else None:
+        the 7x7 / pad 3 / pool 1 layers of radio_ml_conv.yaml (1 -> <=32 and 32 -> 32 channels; 16x16 plane or H % 8 == 0,
+        W % 32 == 0), or the (1,3) / pad (0,1) / pool (1,2) layers of radio_ml_conv_ref.yaml (1 -> 64 and 64 -> 64
+        channels; W a power of two <= 256; k_lif_seq_w3)."""
         i = self.i2h
         H, W = self.im_dims
-        plane_ok = (H, W) == (16, 16) or (H % 8 == 0 and W % 32 == 0)      # k_lif_seq_c1/c32 or the tiled c1t/c32t
-        ok = (plane_ok and i.kernel_size == (7, 7) and i.padding == (3, 3) and
-              self.pooling == (1, 1) and i.stride == 1 and i.dilation == 1 and i.groups == 1 and
-              i.out_channels <= 32 and i.bias is not None and i.spiking)
-        if not ok or i.tau_per_channel() is None:
+        if not (i.stride == 1 and i.dilation == 1 and i.groups == 1 and i.bias is not None and i.spiking) or \
+                i.tau_per_channel() is None:
             return None
-        if i.in_channels == 1:
-            return 'cells'
-        if i.in_channels == 32 and i.out_channels == 32:
-            return 'packed'
+        if i.kernel_size == (7, 7) and i.padding == (3, 3) and self.pooling == (1, 1) and i.out_channels <= 32 and \
+                ((H, W) == (16, 16) or (H % 8 == 0 and W % 32 == 0)):         # k_lif_seq_c1/c32 or the tiled c1t/c32t
+            if i.in_channels == 1:
+                return 'cells'
+            if i.in_channels == 32 and i.out_channels == 32:
+                return 'packed'
+        if i.kernel_size == (1, 3) and i.padding == (0, 1) and self.pooling == (1, 2) and i.out_channels == 64 and \
+                2 <= W <= 256 and (W & (W - 1)) == 0 and (H * W) % 32 == 0:
+            if i.in_channels == 1 and (H * W) % 256 == 0:
+                return 'cells'
+            if i.in_channels == 64:
+                return 'packed'
         return None
 
     def stacked_readout(self):

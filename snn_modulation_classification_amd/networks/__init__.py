@@ -144,31 +144,37 @@ class ConvNetwork(torch.nn.Module):
         return kinds[0] == 'cells' and all(k == 'packed' for k in kinds[1:])
 
     def _sequence_buffers(self, T, B, dev, n_pv=1):
-        """Inter-layer spike, pv and logit buffers of one chunk, cached: flat allocations sized for the largest batch
-        seen so far at this T, handed out as (T, B, ...) views (a smaller last chunk reuses them).  n_pv = number of pv
-        buffers: 1 (every layer's readout runs before the next layer's kernel overwrites it) or one per layer (the
-        readouts run on a second stream under the next layer's kernel)."""
+        """Inter-layer spike, pv and logit buffers of one chunk, cached: flat allocations sized for the largest layer
+        and the largest batch seen so far at this T, handed out as per-layer (T, B, ...) views (a smaller last chunk
+        reuses them).  n_pv = number of pv buffers: 1 (every layer's readout runs before the next layer's kernel
+        overwrites it) or one per layer (the readouts run on a second stream under the next layer's kernel)."""
         key = (T, str(dev))
-        L = self.dcll_slices[0].dclllayer
-        C, (H, W) = L.out_channels, L.output_shape
+        layers = [s.dclllayer for s in self.dcll_slices]
+        npix = [int(np.prod(L.output_shape)) for L in layers]               # (pooled) pixels of a layer's output map
+        chans = [L.out_channels for L in layers]
+        spk_max = max(c * (n // 32) for c, n in zip(chans[:-1], npix[:-1])) if len(layers) > 1 else 1
+        pv_max = max(c * n for c, n in zip(chans, npix))
+        H, W = layers[0].im_dims
         cache = self._seq_buffers.get(key)
         if cache is not None and cache['cap'] >= B:
             while len(cache['pv']) < n_pv:
-                cache['pv'].append(torch.empty(T * cache['cap'] * C * H * W, device=dev, dtype=torch.float32))
+                cache['pv'].append(torch.empty(T * cache['cap'] * pv_max, device=dev, dtype=torch.float32))
         if cache is None or cache['cap'] < B:
             self._seq_buffers.clear()
             n_ro = [self.target_size * (2 if i == self.num_layers - 1 else 1) for i in range(self.num_layers)]
-            cmax = max(s.dclllayer.in_channels for s in self.dcll_slices)
+            cmax = max(L.in_channels for L in layers)
+            tiled = (H, W) != (16, 16) and layers[0].i2h.kernel_size == (7, 7)
             cache = dict(cap=B,
-                         spk=[torch.empty(T * B * C * (H * W // 32), device=dev, dtype=torch.int32) for _ in range(2)],
-                         pv=[torch.empty(T * B * C * H * W, device=dev, dtype=torch.float32) for _ in range(n_pv)],
+                         spk=[torch.empty(T * B * spk_max, device=dev, dtype=torch.int32) for _ in range(2)],
+                         pv=[torch.empty(T * B * pv_max, device=dev, dtype=torch.float32) for _ in range(n_pv)],
                          ro=[torch.empty(T * B * n, device=dev, dtype=torch.float32) for n in n_ro],
-                         # snapshot area of the tiled kernels (planes other than 16x16): initial eps0 / eps1 of a layer
-                         state_scratch=(torch.empty(2 * B * cmax * H * W, device=dev, dtype=torch.float32)
-                                        if (H, W) != (16, 16) else None))
+                         # snapshot area of the tiled 7x7 kernels (planes other than 16x16): initial eps0 / eps1 of a layer
+                         state_scratch=(torch.empty(2 * B * cmax * H * W, device=dev, dtype=torch.float32) if tiled else None))
             self._seq_buffers[key] = cache
-        return dict(spk=[t[:T * B * C * (H * W // 32)].view(T, B, C, H * W // 32) for t in cache['spk']],
-                    pv=[t[:T * B * C * H * W].view(T, B, C, H, W) for t in cache['pv']],
+        return dict(spk=[[t[:T * B * c * (n // 32)].view(T, B, c, n // 32) for t in cache['spk']]
+                         for c, n in zip(chans, npix)],
+                    pv=[[t[:T * B * L.out_channels * n].view(T, B, L.out_channels, *L.output_shape) for t in cache['pv']]
+                        for L, n in zip(layers, npix)],
                     ro=[t[:T * B * (t.numel() // (T * cache['cap']))].view(T, B, -1) for t in cache['ro']],
                     state_scratch=cache['state_scratch'])
 
@@ -213,14 +219,17 @@ class ConvNetwork(torch.nn.Module):
             if t0 is None:
                 t0 = np.random.randint(0, iq.shape[-1] - T + 1)       # same draw as iq2spiketrain
             dev = iq.device
-        else:
+            if self.dcll_slices[0].dclllayer.i2h.kernel_size != (7, 7):
+                # only the 7x7 first-layer kernels have the quantisation fused in: encode with its own (cheap) kernel
+                cells, iq = encoder(iq, T, t0=int(t0)), None
+                T, B = cells.shape
+        if iq is None:
             T, B = cells.shape
             cells = cells.contiguous()
             dev = cells.device
         # Samples are independent, so a batch whose pv buffer (T*B*C*H*W floats per layer) would exceed the budget is
         # run in chunks — on the 128x128 plane T=128 x 512 windows would otherwise need 137 GB for pv alone.
-        L0 = self.dcll_slices[0].dclllayer
-        per_sample = 4 * T * L0.out_channels * int(np.prod(L0.output_shape))
+        per_sample = 4 * T * max(s.dclllayer.out_channels * int(np.prod(s.dclllayer.output_shape)) for s in self.dcll_slices)
         chunk = max(1, min(B, int(self.pv_budget_bytes // max(per_sample, 1))))
         if chunk < B:
             for s in self.dcll_slices:
@@ -289,7 +298,7 @@ class ConvNetwork(torch.nn.Module):
             last = (i == self.num_layers - 1)
             fused = fuse_readout and i > 0
             hidden_skip = output_only and not last
-            lbuf = dict(spk=buf['spk'][i & 1], pv=buf['pv'][i if overlap else 0], ro=buf['ro'][i],
+            lbuf = dict(spk=buf['spk'][i][i & 1], pv=buf['pv'][i][i if overlap else 0], ro=buf['ro'][i],
                         state_scratch=buf['state_scratch'])
             # pv statistics of the reference's histogram steps (:658-661) for slices that collect them; counted from
             # the slice's iteration count as T calls of forward() would

@@ -200,7 +200,7 @@ def _seq_extras(desc, B, T, dev, out, lowhigh_iter0):
     comes from `out['state_scratch']` or is allocated here.  lowhigh_iter0 = the slice's iteration count before the
     call turns the pv statistics on (None = off)."""
     scratch = None
-    if (desc.h, desc.w) != (16, 16):
+    if (desc.h, desc.w) != (16, 16) and (desc.kh, desc.kw) == (7, 7):
         n = 2 * B * desc.c_in * desc.h * desc.w
         scratch = out.get("state_scratch")
         if scratch is None or scratch.numel() < n:
@@ -237,17 +237,19 @@ def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spik
     dev = W.device
     out = {} if out is None else out
     words = desc.h * desc.w // 32
+    ch, cw, ph, pw = conv_out_shape(desc)          # pooling layers (the (1,3) / pool (1,2) geometry) emit POOLED maps
+    owords = ph * pw // 32
     _expect(spk_in, "spk_in", torch.int32, (T, B, desc.c_in, words))
     _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau4=tau4)
     spk = out.get("spk") if want_spikes else None
     if want_spikes and spk is None:
-        spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
+        spk = torch.empty((T, B, desc.c_out, owords), device=dev, dtype=torch.int32)
     pv = out.get("pv") if want_pv else None
     if want_pv and pv is None:
-        pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
-    _expect(spk, "spk_out", torch.int32, (T, B, desc.c_out, words))
-    _expect(pv, "pv_out", torch.float32, (T, B, desc.c_out, desc.h, desc.w))
-    v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+        pv = torch.empty((T, B, desc.c_out, ph, pw), device=dev, dtype=torch.float32)
+    _expect(spk, "spk_out", torch.int32, (T, B, desc.c_out, owords))
+    _expect(pv, "pv_out", torch.float32, (T, B, desc.c_out, ph, pw))
+    v = torch.empty((T, B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if want_v else None
     n_ro, logits = 0, None
     if ro_Wp is not None:
         n_ro = ro_b.numel()
@@ -273,16 +275,19 @@ def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want
     """All T steps of the first layer (c_in = 1) from cell indices (T,B) int32 (k_lif_seq_c1)."""
     dev = W.device
     out = {} if out is None else out
-    words = desc.h * desc.w // 32
+    ch, cw, ph, pw = conv_out_shape(desc)          # pooling layers emit POOLED maps
+    owords = ph * pw // 32
     _expect(cells, "cells", torch.int32, (T, B))
     _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau4=tau4)
     spk = out.get("spk") if want_spikes else None
     if want_spikes and spk is None:
-        spk = torch.empty((T, B, desc.c_out, words), device=dev, dtype=torch.int32)
+        spk = torch.empty((T, B, desc.c_out, owords), device=dev, dtype=torch.int32)
     pv = out.get("pv") if want_pv else None
     if want_pv and pv is None:
-        pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
-    v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
+        pv = torch.empty((T, B, desc.c_out, ph, pw), device=dev, dtype=torch.float32)
+    _expect(spk, "spk_out", torch.int32, (T, B, desc.c_out, owords))
+    _expect(pv, "pv_out", torch.float32, (T, B, desc.c_out, ph, pw))
+    v = torch.empty((T, B, desc.c_out, ch, cw), device=dev, dtype=torch.float32) if want_v else None
     scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
     rc = _lib.get().dcll_conv_lif_sequence_cells(ctypes.byref(desc), ptr(cells), ptr(W), ptr(b), ptr(tau4),
                                                  ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v),

@@ -747,3 +747,77 @@ def test_readout_direct_forms(dev, rows, K, N):
         assert np.array_equal(part, outs[ops.READOUT_CORESIDENT][:2100])
         part = ops.readout(dpv[:2100].contiguous(), dW, db).cpu().numpy()
         assert np.array_equal(part, outs[ops.READOUT_AUTO][:2100])
+
+
+@pytest.mark.parametrize("cin,hw,wrp,T,B,zero_state", [(64, (16, 64), 1.0, 7, 2, False), (64, (16, 16), 1.0, 6, 3, False),
+                                                       (64, (16, 4), 0.0, 5, 3, True), (64, (16, 2), 1.0, 6, 5, False),
+                                                       (64, (4, 32), 1.0, 5, 3, False), (1, (16, 128), 1.0, 9, 2, False),
+                                                       (1, (2, 128), 0.0, 6, 3, True)])
+def test_sequence_w3_vs_oracle(dev, cin, hw, wrp, T, B, zero_state):
+    """k_lif_seq_w3 — the fused all-T kernel of the radio_ml_conv_ref.yaml geometry (64 channels, (1,3) kernel, pad
+    (0,1), max-pool (1,2); pixel tiles over the flattened plane, pooling pairs in lanes j / j+16) — == C oracle
+    stepping, bit for bit: un-pooled v, POOLED spikes (packed) and the final state; pooled pv within the sigmoid
+    tolerance.  Widths from 64 down to 2 (a tile = 1/2 ... 16 rows), ragged workgroups (B x tiles not a multiple of 8),
+    first layer from cell indices."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(31)
+    H, Wd = hw
+    cout, n = 64, cin * 3
+    stdv = 1.0 / np.sqrt(n) / 250
+    W = (rng.uniform(-stdv * 1e-2, stdv * 1e-2, size=(cout, cin, 1, 3)) * 3.0).astype(np.float32)
+    b = rng.uniform(-stdv, stdv, size=(cout,)).astype(np.float32)
+    taum, taus = rng.uniform(5, 35, size=cin) * 1e-3, rng.uniform(5, 10, size=cin) * 1e-3
+    alpha, alphas = (1 - 1e-3 / taum).astype(np.float32), (1 - 1e-3 / taus).astype(np.float32)
+    tau_m = (np.float32(1) / (np.float32(1) - alpha)).astype(np.float32)
+    tau_s = (np.float32(1) / (np.float32(1) - alphas)).astype(np.float32)
+    bc = lambda a: np.ascontiguousarray(np.broadcast_to(a[:, None, None], (cin,) + hw)).astype(np.float32)
+    K = cout * H * (Wd // 2)
+    sd = {"i2h.weight": W, "i2h.bias": b, "i2h.alpha": bc(alpha), "i2h.tau_m__dt": bc(tau_m), "i2h.alphas": bc(alphas),
+          "i2h.tau_s__dt": bc(tau_s), "i2o.weight": rng.uniform(-.005, .005, size=(24, K)).astype(np.float32),
+          "i2o.bias": np.zeros(24, np.float32)}
+    orc = C.OracleConvLayer(sd, hw, (0, 1), (1, 2), wrp)
+    orc.init_state(B)
+    if not zero_state:
+        orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape)
+        orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape)
+        if wrp > 0:
+            orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+    state = [cu(s_.copy(), dev) for s_ in orc.state]
+    eps0, eps1 = state[0], state[1]
+    arp = state[2] if wrp > 0 else None
+    d = ops.make_conv_desc(cin, cout, hw, (1, 3), (0, 1), (1, 2), 24, False, True, wrp)
+    assert ops.conv_out_shape(d) == (H, Wd, H, Wd // 2)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    want_spk = (H * Wd) % 64 == 0
+    if cin == 1:
+        cells = rng.randint(0, H * Wd, size=(T, B)).astype(np.int32)
+        cells[0, 0], cells[1, 0] = 0, H * Wd - 1
+        x = np.zeros((T, B, 1, H * Wd), np.float32)
+        x[np.arange(T)[:, None], np.arange(B)[None, :], 0, cells] = 1
+        spk, pv, v = ops.conv_lif_sequence_cells(d, cu(cells, dev), cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp, T, B,
+                                                 want_spikes=want_spk, want_v=True)
+    else:
+        x = (rng.uniform(size=(T, B, cin, H * Wd)) < 0.1).astype(np.float32)
+        x[0] = rng.uniform(size=(B, cin, H * Wd)) < 0.5
+        spk, pv, v = ops.conv_lif_sequence(d, ops.pack_spikes(cu(x, dev)), cu(W, dev), cu(b, dev), tau4, eps0, eps1, arp,
+                                           T, B, want_spikes=want_spk, want_v=True)
+    torch.cuda.synchronize()
+    assert v.shape == (T, B, cout, H, Wd) and pv.shape == (T, B, cout, H, Wd // 2)
+    v, pv = v.cpu().numpy(), pv.cpu().numpy()
+    if want_spk:
+        assert spk.shape == (T, B, cout, H * Wd // 64)
+        spk_d = ops.unpack_spikes(spk).cpu().numpy().reshape(T, B, cout, H, Wd // 2)
+    nspk = 0
+    for t in range(T):
+        oo, op, opv, ov, os_ = orc.forward(x[t].reshape(B, cin, H, Wd))
+        assert bits_equal(v[t], ov), (t, np.abs(v[t] - ov).max(), np.argwhere(v[t] != ov)[:5])
+        if want_spk:
+            assert np.array_equal(spk_d[t], os_), (t, np.argwhere(spk_d[t] != os_)[:5])
+        np.testing.assert_allclose(pv[t], opv, atol=PV_TOL, rtol=0)
+        nspk += os_.sum()
+    assert bits_equal(eps0.cpu().numpy(), orc.state[0])
+    assert bits_equal(eps1.cpu().numpy(), orc.state[1])
+    if wrp > 0:
+        assert bits_equal(arp.cpu().numpy(), orc.state[2])
+    assert 0.005 < nspk / (T * B * cout * H * Wd / 2) < 0.95, "degenerate test"
