@@ -56,14 +56,15 @@ def bench_ref_network(a):
     """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code, so
     parity is unpinned): radio_ml_conv_ref.yaml — 7 x (64 channels, (1,3) kernels, (1,2) pooling) — on a Q=16 x I=128 I/Q
     plane, per-output-channel int8 conv weights (dequantised for the kernels), T=128, batch `--batch` (default 256).
-    Runs the fused sequence path when the geometry has one, else the per-step path (one C-ABI call per layer and step on
-    device-built spike planes).  One JSON line like the headline benchmark (no CPU leg: the torch-CPU port needs ~1 s per
-    window here)."""
+    Runs the fused sequence path (k_lif_seq_w3 per layer) — or, for a geometry without one, the per-step path (one C-ABI
+    call per layer and step on device-built spike planes).  `--gpus N`: batch shards like the headline benchmark.  One
+    JSON line (no CPU leg: the torch-CPU port needs ~1 s per window here)."""
     from snn_modulation_classification_amd import ops, quant
-    assert a.gpus == 1, "--network ref is a single-GPU measurement"
-    dev = torch.device("cuda", 0)
+    rank, local_rank, world = parallel.init_process_group()
+    assert world == a.gpus, "torchrun --nproc-per-node must equal --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
+    dev = torch.device("cuda", parallel.local_device(local_rank))
     torch.cuda.set_device(dev)
-    H, W, B = 16, 128, (a.batch or 256)
+    H, W, B = 16, 128, (a.batch or 1024)          # windows per GPU (weak scaling: batch shards, no data-path collective)
     convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks",
                                            "radio_ml_conv_ref.yaml"))
     args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
@@ -73,40 +74,81 @@ def bench_ref_network(a):
                       learning_rates=None, burnin=20)
     net.reset(True)
     quant.apply_int8_weights(net)
+    # one pv buffer for the whole batch (33.5 MB per window: 137 GB at batch 4096 of the 288 GB): the narrow late layers
+    # have only B / 8 ... B workgroups, chunks of the default 24 GB budget (767 windows) would leave the chip half empty
+    net.pv_budget_bytes = float(os.environ.get("DCLL_PV_BUDGET_GB", "150")) * 2 ** 30
     enc = IQEncoder(W, H, device=dev)
-    iq = (0.4 * torch.randn(B, 2, L_IQ, generator=torch.Generator().manual_seed(1))).to(dev)
+    g = torch.Generator().manual_seed(1 + rank)
+    iq = (0.4 * torch.randn(B, 2, L_IQ, generator=g)).to(dev)
+    labels = torch.randint(0, N_CLASSES, (B,), generator=g).to(dev)
     fused = net.sequence_supported()
+
+    prof = {}
 
     def step():
         net.zero_states()
         net.reset()
         if fused:
-            return net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False)["vote"][-1]
+            res = net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False, profile=prof)
+            return parallel.allreduce_tallies(parallel.tallies(res["vote"], labels, N_CLASSES))
         cells = enc(iq, T_STEPS, t0=0)
         planes = ops.cells_to_planes(cells, H * W)
         for t in range(T_STEPS):
             net.test(planes[t].reshape(B, 1, H, W))
         return None
 
+    def fence():
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+
+    if world > 1:
+        parallel.all_reduce_(torch.zeros(1, device=dev))          # communicator up before the timed region
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize()
+    fence()
+    prof.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     flop = sum(2 * 64 * (1 if i == 0 else 64) * 3 * H * (W >> i) for i in range(7)) * T_STEPS * B
+    # dominant kernel: k_lif_seq_w3<64> (layers 1..6), HIP-event time of its launches on the launch stream
+    w3_ms = [s_.elapsed_time(e_) for s_, e_ in prof.get("lif_c32", [])]
+    flop_w3 = sum(2 * 64 * 64 * 3 * H * (W >> i) for i in range(1, 7)) * T_STEPS * B * a.steps
+    roof = None
+    if w3_ms:
+        ach = flop_w3 / (sum(w3_ms) / 1e3) / 1e12
+        roof = {"kernel": "k_lif_seq_w3<64> (six 64->64 layers; sum over their launches)", "bound": "mfma", "achieved": ach,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "launch_ms_per_step": sum(w3_ms) / a.steps, "launches_per_step": len(w3_ms) / a.steps}
+    kernel_ms = {k: float(np.sum([s_.elapsed_time(e_) for s_, e_ in v])) / a.steps for k, v in prof.items()}
+    if world > 1:
+        parallel.barrier()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
     print(json.dumps({
-        "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": B * a.steps / dt, "unit": "IQ windows/s", "n_gpus": 1,
+        "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": world * B * a.steps / dt, "unit": "IQ windows/s",
+        "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "radio_ml_conv_ref.yaml (7 x 64 ch, (1,3) kernels, (1,2) pooling), Q=16 x I=128 I/Q plane, "
                                "T=128, int8 per-channel conv weights (dequantised) + 1-bit packed spikes, batch %d, %s; "
                                "parity unpinned (no reference quantisation code)" %
                                (B, "fused sequence kernels" if fused else "per-step path (7 layer calls per timestep)"),
-                   "batch_per_gpu": B, "T": T_STEPS, "plane": [H, W], "path": "sequence" if fused else "per-step"},
-        "conv_tflops": flop * a.steps / dt / 1e12}))
+                   "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [H, W],
+                   "path": "sequence" if fused else "per-step",
+                   "parallelism": "batch shards, %d rank(s), tally all-reduce only" % world},
+        "roofline": roof, "kernel_ms_per_step": kernel_ms, "conv_tflops_per_gpu": flop * a.steps / dt / 1e12}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def log(msg):
@@ -194,13 +236,13 @@ def main():
     ap.add_argument("--network", default="radio", choices=["radio", "ref"],
                     help="radio = radio_ml_conv.yaml (headline); ref = radio_ml_conv_ref.yaml with int8 weights (config 5)")
     a = ap.parse_args()
-    if a.network == "ref":
-        return bench_ref_network(a)
     if a.gpus > 1 and not parallel.under_launcher():
         # started plainly (`python bench.py --gpus N`): this process becomes the launcher of N fresh rank processes and
         # never touches the GPU itself; rank 0's JSON line goes straight to our stdout.  Under torchrun the ranks
         # arrive here with RANK / WORLD_SIZE set and fall through.
         sys.exit(parallel.spawn_local_ranks(a.gpus))
+    if a.network == "ref":
+        return bench_ref_network(a)
     global R
     R = a.plane
     if a.batch is None:
