@@ -86,7 +86,7 @@ SIGNATURES = {
 def build(force=False):
     """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU).  `make` decides what is stale from
     its dependency rules (every source, dcll_internal.h, the ABI header, the Makefile itself); force=True rebuilds all."""
-    subprocess.check_call(["make", "-s", "-C", CSRC] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC] + (["-B"] if force else []))
     return SO_PATH
 
 

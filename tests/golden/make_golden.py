@@ -9,10 +9,11 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz, meta.json
     python tests/golden/make_golden.py --only-r32 # only the 32x32-plane rollout (added for the tiled kernels)
+    python tests/golden/make_golden.py --only-g9  # only the checkpoint fixture (added in round 2)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 one train_dcll step, G7 dense layer steps,
-G8 image2spiketrain (seeded).
+G8 image2spiketrain (seeded), G9 a reference-written .pth checkpoint and the reference's run after restoring it.
 """
 import json
 import os
@@ -393,9 +394,64 @@ def g8_image(du):
                         spikes=pack_bits(a.reshape(20, 3, -1)), target=np.asarray(tg))
 
 
+def g9_checkpoint(lib, nets, du):
+    """A checkpoint written by the reference's own protocol (train.py:300-303: torch.save(net.cpu().state_dict(), path))
+    and what the reference computes after restoring it the way test_radio_ml.py does (:104-110: load_state_dict, then
+    net.reset(True) — which re-draws the time constants, quirk Q4).  radio_ml_conv.yaml, netscale 0.25, 8x8 plane: the
+    .pth is data (parameter tensors), 0.2 MB."""
+    convs = nets.load_network_spec(os.path.join(REF, "networks", "radio_ml_conv.yaml"))
+    args = make_args(netscale=0.25)
+    B, R, T = 3, 8, 16
+    seed(21)
+    trained = nets.ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                               opt_param={}, learning_rates=None, burnin=2)
+    trained.reset(True)
+    path = os.path.join(OUT, "g9_reference_parameters.pth")
+    torch.save(trained.cpu().state_dict(), path)
+    seed(99)                                            # a differently initialised network, then restore
+    net = nets.ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                           opt_param={}, learning_rates=None, burnin=2)
+    net.load_state_dict(torch.load(path))
+    np.random.seed(7)
+    net.reset(True)
+    x = synth_iq(B, 128, 4)
+    labels = torch.randint(0, 24, (B,), generator=torch.Generator().manual_seed(5))
+    y1h = du.to_one_hot(labels, 24)
+    np.random.seed(8)
+    spikes, targets = du.iq2spiketrain(x, y1h, out_w=R, out_h=R, max_duration=T)
+    xin = torch.Tensor(spikes)
+    out = {"x": pack_bits(spikes.reshape(T, B, -1)), "labels": labels.numpy()}
+    pl = [[] for _ in net.dcll_slices]
+    ol = []
+    net.reset()
+    for t in range(T):
+        cur = xin[t]
+        for i, s in enumerate(net.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            pl[i].append(npy(p))
+            if s.dclllayer.output_layer:
+                ol.append(npy(o))
+            cur = o
+    for i in range(len(net.dcll_slices)):
+        out["p/%d" % i] = np.stack(pl[i])
+        out["clout/%d" % i] = np.array(net.dcll_slices[i].clout)
+        out.update(state_dict_np(net.dcll_slices[i].dclllayer, "sd_after_reset/%d/" % i))
+    out["o_last"] = np.stack(ol)
+    out["acc"] = np.array(net.accuracy(torch.Tensor(targets)))
+    np.savez_compressed(os.path.join(OUT, "g9_restored_run.npz"), **out)
+    return dict(B=B, R=R, T=T, netscale=0.25, burnin=2, np_seed_before_reset=7)
+
+
 def main():
     lib, nets, du = import_reference()
     torch.set_num_threads(1)        # pin the oneDNN reduction schedule used for the fixtures
+    if "--only-g9" in sys.argv:
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["g9"] = g9_checkpoint(lib, nets, du)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, default=lambda o: list(o))
+        return
     if "--only-r32" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -420,6 +476,7 @@ def main():
     g6_train_step(lib, nets, du)
     g7_dense(lib)
     g8_image(du)
+    meta["g9"] = g9_checkpoint(lib, nets, du)
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, default=lambda o: list(o))
     for fn in sorted(os.listdir(OUT)):

@@ -916,3 +916,46 @@ def test_ref_yaml_network_fused_sequence_equals_per_step_and_oracle():
         assert np.array_equal(ca[~tie], cb[~tie]), i
         assert a.iter == b.iter == T and np.array_equal(a._activity_rows(), b._activity_rows()) and len(a.activity_hist) == 1
     assert res["vote"][6].shape == (B,)
+
+
+def test_restoring_a_reference_written_checkpoint(golden):
+    """test_radio_ml.py's restore protocol (:104-110) on a .pth the REFERENCE wrote (fixture G9): load_state_dict ->
+    reset(True) -> T steps; the per-step path and the fused path reproduce the reference's own run after its restore:
+    per-step argmax and accuracy equal, logits within 1e-4."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    g = golden("g9_restored_run.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    B, R_, T = 3, 8, 16
+    x = torch.from_numpy(unpack_bits(g["x"], R_ * R_).reshape(T, B, 1, R_, R_)).cuda()
+    y = _one_hot_labels(g["labels"], T, 24)
+    for fused in (False, True):
+        torch.manual_seed(99)
+        np.random.seed(99)
+        net = ConvNetwork(_args(netscale=0.25), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                          opt_param={}, learning_rates=None, burnin=2)
+        net.load_state_dict(torch.load(os.path.join(ROOT, "tests", "golden", "g9_reference_parameters.pth")))
+        net = net.to('cuda')
+        np.random.seed(7)
+        net.reset(True)
+        net.reset()
+        if fused and net.sequence_supported():
+            cells = x.reshape(T, B, -1).argmax(-1).to(torch.int32)
+            res = net.test_sequence(cells)
+            logits = [l.cpu().numpy() for l in res["logits"]]
+            o_last = res["o"].cpu().numpy()
+        else:
+            logits, o_last = [[] for _ in range(3)], []
+            for t in range(T):
+                cur = x[t]
+                for i, s in enumerate(net.dcll_slices):
+                    o, p, pv, v = s.forward(cur, ignore_burnin=True)
+                    logits[i].append(p.cpu().numpy())
+                    if i == 2:
+                        o_last.append(o.cpu().numpy())
+                    cur = o
+            logits, o_last = [np.stack(l) for l in logits], np.stack(o_last)
+        for i in range(3):
+            np.testing.assert_allclose(logits[i], g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+            assert np.array_equal(np.asarray(net.dcll_slices[i].clout), g["clout/%d" % i]), (fused, i)
+        np.testing.assert_allclose(o_last, g["o_last"], atol=LOGIT_TOL, rtol=0)
+        assert np.allclose(net.accuracy(y), g["acc"])

@@ -437,3 +437,25 @@ def test_mnist_idx_reader(tmp_path):
     assert np.array_equal(xb.numpy(), imgs[:8].astype(np.float32) / 255.0) and np.array_equal(yb.numpy(), labs[:8])
     with pytest.raises(FileNotFoundError):
         get_mnist_loader(8, train=True, data_dir=str(tmp_path))
+
+
+def test_reference_written_checkpoint_loads(golden, cpu_device):
+    """A .pth written by the reference itself (torch.save(net.cpu().state_dict()), train.py:300-303; fixture G9) loads
+    strictly into this build's ConvNetwork — same keys, same shapes — and restoring + reset(True) with the same numpy seed
+    yields the state dict the reference had after ITS restore (time constants re-drawn, quirk Q4)."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    g = golden("g9_restored_run.npz")
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(99)
+    np.random.seed(99)
+    net = ConvNetwork(Namespace(netscale=0.25, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True),
+                      (1, 8, 8), 3, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
+                      learning_rates=None, burnin=2)
+    sd = torch.load(os.path.join(ROOT, "tests", "golden", "g9_reference_parameters.pth"))
+    assert sorted(sd.keys()) == sorted(net.state_dict().keys())
+    net.load_state_dict(sd)                              # strict
+    np.random.seed(7)
+    net.reset(True)
+    for i in range(3):
+        for k, v in g.sub("sd_after_reset/%d/" % i).items():
+            assert np.array_equal(net.state_dict()["dcll_slices.%d.dclllayer.%s" % (i, k)].numpy(), v), (i, k)
