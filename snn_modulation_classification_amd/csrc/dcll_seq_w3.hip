@@ -23,9 +23,12 @@
 #include "dcll_internal.h"
 
 constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
-constexpr int W3_CHS = 385;         // floats per channel image: 256 pixels + 256 / W shared pad columns + 1 <= 385 (W = 2)
+constexpr int W3_CHS = 388;         // floats per channel image: 256 pixels + 256 / W shared pad columns + 1 <= 385 (W = 2);
+                                    // = 4 mod 32: the 8 channels x 8 words of a wave's trace access spread over the banks
 
-template <int CIN, bool REFRACTORY, int OUT>     // OUT bit0: pooled pv, bit1: un-pooled v
+// WIDE: W >= 32 — a thread's 32 trace pixels lie in one row, their LDS offsets are immediates (for narrower planes every
+// element adds a wave-uniform row term: two more instructions per access)
+template <int CIN, bool REFRACTORY, int OUT, bool WIDE>     // OUT bit0: pooled pv, bit1: un-pooled v
 __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
                                                      const float *__restrict__ W, const float *__restrict__ bias,
                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
@@ -36,7 +39,14 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
 {
     constexpr int NK = CIN == 1 ? 2 : 96;               // MFMA k-steps of a chain
     constexpr int NE = CIN == 1 ? 1 : 32;               // trace elements per owning thread
-    __shared__ __attribute__((aligned(16))) float img[CIN * W3_CHS + 8];
+    // DB (wide 64-channel layers = 3/4 of the network's work): a channel image needs only 256 + 256/32 + 1 floats, so TWO
+    // images fit (2 x 74.8 KB), double-buffered by step parity: the traces of step t+1 are written into the other image
+    // right after a wave's own chains of step t — one barrier per step instead of two, and the waves of a SIMD drift apart
+    // (one in its trace / epilogue phase while the other issues MFMAs).
+    constexpr bool DB = WIDE && CIN == 64;
+    constexpr int CHS = DB ? 292 : W3_CHS;              // both = 4 mod 32 (bank spread of the trace accesses)
+    constexpr int IMG = CIN * CHS + 8;
+    __shared__ __attribute__((aligned(16))) float img[(DB ? 2 : 1) * IMG];
     __shared__ float sbias[64];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, jj = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,7 +55,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     const long ntot = (long)B * NTS;
     const long G0 = (long)blockIdx.x * W3_NT;            // first tile of this workgroup
 
-    for (int i = tid; i < CIN * W3_CHS + 8; i += 512) img[i] = 0.0f;
+    for (int i = tid; i < (DB ? 2 : 1) * IMG; i += 512) img[i] = 0.0f;
     if (tid < 64) sbias[tid] = bias[tid];
 
     // ---- trace ownership -------------------------------------------------------------------------------------------
@@ -62,13 +72,13 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // (for my 32 consecutive pixels 32 wq + i the row term splits into a per-thread part and a wave-uniform one:
     //  (32 wq + i) >> logW == ((32 wq) >> logW) + (i >> logW), W a power of two)
     const int p0 = CIN == 1 ? tid & (W3_PX - 1) : 32 * wq;
-    const int loff0 = ci_t * W3_CHS + p0 + 1 + (p0 >> logW);
+    const int loff0 = ci_t * CHS + p0 + 1 + (p0 >> logW);
     const long sbase = (bt * CIN + ci_t) * HW + 32L * mtile + (CIN == 1 ? (tid & 31) : 0);     // my first state element
     __syncthreads();                                     // image zeroed
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         e0[i] = tvalid ? eps0_g[sbase + i] : 0.0f;
-        if (tvalid) img[loff0 + i + (i >> logW)] = eps1_g[sbase + i];
+        if (tvalid) img[loff0 + i + (WIDE ? 0 : (i >> logW))] = eps1_g[sbase + i];
     }
 
     // ---- weights of my output-channel tile, stationary: A[co = 32 mt + jj][k] ----------------------------------------
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     const int mA = validA ? (int)(GA % NTS) : 0, mB = validB ? (int)((GA + 1) % NTS) : 0;
     const int pA = 64 * g + perm, pB = pA + 32;
     // B-fragment lane base: CIN = 64: channel h of the pair; CIN = 1: tap h of the pair (tap kx reads x + kx - 1)
-    const int baseA = (CIN == 1 ? h : h * W3_CHS) + pA + (pA >> logW), baseB = (CIN == 1 ? h : h * W3_CHS) + pB + (pB >> logW);
+    const int baseA = (CIN == 1 ? h : h * CHS) + pA + (pA >> logW), baseB = (CIN == 1 ? h : h * CHS) + pB + (pB >> logW);
     float arpA[16], arpB[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -104,30 +114,39 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     else if (tvalid) word = spk_in[(bt * CIN + ci_t) * NTS + mtile];
     const long in_step = (long)B * CIN * NTS;
 
-    for (int t = 0; t < T; ++t) {
-        // ---- (1) traces of step t (dcll/pytorch_libdcll.py:493-494, every op rounded separately); eight elements at a
-        //      time (all 32 in flight would hold 32 more registers on top of weights + accumulators + states) ----
-        {
-            const int pix0 = 32 * mtile + (CIN == 1 ? (tid & 31) : 0);          // my first pixel inside the sample plane
-            int lb = loff0, lw = logW;
-            // opaque per step: keeps the 32 element addresses (and their 32 wave-uniform row terms) out of loop-invariant
-            // registers — they are two instructions each to recompute
-            asm volatile("" : "+v"(lb), "+s"(lw));
+    // traces of one step (dcll/pytorch_libdcll.py:493-494, every op rounded separately): eps1 read from image `src`,
+    // written to image `dst` (float offsets; the same image when single-buffered); eight elements at a time (all 32 in
+    // flight would hold 32 more registers on top of weights + accumulators + states)
+    auto trace_step = [&](const uint32_t wd, const int cl, const int src, const int dst) {
+        const int pix0 = 32 * mtile + (CIN == 1 ? (tid & 31) : 0);          // my first pixel inside the sample plane
+        int lb = loff0, lw = logW;
+        // opaque per step: keeps the 32 element addresses (and their 32 wave-uniform row terms) out of loop-invariant
+        // registers — they are two instructions each to recompute
+        asm volatile("" : "+v"(lb), "+s"(lw));
 #pragma unroll
-            for (int i0 = 0; i0 < NE; i0 += 8) {
-                float e1[8];
+        for (int i0 = 0; i0 < NE; i0 += 8) {
+            float e1[8];
 #pragma unroll
-                for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[lb + i + (i >> lw)];
+            for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[src + lb + i + (WIDE ? 0 : (i >> lw))];
 #pragma unroll
-                for (int i = i0; i < i0 + 8 && i < NE; ++i) {
-                    const float x = CIN == 1 ? (cell == pix0 ? 1.0f : 0.0f) : (float)((word >> i) & 1u);
-                    trace_update(x, ta, tm, tas, ts, e0[i], e1[i - i0]);
-                    if (tvalid) img[lb + i + (i >> lw)] = e1[i - i0];
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = i0; i < i0 + 8 && i < NE; ++i) {
+                const float x = CIN == 1 ? (cl == pix0 ? 1.0f : 0.0f) : (float)((wd >> i) & 1u);
+                trace_update(x, ta, tm, tas, ts, e0[i], e1[i - i0]);
+                if (tvalid) img[dst + lb + i + (WIDE ? 0 : (i >> lw))] = e1[i - i0];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    if (DB) {               // step 0's traces in place in image 0, then the loop runs one barrier per step
+        trace_step(word, cell, 0, 0);
         lds_barrier();
+    }
+    for (int t = 0; t < T; ++t) {
+        const int cur = DB ? (t & 1) * IMG : 0;             // image the chains of this step read
+        if (!DB) {
+            trace_step(word, cell, 0, 0);
+            lds_barrier();
+        }
         // next step's input: lands during the chains
         if (t + 1 < T) {
             if (CIN == 1) cell = cells[(long)(t + 1) * B + bt];
@@ -142,18 +161,18 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
             if (CIN == 1) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0], img[base + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[NK - 1], img[base + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0], img[cur + base + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[NK - 1], img[cur + base + 2], acc, 0, 0, 0);
             } else {
                 // the 6 B fragments of channel pairs cp + 2, cp + 3 are fetched before the MFMAs of pairs cp, cp + 1
                 float bq[2][6];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) bq[0][q] = img[base + (q / 3) * 2 * W3_CHS + q % 3];
+                for (int q = 0; q < 6; ++q) bq[0][q] = img[cur + base + (q / 3) * 2 * CHS + q % 3];
 #pragma unroll
                 for (int c2 = 0; c2 < 16; ++c2) {
                     if (c2 + 1 < 16) {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) bq[(c2 + 1) & 1][q] = img[base + (2 * (c2 + 1) + q / 3) * 2 * W3_CHS + q % 3];
+                        for (int q = 0; q < 6; ++q) bq[(c2 + 1) & 1][q] = img[cur + base + (2 * (c2 + 1) + q / 3) * 2 * CHS + q % 3];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -165,32 +184,55 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
             // epilogue: refractory trace, threshold, sigmoid, (1,2) max-pool, pooled spike half-word.
             // stores as wave-uniform base (per value) + 32-bit lane offset: no 64-bit address VALU
             const long row = ((long)t * B + bb) * 64 + 32 * mt;
-            float *pvb = pv_out + row * HW2, *vb = v_out + row * HW;
-            unsigned lp = 4 * h * HW2 + 16 * mm + jj, lv = 4 * h * HW + 32 * mm + perm;       // + cr * HW2 / + cr * HW
-            int hw2 = HW2, hw1 = HW;
+            const char *pvb = (const char *)(pv_out + row * HW2), *vb = (const char *)(v_out + row * HW);
+            // lane BYTE offsets (+ cr * HW2 * 4 / + cr * HW * 4, wave-uniform, per value): the store takes SGPR base + VGPR
+            // offset as they are — no shift / add per store
+            unsigned lp = 4u * (4 * h * HW2 + 16 * mm + (jj & 15)), lv = 4u * (4 * h * HW + 32 * mm + perm);
+            int hw2 = 4 * HW2, hw1 = 4 * HW;
             // opaque per step: otherwise the per-value store addresses derived from them are hoisted out of the time loop
             asm volatile("" : "+v"(lp), "+v"(lv), "+s"(hw2), "+s"(hw1));
-            static_for<0, 16>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                constexpr int cr = (r & 3) + 8 * (r >> 2);              // + 32 mt + 4 h = output channel
-                float v = acc[r];
-                bool sp;
-                if (REFRACTORY) v = refractory(acc[r], arp[r], alpharp, wrp, sp);
-                else sp = v > 0.0f;
-                const unsigned long long mk = __ballot(sp);
-                // per half h: even pixels in bits 0..15, odd in 16..31 -> 16 pooled bits
-                const uint32_t a0 = (uint32_t)mk, a1 = (uint32_t)(mk >> 32);
-                const uint32_t w0 = (a0 & 0xffffu) | (a0 >> 16), w1 = (a1 & 0xffffu) | (a1 >> 16);
-                // (wait states as the compiler places them around its own v_writelane, see k_lif_seq_c1)
-                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
-                    : "+v"(vw) : "s"(w0), "s"(w1), "n"(r), "n"(32 + r));
+            // four values at a time: their ds_swizzles go out together and are waited for once
+            static_for<0, 4>([&](auto gc) {
+                constexpr int r0 = 4 * decltype(gc)::value;
+                float q[4], vv[4];
+                static_for<0, 4>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value, r = r0 + k;
+                    float v = acc[r];
+                    bool sp;
+                    if (REFRACTORY) v = refractory(acc[r], arp[r], alpharp, wrp, sp);
+                    else sp = v > 0.0f;
+                    const unsigned long long mk = __ballot(sp);
+                    // per half h: even pixels in bits 0..15, odd in 16..31 -> 16 pooled bits
+                    const uint32_t a0 = (uint32_t)mk, a1 = (uint32_t)(mk >> 32);
+                    const uint32_t w0 = (a0 & 0xffffu) | (a0 >> 16), w1 = (a1 & 0xffffu) | (a1 >> 16);
+                    // (wait states as the compiler places them around its own v_writelane, see k_lif_seq_c1)
+                    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
+                        : "+v"(vw) : "s"(w0), "s"(w1), "n"(r), "n"(32 + r));
+                    vv[k] = v;
+                    if (OUT & 1) q[k] = sigmoidf_dev(v);
+                });
                 if (OUT & 1) {
-                    const float q = sigmoidf_dev(v);
-                    const float o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(q), 0x401F));       // lane ^ 16
-                    if (jj < 16 && valid) (pvb + (long)cr * hw2)[lp] = fmaxf(q, o);
+                    float o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(q[k]), 0x401F));   // lane ^ 16
+                    if (valid) {
+                        // both lanes of a pooling pair hold the pair's maximum and store it to the same address: no lane
+                        // predicate, no exec-mask branch per value (sigmoid outputs are never NaN: plain v_max_f32)
+                        static_for<0, 4>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value, r = r0 + k, cr = (r & 3) + 8 * (r >> 2);
+                            float qm;
+                            asm("v_max_f32 %0, %1, %2" : "=v"(qm) : "v"(q[k]), "v"(o[k]));
+                            *(float *)(pvb + (long)cr * hw2 + lp) = qm;
+                        });
+                    }
                 }
-                if ((OUT & 2) && valid) (vb + (long)cr * hw1)[lv] = v;
-                __builtin_amdgcn_sched_barrier(0);      // one value at a time: keeps the temporaries few
+                if ((OUT & 2) && valid) {
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value, r = r0 + k, cr = (r & 3) + 8 * (r >> 2);
+                        *(float *)(vb + (long)cr * hw1 + lv) = vv[k];
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one group at a time: keeps the temporaries few
             });
         };
         do_tile(baseA, arpA, validA, bA, mA, vwA);
@@ -202,14 +244,16 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
             (spk_out + row * NW2)[(unsigned)((jj & 3) + 8 * (jj >> 2) + 4 * h) * (unsigned)NW2 + (unsigned)(mA >> 1)] =
                 (uint32_t)vwA | ((uint32_t)vwB << 16);
         }
+        if (DB && t + 1 < T) trace_step(word, cell, cur, cur ^ IMG);         // step t+1's traces into the other image
         lds_barrier();
     }
+    const int fin = DB ? ((T - 1) & 1) * IMG : 0;           // image holding eps1 of the last step
     // ---- state back to HBM ----
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         if (tvalid) {
             eps0_g[sbase + i] = e0[i];
-            eps1_g[sbase + i] = img[loff0 + i + (i >> logW)];
+            eps1_g[sbase + i] = img[fin + loff0 + i + (WIDE ? 0 : (i >> logW))];
         }
     }
     if (REFRACTORY) {
@@ -247,9 +291,11 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     const long nwg = (ntile + W3_NT - 1) / W3_NT;
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x tiles exceeds the grid limit");
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
+#define DCLL_LAUNCH_W3W(C, R, O, WD)                                                                                    \
+    hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, b, tau4,    \
+                       eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp)
 #define DCLL_LAUNCH_W3(C, R, O)                                                                                         \
-    hipLaunchKernelGGL((k_lif_seq_w3<C, R, O>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, b, tau4, eps0,   \
-                       eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp)
+    do { if (logW >= 5) DCLL_LAUNCH_W3W(C, R, O, true); else DCLL_LAUNCH_W3W(C, R, O, false); } while (0)
 #define DCLL_LAUNCH_W3O(C, R)                                                                                           \
     switch (out) {                                                                                                      \
     case 0: DCLL_LAUNCH_W3(C, R, 0); break;                                                                              \
@@ -264,6 +310,7 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     }
 #undef DCLL_LAUNCH_W3O
 #undef DCLL_LAUNCH_W3
+#undef DCLL_LAUNCH_W3W
     HIP_CHECK_LAUNCH("k_lif_seq_w3");
     return DCLL_OK;
 }
