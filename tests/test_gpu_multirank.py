@@ -97,3 +97,42 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 512
     assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out
     assert "cpu_baseline" not in out            # rank 0 at N = 1 only
+
+
+@pytest.mark.timeout(900)
+def test_entry_points_shard_over_ranks(tmp_path):
+    """`test_radio_ml.py --gpus 2` and `train.py --gpus 2` started plainly: each launches two ranks (sharing cuda:0 here,
+    gloo), shards every batch and reduces — the per-SNR accuracies and confusion matrices equal the single-process
+    evaluation exactly, the trained parameters equal the single-process training within the G6 tolerance."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    common = ["--I_resolution", "16", "--Q_resolution", "16", "--arp", "1.0", "--burnin", "4", "--batch_size_test", "24",
+              "--n_test_samples", "48", "--synthetic", "48", "--n_iters_test", "24", "--min_snr", "10", "--max_snr", "12"]
+    outs = {}
+    for n in (1, 2):
+        out = tmp_path / ("eval%d" % n)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "test_radio_ml.py"), "--gpus", str(n), "--out_dir", str(out)]
+                           + common, env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[n] = (np.load(out / "snr_evaluation_accs.npy"), np.load(out / "confusion_matrix_snr_10.npy"),
+                   [l for l in r.stdout.splitlines() if l.startswith("SNR")])
+    assert outs[1][0].shape == (2, 3) and np.array_equal(outs[1][0], outs[2][0])
+    assert np.array_equal(outs[1][1], outs[2][1]) and outs[1][1].sum() == 48
+    assert len(outs[2][2]) == 2                                   # rank 0 alone reports
+    params = {}
+    for n in (1, 2):
+        res = tmp_path / ("train%d" % n)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--gpus", str(n), "--output", str(res),
+                            "--batch_size", "24", "--n_steps", "2", "--n_iters", "12", "--n_test_interval", "1",
+                            "--learning_rates", "1e-7"] + common, env=env, capture_output=True, text=True, timeout=400,
+                           cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs = list((res / "RadioML").iterdir())
+        assert len(runs) == 1
+        params[n] = torch.load(runs[0] / "parameters_1.pth")
+    for k, v in params[1].items():
+        a, b = v.numpy(), params[2][k].numpy()
+        if "i2o" in k or "alpha" in k or "tau" in k:
+            assert np.array_equal(a, b), k
+        else:
+            np.testing.assert_allclose(b, a, rtol=0, atol=2e-3 * np.abs(a).max(), err_msg=k)
