@@ -4,6 +4,16 @@
 # kernel-trace statistics and the PMC passes are separate rocprofv3 runs (one counter group per pass); the summaries that
 # get committed are written under gpurun_out/r02prof_b$B/ and copied to profiles/ by hand.
 set -e
+if [ "$1" = "ref" ]; then
+    OUT=$PWD/gpurun_out/r02prof_ref
+    mkdir -p "$OUT"
+    export TMPDIR=/tmp
+    python3 bench.py --network ref --steps 3 --warmup 1 --batch 4096 > "$OUT/bench.json" 2> "$OUT/bench.err"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --network ref --steps 2 --warmup 1 --batch 4096 > /dev/null 2> "$OUT/trace.err"
+    find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+    rm -rf "$OUT/trace"
+    exit 0
+fi
 B=${1:-4096}
 OUT=$PWD/gpurun_out/r02prof_b$B
 mkdir -p "$OUT"
@@ -19,3 +29,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_B
 done
 python3 experiments/pmc_summary.py "$OUT/pmc.json" "$OUT/pmc1" "$OUT/pmc2" "$OUT/pmc3" "$OUT/pmc4" > "$OUT/pmc_summary.txt"
 rm -rf "$OUT"/pmc[1-4] "$OUT/trace"
+
+# BASELINE config 5 (radio_ml_conv_ref.yaml): bash profiles/collect_r02.sh ref   -> gpurun_out/r02prof_ref/
