@@ -959,3 +959,43 @@ def test_restoring_a_reference_written_checkpoint(golden):
             assert np.array_equal(np.asarray(net.dcll_slices[i].clout), g["clout/%d" % i]), (fused, i)
         np.testing.assert_allclose(o_last, g["o_last"], atol=LOGIT_TOL, rtol=0)
         assert np.allclose(net.accuracy(y), g["acc"])
+
+
+def test_train_dcll_with_regularisers_takes_the_autograd_path():
+    """DCLLBase.train_dcll(regularize > 0) (the reference's default argument, :690, :697-700): the regularisers reach pv
+    and pvmem directly, which the native step does not serve — the call runs the same HIP forward / backward inside the
+    autograd node with torch's loss modules and optimizer, and equals torch autograd through the CPU oracle ops."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from oracle import torch_ref as R
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    B, R_ = 4, 8
+    net = ConvNetwork(_args(netscale=0.25), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                      opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0}, learning_rates=[1e-7],
+                      burnin=1)
+    net.reset(True)
+    s0 = net.dcll_slices[0]
+    assert s0._native_learning() is not None
+    rng = np.random.RandomState(2)
+    x = torch.from_numpy((rng.uniform(size=(B, 1, R_, R_)) < 0.2).astype(np.float32)).cuda()
+    y = torch.zeros(B, 24)
+    y[np.arange(B), rng.randint(0, 24, size=B)] = 1
+    sd = {k: v.detach().cpu().clone() for k, v in s0.dclllayer.state_dict().items()}
+    w_before = s0.dclllayer.i2h.weight.detach().clone()
+    o, p, pv, v, loss = s0.train_dcll(x, y.cuda(), do_train=True, regularize=0.05)
+    assert loss.ndim == 0 and float(loss) > 0 and not torch.equal(w_before, s0.dclllayer.i2h.weight.detach())
+    # reference graph on the CPU oracle ops: same loss terms -> same gradient of i2h.weight
+    W = sd["i2h.weight"].clone().requires_grad_(True)
+    b = sd["i2h.bias"].clone().requires_grad_(True)
+    layer = R.RefConvLayer(dict(sd, **{"i2h.weight": W, "i2h.bias": b}), 3, 1, 1.0, 0.65, False)
+    layer.init_state(B, (R_, R_))
+    s_, pv_, v_, st = R.conv_lif_step(x.cpu(), W, b, layer.alpha, layer.tau_m, layer.alphas, layer.tau_s, layer.state,
+                                      layer.alpharp, layer.wrp, 1, layer.padding)
+    p_ = torch.nn.functional.linear(pv_.reshape(B, -1), sd["i2o.weight"], sd["i2o.bias"])
+    tgt_loss = torch.nn.SmoothL1Loss()(p_, y)
+    ref_loss = tgt_loss + 20.0 * 0.05 * torch.mean(torch.relu(v_ + 0.01)) + 0.1 * 0.05 * torch.relu(0.1 - torch.mean(pv_))
+    ref_loss.backward()
+    g = s0.dclllayer.i2h.weight.grad.cpu().numpy()
+    np.testing.assert_allclose(g, W.grad.numpy(), rtol=2e-3, atol=1e-6 * np.abs(W.grad.numpy()).max())
+    np.testing.assert_allclose(float(loss), float(tgt_loss.detach()), rtol=1e-4)      # the target loss is what is returned (:716)
