@@ -359,6 +359,23 @@ def main():
             "kernel_ms_per_launch": kernel_ms,
             "vote_accuracy_vs_random_labels": [float(x) for x in acc.cpu()],
         }
+        # the HBM-bound kernels around the hot one (north_star: achieved HBM GB/s of the LIF-update kernel against the
+        # roofline): bytes they must move by this design (pv written once by the first layer's kernel, read once by a
+        # readout GEMM; + packed spikes / logits), over their HIP-event time of this run
+        chunk_b = B * a.steps / max(1, len(prof.get("lif_c1", [])))         # windows per launch (chunked batches)
+        pv_bytes = T_STEPS * chunk_b * 32 * R * R * 4
+        hb = {}
+        if "lif_c1" in kernel_ms:
+            byt = pv_bytes * (1 + 1 / 32.0)                                   # pv + packed spikes out
+            hb["lif_c1 (k_lif_seq_c1 + pv statistics pass)"] = {
+                "bytes_per_launch": byt, "ms": kernel_ms["lif_c1"], "GBps": byt / kernel_ms["lif_c1"] / 1e6,
+                "frac_of_peak": byt / kernel_ms["lif_c1"] / 1e6 / PEAK_HBM_GBS,
+                "note": "bound by the shared matrix / vector pipe, not by this stream (DESIGN.md 4.2)"}
+        if "readout" in kernel_ms:
+            hb["readout (k_readout_t16, mean of the 24- and 48-row launches)"] = {
+                "bytes_per_launch": pv_bytes, "ms": kernel_ms["readout"], "GBps": pv_bytes / kernel_ms["readout"] / 1e6,
+                "frac_of_peak": pv_bytes / kernel_ms["readout"] / 1e6 / PEAK_HBM_GBS}
+        out["hbm_bound_kernels"] = hb
         if world == 1 and a.cpu_windows > 0:
             cells = enc(iq, T_STEPS, t0=0)          # the same quantisation as a separate kernel, for the CPU leg
             out["cpu_baseline"] = cpu_baseline(net, convs, cells.cpu(), res["vote"][-1].cpu().numpy(),

@@ -399,7 +399,9 @@ def test_committed_bench_lines_follow_the_contract():
     """The bench lines committed under profiles/ carry every field of the bench.py contract (metric, value, roofline of
     the dominant kernel, cpu_baseline) and are internally consistent."""
     import json
-    for name, kernel in (("r01_bench_b4096.json", "k_lif_seq_c32d"), ("r01_bench_plane128_b64.json", "k_lif_seq_c32t")):
+    for name, kernel in (("r01_bench_b4096.json", "k_lif_seq_c32d"), ("r01_bench_plane128_b64.json", "k_lif_seq_c32t"),
+                         ("r02_bench_b4096.json", "k_lif_seq_c32d"), ("r02_bench_b8192.json", "k_lif_seq_c32d"),
+                         ("r02_bench_plane128_b64.json", "k_lif_seq_c32t")):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                   "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
