@@ -247,7 +247,8 @@ int dcll_readout_mode(const float *pv, const float *Wt, const float *bias, float
 /*
  * The same readout for FEW rows (per-step calls: rows = batch): K is split into slices over the workgroups, the partial
  * tiles go to caller-provided scratch and are added in slice order (deterministic).  Served, with N <= 64 and 16-byte
- * aligned pv / Wt: K >= 65536, K % 4096 == 0 (large planes, K = c_out*128*128: slices of 4096), or rows <= 2048 with
+ * aligned pv / Wt: K >= 65536, K % 4096 == 0 (large planes, K = c_out*128*128: slices of 4096 for rows <= 2048, else 8
+ * slices — any row count), or rows <= 2048 with
  * 2048 <= K < 65536, K % 256 == 0 (the 16x16 plane, K = 8192: slices of 256);
  * scratch_floats >= dcll_readout_splitk_scratch(rows, K, N) (0 = this shape is not supported, use dcll_readout).
  */

@@ -1824,7 +1824,13 @@ __global__ __launch_bounds__(256) void k_readout_sum(const float *__restrict__ p
 static int splitk_slice(int64_t rows, int32_t K, int32_t N)
 {
     if (rows < 1 || N < 1 || N > 64) return 0;
-    if (K >= 65536 && K % 4096 == 0) return 4096;
+    if (K >= 65536 && K % 4096 == 0) {
+        // very long rows (large planes).  Few of them (per-step calls): 4096-column slices through k_readout_ks.  Many
+        // (the sequence path: rows = T*B, e.g. 8192 x 524288): 8 slices through k_readout_t16 — 8 x rows/128 workgroups with
+        // b128 LDS staging instead of rows/32 workgroups of k_readout_ks (3.2 TB/s there).  The slice count does not depend on
+        // the row count, so a row's logits do not depend on how a batch is chunked.
+        return rows <= 2048 ? 4096 : K / 8;
+    }
     if (rows <= 2048 && K >= 2048 && K < 65536 && K % 256 == 0) return 256;
     return 0;
 }
@@ -1849,7 +1855,7 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
         return fail(DCLL_ERR_INVALID, "dcll_readout_splitk: scratch too small (dcll_readout_splitk_scratch)");
     hipStream_t st = (hipStream_t)stream;
     const int nslice = K / ks;
-    if (ks == 256) {
+    if (ks != 4096) {
         int rc = dcll_launch_readout_t16(pv, Wt, nullptr, scratch, rows, K, N, ks, st);
         if (rc) return rc;
     } else {

@@ -444,32 +444,33 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ky][i], bp[ky * TRW + 2 * i], acc, 0, 0, 0);
-            uint32_t myword = 0;
+            int myword = 0;
             const long opix = (long)(y0 + m) * Wd + x0 + j;
             float *pvb = pv_out + obase * HW;                       // wave-uniform base of this step's pv planes
             const unsigned loff = 4 * h * (unsigned)HW + (unsigned)opix;   // 32 planes fit 32 bits (launcher check)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
                 const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = acc[r];
                 bool s;
                 if (REFRACTORY) v = refractory(acc[r], arp[tl][r], alpharp, wrp, s);
                 else s = v > 0.0f;
-                unsigned long long mk = __ballot(s);
-                uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-                myword = (j == r) ? mine : myword;
+                const unsigned long long mk = __ballot(s);
+                // the two spike words of register r parked in lanes r / 32 + r (see k_lif_seq_c1 for the wait states)
+                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
+                    : "+v"(myword) : "s"((uint32_t)mk), "s"((uint32_t)(mk >> 32)), "n"(r), "n"(32 + r));
                 if (FAST) {
                     (pvb + ((r & 3) + 8 * (r >> 2)) * HW)[loff] = sigmoidf_dev(v);
                 } else if (co < c_out) {
                     if (pv_out) pv_out[(obase + co) * HW + opix] = sigmoidf_dev(v);
                     if (v_out) v_out[(obase + co) * HW + opix] = v;
                 }
-            }
+            });
             const int cow = (j & 3) + 8 * (j >> 2) + 4 * h;
             if (FAST) {
-                if (j < 16) (spk_out + obase * words + (long)(y0 + m) * wpr + tx)[(unsigned)cow * (unsigned)words] = myword;
+                if (j < 16) (spk_out + obase * words + (long)(y0 + m) * wpr + tx)[(unsigned)cow * (unsigned)words] = (uint32_t)myword;
             } else if (spk_out && j < 16 && cow < c_out) {
-                spk_out[(obase + cow) * words + (long)(y0 + m) * wpr + tx] = myword;
+                spk_out[(obase + cow) * words + (long)(y0 + m) * wpr + tx] = (uint32_t)myword;
             }
         }
         lds_barrier();      // LDS-only: does not wait for this step's pv stores

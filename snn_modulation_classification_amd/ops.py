@@ -345,7 +345,7 @@ def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO, scratch=None):
         out = torch.empty((rows, N), device=pv2d.device, dtype=torch.float32)
     _expect(out, "out", torch.float32, (rows, N))
     lib = _lib.get()
-    need = lib.dcll_readout_splitk_scratch(rows, K, N) if (rows <= 2048 and mode == READOUT_AUTO) else 0
+    need = lib.dcll_readout_splitk_scratch(rows, K, N) if ((rows <= 2048 or K >= 65536) and mode == READOUT_AUTO) else 0
     if need > 0 and pv2d.data_ptr() % 16 == 0 and Wt.data_ptr() % 16 == 0:
         # few rows of a long K (per-step calls on a large plane): K split over the workgroups, partials in scratch
         area = None if scratch is None else scratch.get('splitk')

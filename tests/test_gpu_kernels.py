@@ -442,13 +442,14 @@ def test_readout_gemm_long_rows(dev, rows, K, N):
 
 
 @pytest.mark.parametrize("rows,K,N", [(64, 524288, 24), (5, 65536, 48), (700, 131072, 10), (512, 8192, 24), (37, 2048, 48),
-                                      (2048, 8192, 33)])
+                                      (2048, 8192, 33), (2300, 131072, 24)])
 def test_readout_few_rows_long_k(dev, rows, K, N):
     """dcll_readout_splitk (through ops.readout): few rows — the per-step readouts, rows = batch — with K split over the
     chip: 4096-column slices of a very long K (128x128 plane), 256-column slices on the 16x16 plane (K = 8192); partial
     tiles summed in slice order (run-to-run identical)."""
     from snn_modulation_classification_amd import ops, _lib
-    assert _lib.get().dcll_readout_splitk_scratch(rows, K, N) == (K // (4096 if K >= 65536 else 256)) * rows * N
+    assert _lib.get().dcll_readout_splitk_scratch(rows, K, N) == \
+        ((8 if rows > 2048 else K // 4096) if K >= 65536 else K // 256) * rows * N
     assert _lib.get().dcll_readout_splitk_scratch(rows, 8192 + 32, N) == 0
     assert _lib.get().dcll_readout_splitk_scratch(4096, 8192, N) == 0          # many rows: the plain GEMM
     rng = np.random.RandomState(4)
