@@ -1,0 +1,40 @@
+// Where does k_lif_step_c32 spend its time?  (diagnostic, not product)   ./ablate_step
+#include "../snn_modulation_classification_amd/csrc/dcll_hip.hip"
+#include <vector>
+template <int DBG>
+static float run(int B, float *x, float *W, float *bias, float *tau, float *e0, float *e1, float *arp, float *s, float *pv, float *v)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_lif_step_c32<true, DBG>), dim3(B), dim3(256), 0, 0, x, W, bias, tau, tau + 8192, tau + 2 * 8192, tau + 3 * 8192, 1, e0, e1, arp, s, pv, v, 0.65f, 1.0f);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    return best * 1e3f;
+}
+int main()
+{
+    const int BM = 4096;
+    size_t ns = (size_t)BM * 8192;
+    float *x, *W, *bias, *tau, *e0, *e1, *arp, *s, *pv, *v;
+    hipMalloc(&x, ns * 4); hipMalloc(&e0, ns * 4); hipMalloc(&e1, ns * 4); hipMalloc(&arp, ns * 4);
+    hipMalloc(&s, ns * 4); hipMalloc(&pv, ns * 4); hipMalloc(&v, ns * 4);
+    hipMemset(x, 0, ns * 4); hipMemset(e0, 0, ns * 4); hipMemset(e1, 0, ns * 4); hipMemset(arp, 0, ns * 4);
+    hipMalloc(&W, 32 * 32 * 49 * 4); hipMalloc(&bias, 128); hipMalloc(&tau, 4 * 8192 * 4);
+    std::vector<float> hw(32 * 32 * 49, 1e-6f), hb(32, 1e-4f), ht(4 * 8192, 0.9f);
+    hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(bias, hb.data(), 128, hipMemcpyHostToDevice); hipMemcpy(tau, ht.data(), ht.size() * 4, hipMemcpyHostToDevice);
+    printf("%6s %10s %10s %10s %10s %10s %10s   (us; ideal MFMA time at 157.3 TF)\n", "B", "full", "noMFMA", "noStores", "noState", "MFMAonly", "ideal");
+    for (int B : {64, 256, 512, 1024, 2048, 4096}) {
+        float f = run<0>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        float a = run<1>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        float c = run<2>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        float d = run<4>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        float e = run<6>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        printf("%6d %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f\n", B, f, a, c, d, e, 2.0 * 32 * 1568 * 256 * (double)B / 157.3e12 * 1e6);
+    }
+    return 0;
+}

@@ -143,6 +143,11 @@ typedef struct dcll_adam_tensor {
                                 /* optimizer2 of the output layer runs torch's default betas, :637-638)  */
 } dcll_adam_tensor;
 int dcll_adam_step(const dcll_adam_tensor *tensors, int32_t n_tensors, void *stream);
+/* The same update with the quantities that change from step to step read from DEVICE memory at execution time: dyn
+ * (n_tensors x 3 floats) = per tensor (lr, 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)); `lr` and `step` of the structs
+ * are ignored.  This is the form a captured hipGraph of a learning timestep replays (the host refreshes `dyn` with a
+ * stream-ordered copy before each replay). */
+int dcll_adam_step_dyn(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream);
 
 int dcll_cells_to_planes(const int32_t *cells, float *planes, int64_t n_samples, int32_t hw, void *stream);
 

@@ -1882,8 +1882,13 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
 // B fragments serves both tiles: 112 ds_read dwords per 98 MFMAs.  Input is the dense fp32 map x (any values, not
 // only {0,1}), outputs are the dense s / pv / v maps of dcll_conv_lif_step: no packing, no separate trace kernel.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int STEP_WCH = 49 * 64;       // floats per weight chunk: A fragments of one channel pair
-template <bool REFRACTORY>
+// floats per weight chunk (A fragments of one channel pair): 49 taps x 64 lanes, the taps STEP_WTS = 65 floats apart: a
+// wave of the copy-in writes one fragment lane of 64 consecutive TAPS (that is how the weights lie in global memory),
+// which at a stride of 64 floats would be 64 writes into one LDS bank — measured 1.4 us per chunk, during which the
+// operand reads of the MFMA stream wait (experiments/ablate_step.hip)
+constexpr int STEP_WTS = 65, STEP_WCH = 49 * STEP_WTS + 3;
+// DBG (experiments/ablate_step.hip only; 0 in the product): 1 no MFMAs, 2 no epilogue stores, 4 no state traffic
+template <bool REFRACTORY, int DBG = 0>
 __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ x, const float *__restrict__ W,
                                                        const float *__restrict__ bias, const float *__restrict__ alpha,
                                                        const float *__restrict__ tau_m, const float *__restrict__ alphas,
@@ -1901,7 +1906,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 
     for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
-    // weight chunk cp as A fragments: wch[tap*64 + hh*32 + co] = W[co][2cp+hh][tap]; in global memory the 98 floats of
+    // weight chunk cp as A fragments: wch[tap*STEP_WTS + hh*32 + co] = W[co][2cp+hh][tap]; in global memory the 98 floats of
     // (co, channel pair cp) are contiguous.  Thread t moves elements t, t+256, ... of the 32 x 98 block; the index
     // arithmetic is done once (inside the chunk loop it would be issued against the MFMA stream).
     constexpr int NW = 13;
@@ -1911,7 +1916,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     for (int i = 0; i < NW; ++i) {
         const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
         goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
-        loff[i] = (r % 49) * 64 + (r / 49) * 32 + co;
+        loff[i] = (r % 49) * STEP_WTS + (r / 49) * 32 + co;
     }
     auto fetch_w = [&](int cp) {
         const float *wc = W + cp * 98;          // wave-uniform base of the chunk
@@ -1923,28 +1928,59 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         for (int i = 0; i < NW; ++i)
             if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
     };
+    // traces of this step (dcll/pytorch_libdcll.py:493-494), state updated in HBM, eps1 -> image — one channel PAIR at a
+    // time (thread t owns pixel t of both channels): pair cp + 1 is fetched while the MFMAs of pair cp run and finished
+    // (trace arithmetic, state stores, image write) behind them, so that the 160 KB of state traffic per sample is spread
+    // over the MFMA phase instead of sitting in front of it (all workgroups of a launch start together: a separate
+    // prologue is an HBM-bound phase during which no matrix core works)
+    float tx[2], te0[2], te1[2], ta[2], ttm[2], tas[2], tts[2];
+    auto fetch_t = [&](int cp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = (2 * cp + i) * 256 + tid;
+            const long gidx = b * 8192 + e;
+            const int ti = tau_is_tensor ? e : 0;
+            if (DBG & 4) {
+                tx[i] = te0[i] = te1[i] = (float)tid;
+            } else {
+                tx[i] = x[gidx];
+                te0[i] = eps0_g[gidx];
+                te1[i] = eps1_g[gidx];
+            }
+            ta[i] = alpha[ti];
+            ttm[i] = tau_m[ti];
+            tas[i] = alphas[ti];
+            tts[i] = tau_s[ti];
+        }
+    };
+    auto finish_t = [&](int cp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = 2 * cp + i;
+            const long gidx = b * 8192 + c * 256 + tid;
+            trace_update(tx[i], ta[i], ttm[i], tas[i], tts[i], te0[i], te1[i]);
+            if (!(DBG & 4) || te0[i] == 12345.678f) {
+                eps0_g[gidx] = te0[i];
+                eps1_g[gidx] = te1[i];
+            }
+            img[c * CHF + ((tid >> 4) + 3) * ROWF + (tid & 15) + 3] = te1[i];
+        }
+    };
     fetch_w(0);
+    fetch_t(0);
     __syncthreads();        // image zeroed
-    // traces of this step (dcll/pytorch_libdcll.py:493-494): 32 elements per thread, state updated in HBM, eps1 -> image
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        const int e = tid + 256 * i, c = e >> 8, pix = e & 255;
-        const long gidx = b * 8192 + e;
-        const int ti = tau_is_tensor ? e : 0;
-        float e0 = eps0_g[gidx], e1 = eps1_g[gidx];
-        trace_update(x[gidx], alpha[ti], tau_m[ti], alphas[ti], tau_s[ti], e0, e1);
-        eps0_g[gidx] = e0;
-        eps1_g[gidx] = e1;
-        img[c * CHF + ((pix >> 4) + 3) * ROWF + (pix & 15) + 3] = e1;
-    }
+    finish_t(0);
     store_w(0);
-    __syncthreads();        // image, bias and chunk 0 in place
+    __syncthreads();        // channel pair 0 of the image, bias and chunk 0 in place
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
     const int bbase = h * CHF + ((j >> 4) + 4 * w) * ROWF + (j & 15);
     for (int cp = 0; cp < 16; ++cp) {
-        if (cp + 1 < 16) fetch_w(cp + 1);                  // lands during the MFMAs below
+        if (cp + 1 < 16) {                                 // land during the MFMAs below
+            fetch_w(cp + 1);
+            fetch_t(cp + 1);
+        }
         const float *wa = wch + (cp & 1) * STEP_WCH + lane;
         const float *ib = img + bbase + cp * 2 * CHF;
         // LDS rows rho = 0..8 below the pair's first image row: row rho is tap row ky = rho of tile A (rho <= 6) and
@@ -1958,15 +1994,23 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             for (int kx = 0; kx < 7; ++kx) bq[kx] = ib[rho * ROWF + kx];
             if (rho <= 6) {
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[(rho * 7 + kx) * 64];
+                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[(rho * 7 + kx) * STEP_WTS];
             }
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
+                if (DBG & 1) {
+                    if (rho <= 6) accA[kx] += wr[rho % 3][kx] * bq[kx];
+                    if (rho >= 2) accB[kx] += wr[(rho - 2) % 3][kx] * bq[kx];
+                    continue;
+                }
                 if (rho <= 6) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[rho % 3][kx], bq[kx], accA, 0, 0, 0);
                 if (rho >= 2) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[(rho - 2) % 3][kx], bq[kx], accB, 0, 0, 0);
             }
         }
-        if (cp + 1 < 16) store_w((cp + 1) & 1);            // the other buffer: nobody reads it in this iteration
+        if (cp + 1 < 16) {
+            store_w((cp + 1) & 1);                         // the other buffer: nobody reads it in this iteration
+            finish_t(cp + 1);                              // image channels nobody reads in this iteration
+        }
         __syncthreads();
     }
     // epilogue of my two tiles: channel (r&3) + 8(r>>2) + 4h, pixel 32(2w + tl) + j
@@ -1980,12 +2024,13 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             float v = pvm;
             bool s;
             if (REFRACTORY) {
-                float ar = arp_g[o];
+                float ar = (DBG & 2) ? 0.0f : arp_g[o];
                 v = refractory(pvm, ar, alpharp, wrp, s);
-                arp_g[o] = ar;
+                if (!(DBG & 2) || ar == 12345.678f) arp_g[o] = ar;
             } else {
                 s = v > 0.0f;
             }
+            if ((DBG & 2) && v != 12345.678f) continue;
             out_s[o] = s ? 1.0f : 0.0f;
             out_pv[o] = sigmoidf_dev(v);
             if (out_v) out_v[o] = v;

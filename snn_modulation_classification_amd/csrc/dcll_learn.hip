@@ -96,6 +96,7 @@ struct adam_args {
     dcll_adam_tensor t[DCLL_ADAM_MAX_TENSORS];
     long first[DCLL_ADAM_MAX_TENSORS + 1];      // prefix sums of n, in 256-element blocks
     float inv_bc1[DCLL_ADAM_MAX_TENSORS], inv_sqrt_bc2[DCLL_ADAM_MAX_TENSORS];
+    const float *dyn;                           // optional, DEVICE: per tensor (lr, 1/bc1, 1/sqrt(bc2)) — see dcll_adam_step_dyn
     int n_tensors;
 };
 
@@ -112,19 +113,35 @@ __global__ __launch_bounds__(256) void k_adam_multi(adam_args a)
     const float w = 1.0f - t.beta1;
     m = w < 0.5f ? m + w * (g - m) : g - (g - m) * (1.0f - w);                 // torch's lerp
     v = v * t.beta2 + ((1.0f - t.beta2) * g) * g;
-    const float denom = sqrtf(v) * a.inv_sqrt_bc2[k] + t.eps;
-    p = p - (t.lr * a.inv_bc1[k]) * (m / denom);
+    const float lr = a.dyn ? a.dyn[3 * k] : t.lr;
+    const float ibc1 = a.dyn ? a.dyn[3 * k + 1] : a.inv_bc1[k], isbc2 = a.dyn ? a.dyn[3 * k + 2] : a.inv_sqrt_bc2[k];
+    const float denom = sqrtf(v) * isbc2 + t.eps;
+    p = p - (lr * ibc1) * (m / denom);
     t.exp_avg[i] = m;
     t.exp_avg_sq[i] = v;
     t.param[i] = p;
 }
 
+static int adam_launch(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream);
+
 extern "C" int dcll_adam_step(const dcll_adam_tensor *tensors, int32_t n_tensors, void *stream)
+{
+    return adam_launch(tensors, n_tensors, nullptr, stream);
+}
+
+extern "C" int dcll_adam_step_dyn(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream)
+{
+    if (n_tensors > 0 && !dyn) return fail(DCLL_ERR_INVALID, "dcll_adam_step_dyn: null dyn");
+    return adam_launch(tensors, n_tensors, dyn, stream);
+}
+
+static int adam_launch(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream)
 {
     if (n_tensors == 0) return DCLL_OK;
     if (!tensors || n_tensors < 0 || n_tensors > DCLL_ADAM_MAX_TENSORS)
         return fail(DCLL_ERR_INVALID, "dcll_adam_step: bad argument (1..8 tensors)");
     adam_args a;
+    a.dyn = dyn;
     long blocks = 0;
     for (int k = 0; k < n_tensors; ++k) {
         if (!tensors[k].param || !tensors[k].grad || !tensors[k].exp_avg || !tensors[k].exp_avg_sq || tensors[k].n < 0 ||

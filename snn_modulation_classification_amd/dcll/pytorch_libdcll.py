@@ -109,6 +109,17 @@ class ContinuousConv2D(nn.Module):
     # -- parameters ---------------------------------------------------------------------------------------------
     def _set_tau(self, alpha, alphas):
         """alpha -> tau/dt = 1/(1-alpha) in fp32, as Parameters without grad (reference :349-356, :398-405)."""
+        old = [getattr(self, n, None) for n in ('alpha', 'tau_m__dt', 'alphas', 'tau_s__dt')]
+        if all(isinstance(t, nn.Parameter) for t in old) and old[0].shape == alpha.shape and \
+                old[2].shape == alphas.shape and old[0].device == alpha.device and old[2].device == alphas.device:
+            # same geometry (the refractory variant re-draws on every init_state): overwrite in place, so that the device
+            # addresses a captured learning step has baked in stay valid
+            with torch.no_grad():
+                self.alpha.copy_(alpha)
+                self.tau_m__dt.copy_(1. / (1 - self.alpha))
+                self.alphas.copy_(alphas)
+                self.tau_s__dt.copy_(1. / (1 - self.alphas))
+            return
         self.alpha = nn.Parameter(alpha, requires_grad=False)
         self.tau_m__dt = nn.Parameter(1. / (1 - self.alpha), requires_grad=False)
         self.alphas = nn.Parameter(alphas, requires_grad=False)
@@ -138,10 +149,23 @@ class ContinuousConv2D(nn.Module):
         return h, w
 
     # -- state --------------------------------------------------------------------------------------------------
-    def _alloc_state(self, batch_size, im_dims, init_value):
+    def _state_tensors(self, shapes, init_values):
+        """Neuron state tensors of the given shapes filled with init_values: the existing ones re-filled in place when
+        the geometry is unchanged (the per-batch reset of train.py; keeps the addresses a captured learning step has
+        baked in), new ones otherwise."""
         dev = self.weight.device
+        old = getattr(self, 'state', None)
+        if old is not None and len(old) == len(shapes) and all(
+                tuple(t.shape) == tuple(sh) and t.device == dev and t.dtype == torch.float32
+                for t, sh in zip(old, shapes)):
+            for t, val in zip(old, init_values):
+                t.fill_(val)
+            return list(old)
+        return [torch.zeros(tuple(sh), device=dev) + val for sh, val in zip(shapes, init_values)]
+
+    def _alloc_state(self, batch_size, im_dims, init_value):
         shape = (batch_size, self.in_channels, im_dims[0], im_dims[1])
-        return [torch.zeros(shape, device=dev) + init_value, torch.zeros(shape, device=dev) + init_value]
+        return self._state_tensors([shape, shape], [init_value, init_value])
 
     def init_state(self, batch_size, im_dims, init_value=0):
         self.state = self.NeuronState(*self._alloc_state(batch_size, im_dims, init_value))
@@ -257,8 +281,8 @@ class ContinuousRelativeRefractoryConv2D(ContinuousConv2D):
 
     def init_state(self, batch_size, im_dims, init_value=0):
         oh, ow = self.get_output_shape(im_dims)
-        st = self._alloc_state(batch_size, im_dims, init_value)
-        st.append(torch.zeros((batch_size, self.out_channels, oh, ow), device=self.weight.device))
+        shape = (batch_size, self.in_channels, im_dims[0], im_dims[1])
+        st = self._state_tensors([shape, shape, (batch_size, self.out_channels, oh, ow)], [init_value, init_value, 0])
         self.state = self.NeuronState(*st)
         if self.random_tau:
             # observable quirk: this variant never clears the flag, so EVERY init_state re-draws the
@@ -743,10 +767,12 @@ class DCLLBase(nn.Module):
         self._native_kind = kind
         return kind
 
-    def _learn_forward_backward(self, input, target, want_loss=True):
+    def _learn_forward_backward(self, input, target, want_loss=True, clout_out=None):
         """Forward of one step plus — once iter >= burnin (reference :691) — the gradients of the local loss(es) in the
         .grad of i2h.weight / i2h.bias (and output_.weight / output_.bias): dcll_conv_lif_step -> dcll_local_loss_grad
         -> dcll_conv_lif_backward, all on preallocated buffers.  No optimizer step.
+        clout_out: write the recorded argmax there instead of appending a fresh tensor to clout (graph capture: the
+        caller copies it out after each replay).
         -> (output, pvoutput, pv, pvmem, loss (1,) device tensor or None, learned)"""
         L = self.dclllayer
         i2h = L.i2h
@@ -761,9 +787,9 @@ class DCLLBase(nn.Module):
                 # (DCLLClassification records the per-step argmax once the burn-in is over, :724-728: same kernel)
                 rec = isinstance(self, DCLLClassification)
                 res = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(), out=bufs,
-                                          want_loss=want_loss, want_clout=rec)
+                                          want_loss=want_loss, want_clout=rec, clout_out=clout_out)
                 g_p, g_o, loss = res[:3]
-                if rec:
+                if rec and clout_out is None:
                     self._clout.append(res[3])
                 prm = [i2h.weight, i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
                 for q in prm:
@@ -785,9 +811,10 @@ class DCLLBase(nn.Module):
         prm = [L.i2h.weight, L.i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
         return [q.grad for q in prm]
 
-    def _adam_tensors(self):
+    def _adam_tensors(self, advance=True):
         """This slice's parameters as dcll_adam_step entries, on the state tensors of its torch optimizer objects (created
-        here, in torch's own layout, on first use): optimizer.state_dict() stays loadable by torch.optim.Adam."""
+        here, in torch's own layout, on first use): optimizer.state_dict() stays loadable by torch.optim.Adam.
+        advance: count this call as an update (state['step'] += 1); False only describes the tensors."""
         out = []
         opts = [self.optimizer] + ([self.optimizer2] if self.dclllayer.output_layer else [])
         for opt in opts:
@@ -800,10 +827,11 @@ class DCLLBase(nn.Module):
                         st['step'] = torch.tensor(0.0)
                         st['exp_avg'] = torch.zeros_like(q, memory_format=torch.preserve_format)
                         st['exp_avg_sq'] = torch.zeros_like(q, memory_format=torch.preserve_format)
-                    st['step'] += 1
+                    if advance:
+                        st['step'] += 1
                     out.append(dict(param=q.data, grad=q.grad, exp_avg=st['exp_avg'], exp_avg_sq=st['exp_avg_sq'],
                                     lr=g['lr'], weight_decay=g['weight_decay'], beta1=g['betas'][0], beta2=g['betas'][1],
-                                    eps=g['eps'], step=int(st['step'])))
+                                    eps=g['eps'], step=max(1, int(st['step']))))
         return out
 
     def train_dcll(self, input, target, do_train=True, regularize=0.05):

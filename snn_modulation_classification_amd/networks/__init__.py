@@ -62,6 +62,9 @@ class ConvNetwork(torch.nn.Module):
                                               optimizer=opt, kwargs_optimizer=layer_opt, collect_stats=True,
                                               burnin=burnin))
         self._seq_buffers = {}
+        # captured learning timesteps (hipGraph), per input shape; see _learn_graphed
+        self.graph_learn = os.environ.get('DCLL_GRAPH_LEARN', '1') != '0'
+        self._learn_graphs, self._learn_eager_steps, self._learn_last_key = {}, {}, None
         # largest pv buffer (one layer, all T steps) the sequence path allocates; bigger batches run in chunks
         self.pv_budget_bytes = float(os.environ.get('DCLL_PV_BUDGET_GB', '24')) * 2 ** 30
 
@@ -76,6 +79,11 @@ class ConvNetwork(torch.nn.Module):
             for s in self.dcll_slices:
                 spikes, _, _, _, _ = s.train_dcll(spikes, labels, regularize=False)
             return
+        key = (tuple(x.shape), tuple(labels.shape))
+        if key != self._learn_last_key:                # another geometry: the slices' buffers are reallocated
+            self._learn_last_key, self._learn_eager_steps[key] = key, 0
+        if self._graph_learn_ok(x, labels, key) and self._learn_graphed(x, labels, key):
+            return
         spikes, learned = x, []
         for s in self.dcll_slices:
             spikes, _, _, _, _, l = s._learn_forward_backward(spikes, labels, want_loss=False)   # nobody reads the value
@@ -85,6 +93,111 @@ class ConvNetwork(torch.nn.Module):
             from .. import parallel
             parallel.allreduce_mean_tensors([g for s in learned for g in s._grad_tensors()], local_n=x.shape[0])
             ops.adam_step([t for s in learned for t in s._adam_tensors()])
+            if len(learned) == len(self.dcll_slices):
+                self._learn_eager_steps[key] = self._learn_eager_steps.get(key, 0) + 1
+
+    # -- the learning timestep as a captured hipGraph ------------------------------------------------------------------
+    # At the reference's small batches (argparse default 64) a learning timestep is ~25 kernel launches of a few
+    # microseconds each: the host's launch path, not the GPU, sets the pace (0.50 ms per timestep at B = 64..256).  The
+    # launches of a step in which EVERY slice learns are the same from step to step except for Adam's step-dependent
+    # scalars, so they are captured once (torch.cuda.CUDAGraph = hipGraph) on static input buffers and replayed: the
+    # step-dependent scalars are read on the device (dcll_adam_step_dyn), refreshed from the host before each replay.
+    _DYN_RING = 32
+
+    def _graph_learn_ok(self, x, labels, key):
+        if not (self.graph_learn and x.is_cuda and x.dtype == torch.float32 and labels.dtype == torch.float32):
+            return False
+        if self._learn_eager_steps.get(key, 0) < 2:            # buffers, .grad and Adam state exist after eager steps
+            return False
+        from .. import parallel
+        if parallel.is_distributed():                          # the gradient bucket's collective stays outside graphs
+            return False
+        for s in self.dcll_slices:
+            it = s.iter + 1
+            if it < s.burnin or (s.collect_stats and it % 20 == 0):      # burn-in and histogram steps run eagerly
+                return False
+        return True
+
+    def _graph_signature(self):
+        """Everything a captured step has baked in: addresses of state, parameters, gradients and optimizer state, and
+        the hyper-parameters that are kernel arguments.  (lr and the step count are read on the device.)"""
+        sig = []
+
+        def walk(d):
+            for v in d.values():
+                if isinstance(v, dict):
+                    walk(v)
+                elif isinstance(v, torch.Tensor):
+                    sig.append(v.data_ptr())
+        for s in self.dcll_slices:
+            L = s.dclllayer
+            sig += [t.data_ptr() for t in L.i2h.state]
+            sig += [t.data_ptr() for t in (L.i2h.alpha, L.i2h.tau_m__dt, L.i2h.alphas, L.i2h.tau_s__dt, L.i2o.weight,
+                                           L.i2o.bias)]
+            walk(s.__dict__.get('_learn_bufs', {}))
+            for t in s._adam_tensors(advance=False):
+                sig += [t['param'].data_ptr(), t['grad'].data_ptr(), t['exp_avg'].data_ptr(),
+                        t['exp_avg_sq'].data_ptr(), t['weight_decay'], t['beta1'], t['beta2'], t['eps']]
+        return tuple(sig)
+
+    @torch.no_grad()
+    def _learn_graphed(self, x, labels, key):
+        """One learning timestep by replaying its captured graph -> True; False (nothing done) when the capture on
+        record no longer matches the tensors in use — the caller then runs eager steps, after which a new one is taken."""
+        sig = self._graph_signature()
+        g = self._learn_graphs.get(key)
+        if g is not None and g['sig'] != sig:
+            del self._learn_graphs[key]
+            self._learn_eager_steps[key] = 0
+            return False
+        if g is None:
+            g = self._learn_graphs[key] = self._capture_learn(x, labels, sig)
+        g['x'].copy_(x)
+        g['y'].copy_(labels)
+        tensors = [t for s in self.dcll_slices for t in s._adam_tensors()]            # counts the update
+        slot = g['n'] % self._DYN_RING
+        g['n'] += 1
+        if g['events'][slot] is not None:
+            g['events'][slot].synchronize()                     # the copy that last read this pinned row is done
+        else:
+            g['events'][slot] = torch.cuda.Event()
+        g['dyn_host_np'][slot, :] = ops.adam_dyn_values(tensors)
+        g['dyn'].copy_(g['dyn_host'][slot], non_blocking=True)
+        g['events'][slot].record()
+        g['graph'].replay()
+        rec = g['clout'].clone()
+        for i, s in enumerate(self.dcll_slices):
+            s.iter += 1
+            if g['records'][i]:
+                s._clout.append(rec[i])
+        return True
+
+    def _capture_learn(self, x, labels, sig):
+        from ..dcll.pytorch_libdcll import DCLLClassification
+        n_t = sum(len(s._adam_tensors(advance=False)) for s in self.dcll_slices)
+        dev = x.device
+        g = dict(sig=sig, n=0, x=torch.empty_like(x), y=torch.empty_like(labels),
+                 clout=torch.zeros((self.num_layers, x.shape[0]), device=dev, dtype=torch.int32),
+                 dyn=torch.zeros(3 * n_t, device=dev), dyn_host=torch.zeros((self._DYN_RING, 3 * n_t)).pin_memory(),
+                 events=[None] * self._DYN_RING,
+                 records=[isinstance(s, DCLLClassification) for s in self.dcll_slices])
+        g['dyn_host_np'] = g['dyn_host'].numpy()
+        iters = [s.iter for s in self.dcll_slices]
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        try:
+            with torch.cuda.graph(graph):
+                spikes = g['x']
+                for i, s in enumerate(self.dcll_slices):
+                    spikes, _, _, _, _, l = s._learn_forward_backward(spikes, g['y'], want_loss=False,
+                                                                     clout_out=g['clout'][i])
+                    assert l
+                ops.adam_step([t for s in self.dcll_slices for t in s._adam_tensors(advance=False)], dyn=g['dyn'])
+        finally:
+            for s, it in zip(self.dcll_slices, iters):         # capturing records the launches, it runs nothing
+                s.iter = it
+        g['graph'] = graph
+        return g
 
     @torch.no_grad()
     def learn_sequence(self, cells, labels):

@@ -3,7 +3,9 @@
 PyTorch is only the owner of device memory and streams here; all arithmetic happens in libdcll_hip.so.
 """
 import ctypes
+import math
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -409,10 +411,10 @@ def pack_spikes(dense):
 LOSS_KINDS = {"SmoothL1Loss": _lib.LOSS_SMOOTH_L1, "MSELoss": _lib.LOSS_MSE}
 
 
-def local_loss_grad(p, o, target, kind, out=None, want_loss=True, want_clout=False):
+def local_loss_grad(p, o, target, kind, out=None, want_loss=True, want_clout=False, clout_out=None):
     """Gradient and value of the local losses with mean reduction (dcll_local_loss_grad): crit(p, target) [+
     crit(o, target)] -> (g_p, g_o or None, loss (1,) or None[, clout (B) int32 = argmax of o, or of p without o]).
-    kind: LOSS_KINDS[...]."""
+    kind: LOSS_KINDS[...].  clout_out: where to write the argmax (else a fresh tensor, which the caller keeps)."""
     out = {} if out is None else out
     B, N = p.shape
     _expect(p, "p", torch.float32)
@@ -427,7 +429,10 @@ def local_loss_grad(p, o, target, kind, out=None, want_loss=True, want_clout=Fal
             t = out[key] = torch.empty(shape, device=p.device, dtype=torch.float32)
         return t
     g_p, g_o, loss = buf('g_p', (B, N)), buf('g_o', (B, N), o is not None), buf('loss', (1,), want_loss)
-    clout = torch.empty((B,), device=p.device, dtype=torch.int32) if want_clout else None   # kept by the caller: fresh
+    clout = None
+    if want_clout:
+        clout = torch.empty((B,), device=p.device, dtype=torch.int32) if clout_out is None else clout_out
+        _expect(clout, "clout", torch.int32, (B,))
     check(_lib.get().dcll_local_loss_grad(ptr(p.contiguous()), ptr(None if o is None else o.contiguous()),
                                           ptr(target.contiguous()), ptr(g_p), ptr(g_o), ptr(loss), ptr(clout), B, N,
                                           int(kind), stream_ptr()), "dcll_local_loss_grad")
@@ -436,11 +441,25 @@ def local_loss_grad(p, o, target, kind, out=None, want_loss=True, want_clout=Fal
     return g_p, g_o, loss
 
 
-def adam_step(tensors):
+def adam_dyn_values(tensors):
+    """Per tensor (lr, 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)) as a flat float list — the `dyn` of adam_step,
+    computed exactly as dcll_adam_step does on the host (float64 arithmetic on the float32 betas of the struct)."""
+    out = []
+    for t in tensors:
+        b1, b2, step = float(np.float32(t["beta1"])), float(np.float32(t["beta2"])), int(t["step"])
+        out += [float(t["lr"]), 1.0 / (1.0 - math.pow(b1, step)), 1.0 / math.sqrt(1.0 - math.pow(b2, step))]
+    return out
+
+
+def adam_step(tensors, dyn=None):
     """torch.optim.Adam's update over several tensors — of one or several optimizers — in one launch (dcll_adam_step).
     tensors: list of dicts with param, grad, exp_avg, exp_avg_sq (tensors) and lr, weight_decay, beta1, beta2, eps, step
-    (1-based count of this update).  More than 8 tensors are split into several launches."""
+    (1-based count of this update).  More than 8 tensors are split into several launches.
+    dyn: optional device tensor (3 floats per tensor, adam_dyn_values): lr and the bias corrections are then read on the
+    device at execution time (dcll_adam_step_dyn) — the form that can be captured in a graph and replayed."""
     lib = _lib.get()
+    if dyn is not None:
+        _expect(dyn, "dyn", torch.float32, numel=3 * len(tensors))
     for k0 in range(0, len(tensors), _lib.ADAM_MAX_TENSORS):
         part = tensors[k0:k0 + _lib.ADAM_MAX_TENSORS]
         arr = (_lib.AdamTensor * len(part))()
@@ -455,7 +474,11 @@ def adam_step(tensors):
             a.n, a.step = prm.numel(), int(t["step"])
             a.lr, a.weight_decay = float(t["lr"]), float(t["weight_decay"])
             a.beta1, a.beta2, a.eps = float(t["beta1"]), float(t["beta2"]), float(t["eps"])
-        check(lib.dcll_adam_step(arr, len(part), stream_ptr()), "dcll_adam_step")
+        if dyn is not None:
+            check(lib.dcll_adam_step_dyn(arr, len(part), ptr(dyn[3 * k0:3 * (k0 + len(part))]), stream_ptr()),
+                  "dcll_adam_step_dyn")
+        else:
+            check(lib.dcll_adam_step(arr, len(part), stream_ptr()), "dcll_adam_step")
 
 
 def cells_to_planes(cells, hw):

@@ -816,6 +816,65 @@ def test_learn_sequence_equals_per_step_learning_on_host_encoded_planes():
     assert a.accuracy(y3) == b.accuracy(y3)
 
 
+def test_graph_captured_learning_steps_equal_eager_steps():
+    """The learning timestep replayed from its captured hipGraph (ConvNetwork._learn_graphed: static input buffers, Adam's
+    step-dependent scalars read on the device) == the same step launched eagerly, bit for bit, over three 'batches' with
+    the per-batch reset of train.py (state re-filled in place, random_tau re-drawn in place), an lr change (train.py's
+    schedule) and the every-20th-step pv statistics (run eagerly) in between; clout, iter and Adam's state agree, and the
+    graph was really used (one capture, many replays)."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    B, R_, T, burnin = 8, 16, 47, 5
+
+    def make(graph):
+        torch.manual_seed(1)
+        np.random.seed(1)
+        net = ConvNetwork(_args(), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                          opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0},
+                          learning_rates=[1e-6], burnin=burnin)
+        net.graph_learn = graph
+        net.reset(True)
+        return net
+    rng = np.random.RandomState(3)
+    batches = []
+    for _ in range(3):
+        cells = torch.from_numpy(rng.randint(0, R_ * R_, size=(T, B)).astype(np.int32)).cuda()
+        y = torch.zeros(B, 24)
+        y[np.arange(B), rng.randint(0, 24, size=B)] = 1
+        batches.append((cells, y.cuda()))
+    nets = {}
+    for graph in (True, False):
+        net = nets[graph] = make(graph)
+        np.random.seed(7)                                  # random_tau draws at every reset
+        for k, (cells, y) in enumerate(batches):
+            net.reset(True)
+            net.train()
+            if k == 2:
+                for s_ in net.dcll_slices:
+                    s_.optimizer.param_groups[0]["lr"] *= 0.5
+            net.learn_sequence(cells, y)
+            if k == 0:
+                clout0 = [np.asarray(s_.clout).copy() for s_ in net.dcll_slices]
+                nets[(graph, "clout0")] = clout0
+    a, b = nets[True], nets[False]
+    g = a._learn_graphs[((B, 1, R_, R_), (B, 24))]
+    assert g["n"] >= 3 * (T - burnin + 1) - 3 * 2 - 3 * 3 and not b._learn_graphs     # minus warm-up and histogram steps
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for ca, cb in zip(nets[(True, "clout0")], nets[(False, "clout0")]):
+        assert np.array_equal(ca, cb) and len(ca) == T - burnin + 1
+    for sl_a, sl_b in zip(a.dcll_slices, b.dcll_slices):
+        assert sl_a.iter == sl_b.iter == T
+        assert np.array_equal(np.asarray(sl_a.clout), np.asarray(sl_b.clout)) and len(sl_a.clout) == T - burnin + 1
+        assert np.array_equal(sl_a._activity_rows(), sl_b._activity_rows()) and len(sl_a.activity_hist) == 2
+        for q in sl_a.optimizer.state:
+            pass
+        for (qa, sta), (qb, stb) in zip(sl_a.optimizer.state.items(), sl_b.optimizer.state.items()):
+            assert float(sta["step"]) == float(stb["step"]) == 3 * (T - burnin + 1)
+            assert torch.equal(sta["exp_avg_sq"], stb["exp_avg_sq"]) and torch.equal(sta["exp_avg"], stb["exp_avg"])
+
+
 def test_native_learning_pieces_vs_torch():
     """dcll_local_loss_grad == autograd of torch's SmoothL1Loss / MSELoss (mean), dcll_adam_step == torch.optim.Adam over
     several steps with per-tensor hyper-parameters (the slices' optimizer and optimizer2), dcll_cells_to_planes == one-hot."""
