@@ -27,14 +27,16 @@ int main()
     std::vector<float> hw(32 * 32 * 49, 1e-6f), hb(32, 1e-4f), ht(4 * 8192, 0.9f);
     hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(bias, hb.data(), 128, hipMemcpyHostToDevice); hipMemcpy(tau, ht.data(), ht.size() * 4, hipMemcpyHostToDevice);
-    printf("%6s %10s %10s %10s %10s %10s %10s   (us; ideal MFMA time at 157.3 TF)\n", "B", "full", "noMFMA", "noStores", "noState", "MFMAonly", "ideal");
+    printf("%6s %10s %10s %10s %10s %10s %10s %10s %10s  (us; ideal MFMA time at 157.3 TF)\n", "B", "full", "noMFMA", "noStores", "noState", "MFMAonly", "+noWstream", "+noBarrier", "ideal");
     for (int B : {64, 256, 512, 1024, 2048, 4096}) {
         float f = run<0>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         float a = run<1>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         float c = run<2>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         float d = run<4>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         float e = run<6>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
-        printf("%6d %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f\n", B, f, a, c, d, e, 2.0 * 32 * 1568 * 256 * (double)B / 157.3e12 * 1e6);
+        float g = run<14>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        float h = run<30>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        printf("%6d %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f\n", B, f, a, c, d, e, g, h, 2.0 * 32 * 1568 * 256 * (double)B / 157.3e12 * 1e6);
     }
     return 0;
 }

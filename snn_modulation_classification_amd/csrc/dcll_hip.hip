@@ -535,54 +535,96 @@ __global__ __launch_bounds__(128) void k_bwd_wgrad_c1(const float *__restrict__ 
 // k_bwd_dv for layers without pooling: thread = one position k = (co, y, x) of the map, the (<= 32) readout weights of
 // that position in registers, a chunk of samples looped over (g_p is wave-uniform -> scalar loads): i2o_W is read once
 // per chunk instead of once per sample (786 KB x B through L2 before).
+constexpr int DV_MAXPB = 16;            // samples per workgroup of k_bwd_dv_nopool (its per_block argument), at most
+// NP: N rounded up to a multiple of 8 — the sum over the readout weights runs over NP terms without a test per term (the
+// padding terms are 0 * 0); with the test the loop was a chain of branch, LDS read, wait, FMA (24 us at B = 512)
+template <int NP>
 __global__ __launch_bounds__(256) void k_bwd_dv_nopool(int K, int N, const float *__restrict__ v,
                                                         const float *__restrict__ g_p, const float *__restrict__ g_pv,
                                                         const float *__restrict__ g_v, const float *__restrict__ i2o_W,
                                                         float *__restrict__ gvf, int B, int per_block)
 {
+    // the chunk's g_p rows through LDS (read back as broadcasts): as scalar loads from global memory they were a chain
+    // of ~400 dependent s_load latencies per thread
+    __shared__ __attribute__((aligned(16))) float gp[DV_MAXPB][32];
+    const int b0 = blockIdx.y * per_block, b1 = min(B, b0 + per_block);
+    for (int e = threadIdx.x; e < per_block * 32; e += 256) {
+        const int bb = b0 + (e >> 5), n = e & 31;
+        gp[e >> 5][n] = (g_p && n < N && bb < b1) ? g_p[(long)bb * N + n] : 0.0f;
+    }
+    __syncthreads();
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
-    float wk[32];
+    float wk[NP];
 #pragma unroll
-    for (int n = 0; n < 32; ++n) wk[n] = (g_p && n < N) ? i2o_W[(long)n * K + k] : 0.0f;
-    const int b0 = blockIdx.y * per_block, b1 = min(B, b0 + per_block);
-    for (int b = b0; b < b1; ++b) {
-        const long i = (long)b * K + k;
-        float g = g_pv ? g_pv[i] : 0.0f;
-        if (g_p) {
-            float acc = 0.0f;
+    for (int n = 0; n < NP; ++n) wk[n] = (g_p && n < N) ? i2o_W[(long)n * K + k] : 0.0f;
+    // samples in groups of DV_G: all loads of a group are issued before the first is used (one sample at a time the loop
+    // is a chain of HBM latencies: 29 us for 16 samples per thread at B = 512, 1.1 TB/s)
+    constexpr int DV_G = 8;
+    for (int bg = b0; bg < b1; bg += DV_G) {
+        float vv[DV_G], gg[DV_G], ga[DV_G];
 #pragma unroll
-            for (int n = 0; n < 32; ++n)
-                if (n < N) acc = __builtin_fmaf(g_p[(long)b * N + n], wk[n], acc);
-            g += acc;
+        for (int q = 0; q < DV_G; ++q) {
+            const int b = min(bg + q, b1 - 1);
+            const long i = (long)b * K + k;
+            vv[q] = v[i];
+            gg[q] = g_pv ? g_pv[i] : 0.0f;
+            ga[q] = g_v ? g_v[i] : 0.0f;
         }
-        const float pv = sigmoidf_dev(v[i]);
-        float out = g * pv * (1.0f - pv);
-        if (g_v) out += g_v[i];
-        gvf[i] = out;
+#pragma unroll
+        for (int q = 0; q < DV_G; ++q) {
+            const int b = min(bg + q, b1 - 1);
+            float g = gg[q];
+            if (g_p) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int n4 = 0; n4 < NP; n4 += 4) {
+                    const f32x4 gq = *(const f32x4 *)&gp[b - b0][n4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(gq[u], wk[n4 + u], acc);
+                }
+                g += acc;
+            }
+            const float pv = sigmoidf_dev(vv[q]);
+            float out = g * pv * (1.0f - pv);
+            if (g_v) out += ga[q];
+            if (bg + q < b1) gvf[(long)b * K + k] = out;
+        }
     }
 }
 
 // The same sum with four threads per output (64 outputs x 4 groups of partial rows per workgroup), the four group sums
 // combined in fixed order through LDS: a quarter of the dependent-load latency of k_bwd_reduce (54 -> ~15 us for 256
 // partial rows of 50 208 floats), still deterministic.
-__global__ __launch_bounds__(256) void k_bwd_reduce4(const float *__restrict__ part, float *__restrict__ dW,
-                                                      float *__restrict__ db, int nchunk, int c_out, long rowlen)
+template <int GR>
+__global__ __launch_bounds__(64 * GR) void k_bwd_reduce4(const float *__restrict__ part, float *__restrict__ dW,
+                                                           float *__restrict__ db, int nchunk, int c_out, long rowlen)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[GR][64];
     const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     const int grp = threadIdx.x >> 6;
     const long total = c_out * rowlen;
     float acc = 0.0f;
     if (i < total) {
-        const int per = (nchunk + 3) / 4, c0 = grp * per, c1 = min(nchunk, c0 + per);
-        for (int c = c0; c < c1; ++c) acc += part[(long)c * total + i];
+        const int per = (nchunk + GR - 1) / GR, c0 = grp * per, c1 = min(nchunk, c0 + per);
+        const float *src = part + i;
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {                     // eight loads in flight, added in chunk order
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = src[(long)(c + q) * total];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += t[q];
+        }
+        for (; c < c1; ++c) acc += src[(long)c * total];
     }
     red[grp][threadIdx.x & 63] = acc;
     __syncthreads();
     if (grp == 0 && i < total) {
         const int l = threadIdx.x & 63;
-        const float tot = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+        float tot = red[0][l];
+#pragma unroll
+        for (int q = 1; q < GR; ++q) tot += red[q][l];
         const int co = (int)(i / rowlen);
         const long n = i % rowlen;
         if (n < rowlen - 1) dW[(long)co * (rowlen - 1) + n] = tot;
@@ -1887,7 +1929,8 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
 // which at a stride of 64 floats would be 64 writes into one LDS bank — measured 1.4 us per chunk, during which the
 // operand reads of the MFMA stream wait (experiments/ablate_step.hip)
 constexpr int STEP_WTS = 65, STEP_WCH = 49 * STEP_WTS + 3;
-// DBG (experiments/ablate_step.hip only; 0 in the product): 1 no MFMAs, 2 no epilogue stores, 4 no state traffic
+// DBG (experiments/ablate_step.hip only; 0 in the product): 1 no MFMAs, 2 no epilogue stores, 4 no state traffic,
+// 8 no weight streaming, 16 no barrier per chunk (8, 16: wrong results, timing only)
 template <bool REFRACTORY, int DBG = 0>
 __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ x, const float *__restrict__ W,
                                                        const float *__restrict__ bias, const float *__restrict__ alpha,
@@ -1978,7 +2021,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     const int bbase = h * CHF + ((j >> 4) + 4 * w) * ROWF + (j & 15);
     for (int cp = 0; cp < 16; ++cp) {
         if (cp + 1 < 16) {                                 // land during the MFMAs below
-            fetch_w(cp + 1);
+            if (!(DBG & 8)) fetch_w(cp + 1);
             fetch_t(cp + 1);
         }
         const float *wa = wch + (cp & 1) * STEP_WCH + lane;
@@ -2008,10 +2051,10 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             }
         }
         if (cp + 1 < 16) {
-            store_w((cp + 1) & 1);                         // the other buffer: nobody reads it in this iteration
+            if (!(DBG & 8)) store_w((cp + 1) & 1);         // the other buffer: nobody reads it in this iteration
             finish_t(cp + 1);                              // image channels nobody reads in this iteration
         }
-        __syncthreads();
+        if (!(DBG & 16)) __syncthreads();
     }
     // epilogue of my two tiles: channel (r&3) + 8(r>>2) + 4h, pixel 32(2w + tl) + j
 #pragma unroll
@@ -2210,7 +2253,19 @@ __global__ __launch_bounds__(256) void k_bwd_outgrad_mfma(const float *__restric
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int b = b0; b < b1; b += 2) {
+    int b = b0;
+    for (; b + 16 <= b1; b += 16) {                            // eight sample pairs: all loads issued before the first MFMA
+        float av[8], bvv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int bb = b + 2 * q + h;
+            av[q] = j < N ? g_o[(long)bb * N + j] : 0.0f;
+            bvv[q] = pvp[(long)bb * K + k0 + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bvv[q], acc, 0, 0, 0);
+    }
+    for (; b < b1; b += 2) {
         const int bb = b + h;
         const bool ok = bb < b1;
         const float a = (ok && j < N) ? g_o[(long)bb * N + j] : 0.0f;
@@ -2261,8 +2316,14 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
     const long nconv = (long)B * d->c_out * ch * cw;
     if (d->pool_h == 1 && d->pool_w == 1 && d->target <= 32) {
         const int Kmap = d->c_out * ch * cw, per_block = 16;
-        hipLaunchKernelGGL(k_bwd_dv_nopool, dim3(nblk(Kmap, 256), nblk(B, per_block)), dim3(256), 0, st, Kmap, d->target,
-                           v, g_p, g_pv, g_v, i2o_W, scratch, B, per_block);
+        const dim3 grid(nblk(Kmap, 256), nblk(B, per_block));
+#define DCLL_DV(NP_) hipLaunchKernelGGL(k_bwd_dv_nopool<NP_>, grid, dim3(256), 0, st, Kmap, d->target, v, g_p, g_pv, g_v, \
+                                        i2o_W, scratch, B, per_block)
+        if (d->target <= 8) DCLL_DV(8);
+        else if (d->target <= 16) DCLL_DV(16);
+        else if (d->target <= 24) DCLL_DV(24);
+        else DCLL_DV(32);
+#undef DCLL_DV
     } else {
         hipLaunchKernelGGL(k_bwd_dv, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, v, g_p, g_pv, g_v, i2o_W,
                            scratch, nconv);
@@ -2307,8 +2368,10 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
                            eps1, part, B, RB);
         HIP_CHECK_LAUNCH("k_bwd_wgrad");
     }
-    if (nchunk >= 16)
-        hipLaunchKernelGGL(k_bwd_reduce4, dim3(nblk(per_chunk, 64)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+    if (nchunk >= 64)
+        hipLaunchKernelGGL(k_bwd_reduce4<16>, dim3(nblk(per_chunk, 64)), dim3(1024), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+    else if (nchunk >= 16)
+        hipLaunchKernelGGL(k_bwd_reduce4<4>, dim3(nblk(per_chunk, 64)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
     else
         hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
     HIP_CHECK_LAUNCH("k_bwd_reduce");
