@@ -48,13 +48,42 @@ def _clout_to_numpy(pvoutput):
     return np.asarray([c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in pvoutput])
 
 
+def _modes_first_seen(rows):
+    """_mode_first_seen of every row of a (B,T) integer array, without a Python loop over B (the reference's loop is
+    0.3 s per call at B = 4096): per row and value the count and the first position; the winner has the largest count,
+    among equal counts the smallest first position."""
+    rows = np.asarray(rows)
+    B, T = rows.shape
+    lo = int(rows.min()) if rows.size else 0
+    V = (int(rows.max()) - lo + 1) if rows.size else 0
+    if B == 0 or T == 0 or rows.dtype.kind not in 'iu' or V > 4096:       # (class indices: a few dozen values)
+        return np.array([_mode_first_seen(r) for r in rows], dtype=np.float64)
+    vals = np.arange(lo, lo + V)
+    flat = np.arange(B, dtype=np.int64)[:, None] * V + (rows.astype(np.int64) - lo)
+    counts = np.bincount(flat.ravel(), minlength=B * V).reshape(B, V)
+    first = np.full(B * V, T, dtype=np.int64)
+    # positions written in descending order: for a repeated index the last assignment (the smallest position) stays
+    first[flat[:, ::-1].ravel()] = np.broadcast_to(np.arange(T - 1, -1, -1, dtype=np.int64), (B, T)).ravel()
+    key = counts * (T + 1) + (T - first.reshape(B, V))
+    return vals[key.argmax(axis=1)]
+
+
 def get_predictions_by_vote(pvoutput, labels):
     """pvoutput: T arrays of per-sample argmax; labels: (T,B,C) one-hot tensor.  -> (pred (B), label (B))."""
     votes = _clout_to_numpy(pvoutput).T
-    lab = labels.detach().cpu().numpy().argmax(axis=2).T
-    pred = np.array([_mode_first_seen(r) for r in votes], dtype=np.float64)
-    labv = np.array([_mode_first_seen(r) for r in lab], dtype=np.float64)
-    return pred, labv
+    pred = np.asarray(_modes_first_seen(votes), dtype=np.float64)
+    return pred, _label_votes(labels)
+
+
+def _label_votes(labels):
+    """Mode over T of the labels' argmax ((T,B,C) one-hot tensor) -> (B) float64."""
+    if isinstance(labels, torch.Tensor) and labels.dim() == 3 and labels.shape[0] > 0 and labels.stride(0) == 0:
+        # one label row per sample expanded over T (iq2spiketrain repeats the labels): the mode over T is that row's
+        labv = labels[0].detach().cpu().numpy().argmax(axis=1).astype(np.float64)
+    else:
+        lab = labels.detach().cpu().numpy().argmax(axis=2).T
+        labv = np.asarray(_modes_first_seen(lab), dtype=np.float64)
+    return labv
 
 
 def accuracy_by_vote(pvoutput, labels):
@@ -679,6 +708,7 @@ class DCLLBase(nn.Module):
     @clout.setter
     def clout(self, value):
         self._clout = value
+        self._seq_vote = None           # (a stashed device-side vote belongs to the list it was computed from)
 
     def init(self, batch_size, init_states=True):
         self.clout = []
@@ -890,14 +920,18 @@ class DCLLClassification(DCLLBase):
             self._clout.append(logits.argmax(1).detach())
         return o, p, pv, pvmem
 
-    def set_sequence_result(self, clout_dev, n_steps, lowhigh=None, numel=0):
+    def set_sequence_result(self, clout_dev, n_steps, lowhigh=None, numel=0, vote=None):
         """Install the results of a whole-sequence run as n_steps calls of forward() would have left them: the per-step
         argmax ((T,B) int32 on device) appended to `clout`, the iteration count advanced, and — `lowhigh` (n,2) int64
         device counters of the histogram steps, `numel` pv values per step — the pv statistics appended to
-        `activity_hist` (reference :658-661)."""
+        `activity_hist` (reference :658-661).  `vote` ((B) int32 on device): the mode over exactly these steps as the
+        vote kernel computed it (ties -> first seen, dcll_argmax_vote); accuracy() / confusion_matrix() use it as long
+        as `clout` holds these steps and nothing else, instead of reading all T x B entries back and voting on the host."""
         self.iter += n_steps
+        fresh = len(self._clout) == 0
         if clout_dev is not None:       # (None: steps whose argmax is not recorded — the burn-in of a learning sequence)
             self._clout.extend(clout_dev.to(torch.int64))   # like n_steps calls of forward(): appended, not replaced
+        self._seq_vote = (vote, len(self._clout)) if (vote is not None and clout_dev is not None and fresh) else None
         if lowhigh is not None and self.collect_stats:
             self.activity_hist.extend((row, numel) for row in lowhigh)
 
@@ -905,16 +939,24 @@ class DCLLClassification(DCLLBase):
         super().write_stats(writer, label, epoch)
         writer.add_scalar(self.name + '/acc/' + label, self.acc, epoch)
 
+    def _predictions(self, targets):
+        """get_predictions_by_vote(self.clout, targets[-len(clout):]) (reference :735-749); the prediction comes from
+        the device-side vote of a whole-sequence run when `clout` is exactly that run (set_sequence_result)."""
+        sv = getattr(self, '_seq_vote', None)
+        begin = len(self._clout)
+        if sv is not None and sv[1] == begin and begin > 0:
+            pred = sv[0].detach().cpu().numpy().astype(np.float64)
+            return pred, _label_votes(targets[-begin:])
+        return get_predictions_by_vote(self.clout, targets[-begin:])
+
     def accuracy(self, targets):
-        begin = len(self.clout)
-        self.acc = accuracy_by_vote(self.clout, targets[-begin:])
+        pred, labv = self._predictions(targets)
+        self.acc = float(np.mean(pred == labv))
         return self.acc
 
     def confusion_matrix(self, targets):
-        begin = len(self.clout)
-        pred, labv = get_predictions_by_vote(self.clout, targets[-begin:])
+        pred, labv = self._predictions(targets)
         n = self.dclllayer.target_size
         cm = np.zeros((n, n), dtype=int)
-        for p_, l_ in zip(pred, labv):
-            cm[int(p_), int(l_)] += 1
+        np.add.at(cm, (pred.astype(np.int64), labv.astype(np.int64)), 1)
         return cm

@@ -372,7 +372,7 @@ class ConvNetwork(torch.nn.Module):
                 if res['clout'][i] is not None:
                     L = s.dclllayer
                     s.set_sequence_result(res['clout'][i], T, lowhigh=res['lowhigh'][i],
-                                          numel=B * L.out_channels * int(np.prod(L.output_shape)))
+                                          numel=B * L.out_channels * int(np.prod(L.output_shape)), vote=res['vote'][i])
         return res
 
     def _sequence_chunk(self, first_input, first_kind, T, B, dev, profile, fuse_readout, batch_slice=None,

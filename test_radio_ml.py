@@ -121,7 +121,7 @@ def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
             parallel.all_reduce_(tal)
             return _split_eval_tally(tal, len(net.dcll_slices))
     if use_sequence:
-        targets = labels1h.unsqueeze(0).repeat(T, 1, 1)
+        targets = labels1h.unsqueeze(0).expand(T, -1, -1)        # iq2spiketrain repeats the labels over t
         net.reset()
         net.eval()
         # raw IQ to the GPU; quantisation to I/Q-plane cells happens inside the first layer's kernel
@@ -139,7 +139,8 @@ def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
         net.eval()
         for t in range(T):
             net.test(x=test_input[t])
-    targets = torch.as_tensor(np.asarray(targets), dtype=torch.float32)
+    if not isinstance(targets, torch.Tensor):
+        targets = torch.as_tensor(np.asarray(targets), dtype=torch.float32)
     acc, cm = net.accuracy(targets), net.confusion_matrix(targets)
     if world > 1:
         n = samples.shape[0]

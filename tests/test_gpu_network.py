@@ -1058,3 +1058,35 @@ def test_train_dcll_with_regularisers_takes_the_autograd_path():
     g = s0.dclllayer.i2h.weight.grad.cpu().numpy()
     np.testing.assert_allclose(g, W.grad.numpy(), rtol=2e-3, atol=1e-6 * np.abs(W.grad.numpy()).max())
     np.testing.assert_allclose(float(loss), float(tgt_loss.detach()), rtol=1e-4)      # the target loss is what is returned (:716)
+
+
+def test_accuracy_after_sequence_run_uses_device_vote_and_equals_host_vote():
+    """ConvNetwork.accuracy / confusion_matrix after test_sequence take the prediction from the device-side vote
+    (set_sequence_result) — equal to the host vote over the read-back clout (reference :44-61, :735-749); appending
+    further steps or replacing clout falls back to the host vote."""
+    from snn_modulation_classification_amd.dcll import pytorch_libdcll as L
+    B, R_, T = 96, 16, 40
+    net = _radio_net(B, R_)
+    rng = np.random.RandomState(5)
+    cells = torch.from_numpy(rng.randint(0, R_ * R_, size=(T, B)).astype(np.int32)).cuda()
+    y = torch.zeros(B, 24)
+    y[np.arange(B), rng.randint(0, 24, size=B)] = 1
+    targets = y.unsqueeze(0).expand(T, -1, -1)
+    net.reset()
+    net.test_sequence(cells)
+    for s_ in net.dcll_slices:
+        assert s_._seq_vote is not None and s_._seq_vote[1] == T
+    acc, cm = net.accuracy(targets), net.confusion_matrix(targets)
+    host = [L.get_predictions_by_vote(s_.clout, targets) for s_ in net.dcll_slices]
+    assert acc == [float(np.mean(p == l)) for p, l in host]
+    cm_ref = np.zeros((24, 24), dtype=int)
+    np.add.at(cm_ref, (host[-1][0].astype(int), host[-1][1].astype(int)), 1)
+    assert np.array_equal(cm, cm_ref) and cm.sum() == B
+    # one more per-step call: clout is no longer the sequence run alone
+    x = torch.zeros(B, 1, R_, R_, device="cuda")
+    net.test(x)
+    assert len(net.dcll_slices[0].clout) == T + 1
+    tg2 = y.unsqueeze(0).expand(T + 1, -1, -1)
+    assert net.accuracy(tg2) == [L.accuracy_by_vote(s_.clout, tg2) for s_ in net.dcll_slices]
+    net.reset()
+    assert all(s_._seq_vote is None for s_ in net.dcll_slices)

@@ -461,3 +461,23 @@ def test_reference_written_checkpoint_loads(golden, cpu_device):
     for i in range(3):
         for k, v in g.sub("sd_after_reset/%d/" % i).items():
             assert np.array_equal(net.state_dict()["dcll_slices.%d.dclllayer.%s" % (i, k)].numpy(), v), (i, k)
+
+
+def test_vectorised_vote_equals_counter_loop():
+    """get_predictions_by_vote without the Python loop over B (reference :44-56: Counter.most_common per sample, ties ->
+    first seen) gives the same winners, also with ties, negative / sparse values, and for labels expanded over T."""
+    from snn_modulation_classification_amd.dcll import pytorch_libdcll as L
+    rng = np.random.RandomState(0)
+    for B, T, C in [(1, 1, 3), (7, 5, 2), (300, 128, 24), (50, 4, 24), (64, 128, 3), (9, 6, 50000)]:
+        a = rng.randint(0, C, size=(B, T)) - (3 if C == 3 else 0)
+        assert np.array_equal(np.array([L._mode_first_seen(r) for r in a]), L._modes_first_seen(a)), (B, T, C)
+    ties = np.array([[2, 1, 1, 2], [1, 2, 2, 1], [0, 3, 3, 0], [5, 5, 4, 4]])
+    assert list(L._modes_first_seen(ties)) == [2, 1, 0, 5]
+    Bn, T, C = 33, 11, 24
+    clout = [rng.randint(0, C, size=Bn) for _ in range(T)]
+    y = torch.zeros(Bn, C)
+    y[np.arange(Bn), rng.randint(0, C, size=Bn)] = 1
+    p1, l1 = L.get_predictions_by_vote(clout, y.unsqueeze(0).expand(T, -1, -1))
+    p2, l2 = L.get_predictions_by_vote(clout, y.unsqueeze(0).repeat(T, 1, 1))
+    assert np.array_equal(p1, p2) and np.array_equal(l1, l2) and np.array_equal(l1, y.argmax(1).numpy())
+    assert np.array_equal(p1, [L._mode_first_seen(r) for r in np.asarray(clout).T])
