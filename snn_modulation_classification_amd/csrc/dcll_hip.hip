@@ -189,14 +189,25 @@ __global__ __launch_bounds__(256) void k_conv_lif_tiled(dcll_conv_desc d, int ch
                 win[0][ky * KW + kx] = in[0][(ly + ky) * IW + lx + kx];
                 win[1][ky * KW + kx] = in[1][(ly + ky) * IW + lx + kx];
             }
+        if (2 * cp + 1 < d.c_in) {
 #pragma unroll
-        for (int c = 0; c < COG; ++c) {
-            const f32x2 *wp = (const f32x2 *)(wl + c * KK * 2);
+            for (int c = 0; c < COG; ++c) {
+                const f32x2 *wp = (const f32x2 *)(wl + c * KK * 2);
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const f32x2 w2 = wp[tap];
-                acc[c] = __builtin_fmaf(win[0][tap], w2[0], acc[c]);
-                acc[c] = __builtin_fmaf(win[1][tap], w2[1], acc[c]);
+                for (int tap = 0; tap < KK; ++tap) {
+                    const f32x2 w2 = wp[tap];
+                    acc[c] = __builtin_fmaf(win[0][tap], w2[0], acc[c]);
+                    acc[c] = __builtin_fmaf(win[1][tap], w2[1], acc[c]);
+                }
+            }
+        } else {
+            // odd c_in (the first layer: one input channel): the pair's second member does not exist; its terms
+            // fmaf(0, 0, acc) are left out — acc is unchanged by them (but for the sign of an exact zero)
+#pragma unroll
+            for (int c = 0; c < COG; ++c) {
+                const float *wp = wl + c * KK * 2;
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) acc[c] = __builtin_fmaf(win[0][tap], wp[2 * tap], acc[c]);
             }
         }
     }
@@ -412,14 +423,15 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
     float *img = lds, *gl = lds + IMG;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntile = (w == 0) ? 7 : 6;
     for (int i = tid; i < IMG; i += 512) img[i] = 0.0f;
+    // 49 column tiles over 8 waves: wave w owns tiles w, w + 8, ..., w + 40 (six) and ONE EIGHTH of tile 48 — the pixel
+    // pairs 16w .. 16w+15 of every sample, summed over the waves in wave order at the end.  (Tile 48 whole on wave 0 made
+    // its SIMD carry 13 tiles against 12: the slowest SIMD sets the time, +6 %.)
     int bbase[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
-        const int n = (w + 8 * q) * 32 + j;                  // my column in tile q (n < 1568 for q < ntile)
-        const int nn = n < 1568 ? n : 0;
-        const int ci = nn / 49, tap = nn % 49;
+        const int n = (q < 6 ? w + 8 * q : 48) * 32 + j;     // my column in tile q
+        const int ci = n / 49, tap = n % 49;
         bbase[q] = ci * CF + (tap / 7) * RF + (tap % 7) + h;
     }
     f32x16 acc[7];
@@ -431,6 +443,17 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
     const int tpr = Wd >> 4, tps = (H >> 4) * tpr;            // 16x16 tiles per row / per sample
     const long njob = TILED ? (long)B * tps : B;
     const long HW = (long)H * Wd;
+    // 16x16 plane: the next sample's g and eps1 (16 + 16 floats per thread) are fetched into registers while the MFMAs of
+    // this one run; only the LDS copy and two barriers stay between the samples of a workgroup
+    float pg[16], pe[16];
+    auto fetch = [&](long job) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            pg[k] = gvf[job * 8192 + tid + 512 * k];
+            pe[k] = eps1[job * 8192 + tid + 512 * k];
+        }
+    };
+    if (!TILED && (long)blockIdx.x < njob) fetch(blockIdx.x);
     for (long job = blockIdx.x; job < njob; job += gridDim.x) {
         __syncthreads();
         if (TILED) {
@@ -447,37 +470,53 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
                              ? eps1[(b * 32 + c) * HW + (long)gy * Wd + gx] : 0.0f;
             }
         } else {
-            for (int i = tid; i < 32 * 256; i += 512) {
-                const int c = i >> 8, p = i & 255;
-                gl[c * WG32_GLD + p] = gvf[job * 8192 + i];
-                img[c * CF + ((p >> 4) + 3) * RF + (p & 15) + 3] = eps1[job * 8192 + i];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = tid + 512 * k, c = i >> 8, p = i & 255;
+                gl[c * WG32_GLD + p] = pg[k];
+                img[c * CF + ((p >> 4) + 3) * RF + (p & 15) + 3] = pe[k];
             }
         }
         __syncthreads();
+        if (!TILED && job + gridDim.x < njob) fetch(job + gridDim.x);
         {   // bias gradient: co = 4w + lane/16, pixels lane%16 + 16*k
             const float *gr = gl + (4 * w + (lane >> 4)) * WG32_GLD + (lane & 15);
 #pragma unroll
             for (int k = 0; k < 16; ++k) bsum += gr[16 * k];
         }
         const float *ga = gl + j * WG32_GLD + h;              // A: co = j, pixel p + h
+        for (int seg = 0; seg < 8; ++seg) {                   // 16 pixel pairs = two image rows per segment
+            const bool mine = seg == w;                       // wave-uniform: my eighth of tile 48
 #pragma unroll 4
-        for (int pp = 0; pp < 128; ++pp) {
-            const int p = 2 * pp;
-            const float a = ga[p];
-            const int poff = (p >> 4) * RF + (p & 15);
+            for (int pp = 16 * seg; pp < 16 * seg + 16; ++pp) {
+                const int p = 2 * pp;
+                const float a = ga[p];
+                const int poff = (p >> 4) * RF + (p & 15);
 #pragma unroll
-            for (int q = 0; q < 7; ++q)
-                if (q < ntile) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
+                for (int q = 0; q < 6; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
+                if (mine) acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[6] + poff], acc[6], 0, 0, 0);
+            }
         }
     }
     float *pw = part + (long)blockIdx.x * 32 * 1569;
 #pragma unroll
-    for (int q = 0; q < 7; ++q)
-        if (q < ntile) {
-            const int n = (w + 8 * q) * 32 + j;
+    for (int q = 0; q < 6; ++q) {
+        const int n = (w + 8 * q) * 32 + j;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pw[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * 1569 + n] = acc[q][r];
-        }
+        for (int r = 0; r < 16; ++r) pw[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * 1569 + n] = acc[q][r];
+    }
+    // tile 48: the eight partial tiles through LDS (the staging area is free), added in wave order
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[(w * 16 + r) * 64 + lane] = acc[6][r];
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += 512) {
+        const int l = e & 63, r = e >> 6;
+        float tot = lds[r * 64 + l];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) tot += lds[(ww * 16 + r) * 64 + l];
+        pw[(long)((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 1569 + 48 * 32 + (l & 31)] = tot;
+    }
     // bias partial: reduce the 16 lanes of each co group
     bsum += __shfl_xor(bsum, 1); bsum += __shfl_xor(bsum, 2); bsum += __shfl_xor(bsum, 4); bsum += __shfl_xor(bsum, 8);
     if ((lane & 15) == 0) pw[(long)(4 * w + (lane >> 4)) * 1569 + 1568] = bsum;
