@@ -414,7 +414,10 @@ constexpr int WG32_GLD = 257;
 // TILED = false: the 16x16 plane, one sample per job, image rows / channels share their zero padding (RF 19, CF 361).
 // TILED = true: planes with h % 16 == 0 and w % 16 == 0, one 16x16 tile of a sample per job; the tile's 22x22 eps1
 // region with its real halo (zero outside the plane) is staged per channel (RF 22, CF 484).
-template <int RF, int CF, bool TILED>
+// SPLIT: workgroups per batch chunk (blockIdx.y), each with 6 / SPLIT of every wave's column tiles — small batches have
+// fewer samples than the GPU has CUs, so a sample's 49 column tiles are spread over several workgroups (which all
+// stage the same g and image; the columns they write are disjoint, the fixed-order reduce is unchanged).
+template <int RF, int CF, bool TILED, int SPLIT = 1>
 __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__ gvf, const float *__restrict__ eps1,
                                                         float *__restrict__ part, int B, int H, int Wd)
 {
@@ -427,16 +430,20 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
     // 49 column tiles over 8 waves: wave w owns tiles w, w + 8, ..., w + 40 (six) and ONE EIGHTH of tile 48 — the pixel
     // pairs 16w .. 16w+15 of every sample, summed over the waves in wave order at the end.  (Tile 48 whole on wave 0 made
     // its SIMD carry 13 tiles against 12: the slowest SIMD sets the time, +6 %.)
-    int bbase[7];
+    constexpr int NQ = 6 / SPLIT;                             // whole tiles per wave in this workgroup
+    static_assert(6 % SPLIT == 0, "SPLIT divides the six whole tiles of a wave");
+    const int q0 = blockIdx.y * NQ;                           // my tiles: w + 8 (q0 + q), q < NQ
+    const bool last48 = blockIdx.y == 0;                      // tile 48 belongs to the first workgroup of the chunk
+    int bbase[NQ + 1];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-        const int n = (q < 6 ? w + 8 * q : 48) * 32 + j;     // my column in tile q
+    for (int q = 0; q < NQ + 1; ++q) {
+        const int n = (q < NQ ? w + 8 * (q0 + q) : 48) * 32 + j;     // my column in tile q
         const int ci = n / 49, tap = n % 49;
         bbase[q] = ci * CF + (tap / 7) * RF + (tap % 7) + h;
     }
-    f32x16 acc[7];
+    f32x16 acc[NQ + 1];
 #pragma unroll
-    for (int q = 0; q < 7; ++q)
+    for (int q = 0; q < NQ + 1; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
     float bsum = 0.0f;                                        // wave w, lanes: co = 4w + (lane>>4), 16 pixels per pass
@@ -486,29 +493,30 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
         }
         const float *ga = gl + j * WG32_GLD + h;              // A: co = j, pixel p + h
         for (int seg = 0; seg < 8; ++seg) {                   // 16 pixel pairs = two image rows per segment
-            const bool mine = seg == w;                       // wave-uniform: my eighth of tile 48
+            const bool mine = seg == w && last48;             // wave-uniform: my eighth of tile 48
 #pragma unroll 4
             for (int pp = 16 * seg; pp < 16 * seg + 16; ++pp) {
                 const int p = 2 * pp;
                 const float a = ga[p];
                 const int poff = (p >> 4) * RF + (p & 15);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
-                if (mine) acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[6] + poff], acc[6], 0, 0, 0);
+                for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
+                if (mine) acc[NQ] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[NQ] + poff], acc[NQ], 0, 0, 0);
             }
         }
     }
     float *pw = part + (long)blockIdx.x * 32 * 1569;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int n = (w + 8 * q) * 32 + j;
+    for (int q = 0; q < NQ; ++q) {
+        const int n = (w + 8 * (q0 + q)) * 32 + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pw[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * 1569 + n] = acc[q][r];
     }
+    if (!last48) return;                                      // (workgroup-uniform)
     // tile 48: the eight partial tiles through LDS (the staging area is free), added in wave order
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) lds[(w * 16 + r) * 64 + lane] = acc[6][r];
+    for (int r = 0; r < 16; ++r) lds[(w * 16 + r) * 64 + lane] = acc[NQ][r];
     __syncthreads();
     for (int e = tid; e < 16 * 64; e += 512) {
         const int l = e & 63, r = e >> 6;
@@ -2378,8 +2386,19 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
     if (c32 && d->h == 16 && d->w == 16) {
         if (nchunk > 256) nchunk = 256;
         if (nchunk > B) nchunk = B;
-        hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false>), dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1,
-                           part, B, 16, 16);
+        // fewer samples than CUs: a sample's column tiles over 2, 3 or 6 workgroups
+        if (nchunk <= 48)
+            hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false, 6>), dim3((unsigned)nchunk, 6), dim3(512), 0, st, scratch,
+                               eps1, part, B, 16, 16);
+        else if (nchunk <= 96)
+            hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false, 3>), dim3((unsigned)nchunk, 3), dim3(512), 0, st, scratch,
+                               eps1, part, B, 16, 16);
+        else if (nchunk <= 160)
+            hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false, 2>), dim3((unsigned)nchunk, 2), dim3(512), 0, st, scratch,
+                               eps1, part, B, 16, 16);
+        else
+            hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false>), dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1,
+                               part, B, 16, 16);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c32");
     } else if (d->c_in == 1 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->h == 16 &&
                d->w == 16) {                                   // first layer of radio_ml_conv.yaml: MFMA, two column tiles

@@ -523,7 +523,9 @@ def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
 
 @pytest.mark.parametrize("cin,cout,out_layer,hw,B", [(1, 8, False, (128, 128), 2), (3, 4, True, (128, 128), 2),
                                                      (32, 32, False, (32, 48), 2), (32, 32, True, (128, 128), 2),
-                                                     (1, 32, False, (16, 16), 300), (32, 32, True, (16, 16), 5)])
+                                                     (1, 32, False, (16, 16), 300), (32, 32, True, (16, 16), 5),
+                                                     (32, 32, False, (16, 16), 70), (32, 32, False, (16, 16), 130),
+                                                     (32, 32, True, (16, 16), 300)])
 def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
     """dcll_conv_lif_backward on large planes incl. the argparse default 128x128 (train.py:40-41): the generic
     weight-gradient kernel stages the eps1 plane in LDS in row bands (two bands at 128 rows), the 32 -> 32 layers use the
@@ -533,7 +535,8 @@ def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
     from oracle import torch_ref as R
     rng = np.random.RandomState(17)
     # 32 -> 32 layers: the MFMA weight-gradient kernel over 16x16 tiles with their real halo; the two 16x16 cases: the
-    # first layer's two-tile MFMA kernel k_bwd_wgrad_c1 (300 samples over 256 workgroups) and k_bwd_wgrad_c32
+    # first layer's two-tile MFMA kernel k_bwd_wgrad_c1 (300 samples over 256 workgroups) and k_bwd_wgrad_c32 with a
+    # sample's column tiles over 6 / 3 / 2 / 1 workgroups (B = 5 / 70 / 130 / 300)
     Wn, bn, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout, gain=3.0)
     sdn = _sd_from(Wn, bn, alpha, tau_m, alphas, tau_s, hw, rng=rng)
     K = cout * hw[0] * hw[1]
