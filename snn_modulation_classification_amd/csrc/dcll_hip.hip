@@ -189,25 +189,14 @@ __global__ __launch_bounds__(256) void k_conv_lif_tiled(dcll_conv_desc d, int ch
                 win[0][ky * KW + kx] = in[0][(ly + ky) * IW + lx + kx];
                 win[1][ky * KW + kx] = in[1][(ly + ky) * IW + lx + kx];
             }
-        if (2 * cp + 1 < d.c_in) {
 #pragma unroll
-            for (int c = 0; c < COG; ++c) {
-                const f32x2 *wp = (const f32x2 *)(wl + c * KK * 2);
+        for (int c = 0; c < COG; ++c) {
+            const f32x2 *wp = (const f32x2 *)(wl + c * KK * 2);
 #pragma unroll
-                for (int tap = 0; tap < KK; ++tap) {
-                    const f32x2 w2 = wp[tap];
-                    acc[c] = __builtin_fmaf(win[0][tap], w2[0], acc[c]);
-                    acc[c] = __builtin_fmaf(win[1][tap], w2[1], acc[c]);
-                }
-            }
-        } else {
-            // odd c_in (the first layer: one input channel): the pair's second member does not exist; its terms
-            // fmaf(0, 0, acc) are left out — acc is unchanged by them (but for the sign of an exact zero)
-#pragma unroll
-            for (int c = 0; c < COG; ++c) {
-                const float *wp = wl + c * KK * 2;
-#pragma unroll
-                for (int tap = 0; tap < KK; ++tap) acc[c] = __builtin_fmaf(win[0][tap], wp[2 * tap], acc[c]);
+            for (int tap = 0; tap < KK; ++tap) {
+                const f32x2 w2 = wp[tap];
+                acc[c] = __builtin_fmaf(win[0][tap], w2[0], acc[c]);
+                acc[c] = __builtin_fmaf(win[1][tap], w2[1], acc[c]);
             }
         }
     }
@@ -2127,6 +2116,85 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_lif_step_c1 — ONE timestep of the first layer (c_in = 1 -> c_out <= 32 channels, 7x7 pad 3, 16x16 plane, pool 1)
+// for the per-step drop-in and the forward of a learning step: the MFMA form of k_lif_seq_c1 (25 MFMAs per 32-pixel tile,
+// taps paired over the k lanes in their pinned linear order, the pad tap with weight 0) on a dense fp32 input map and
+// dense s / pv / v outputs, state through HBM.  One 256-thread workgroup per sample (thread = pixel of the traces, wave w
+// = image rows 4w..4w+3 = two tiles).  The kernel is bound by its maps (160 KB per sample); the generic pair
+// k_trace + k_conv_lif_tiled it replaces ran 98 VALU FMAs per output with LDS weight broadcasts (41 us at B = 512).
+// ------------------------------------------------------------------------------------------------------------
+template <bool REFRACTORY>
+__global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__restrict__ x, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, const float *__restrict__ alpha,
+                                                      const float *__restrict__ tau_m, const float *__restrict__ alphas,
+                                                      const float *__restrict__ tau_s, int tau_is_tensor,
+                                                      float *__restrict__ eps0_g, float *__restrict__ eps1_g,
+                                                      float *__restrict__ arp_g, float *__restrict__ out_s,
+                                                      float *__restrict__ out_pv, float *__restrict__ out_v,
+                                                      float alpharp, float wrp)
+{
+    constexpr int PS = 24;                      // plane row stride: 16 + 2*3 padding + the pad tap's column
+    __shared__ float plane[22 * PS + 8];
+    __shared__ float sbias[32];
+    const long b = blockIdx.x;
+    const int pix = threadIdx.x, y = pix >> 4, xx = pix & 15, lane = pix & 63;
+    const int w = __builtin_amdgcn_readfirstlane(pix >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    for (int i = pix; i < 22 * PS + 8; i += 256) plane[i] = 0.0f;
+    if (pix < 32) sbias[pix] = pix < c_out ? bias[pix] : 0.0f;
+    const int ti = tau_is_tensor ? pix : 0;
+    float e0 = eps0_g[b * 256 + pix], e1 = eps1_g[b * 256 + pix];
+    const float xin = x[b * 256 + pix];
+    const float al = alpha[ti], tm = tau_m[ti], as = alphas[ti], ts = tau_s[ti];
+    // weight fragments: pair p: lane (co = j, tap = 2p + h); the pad tap and channels >= c_out carry 0
+    float wf[25];
+#pragma unroll
+    for (int p = 0; p < 25; ++p) {
+        const int tap = 2 * p + h;
+        wf[p] = (tap < 49 && j < c_out) ? W[j * 49 + tap] : 0.0f;
+    }
+    __syncthreads();                            // plane zeroed
+    trace_update(xin, al, tm, as, ts, e0, e1);  // dcll/pytorch_libdcll.py:493-494
+    eps0_g[b * 256 + pix] = e0;
+    eps1_g[b * 256 + pix] = e1;
+    plane[(y + 3) * PS + xx + 3] = e1;
+    __syncthreads();
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+        const int m = 2 * w + tl;
+        const float *bn = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h;               // second tap: + 1
+        const float *bx = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h * (PS - 6);    // ... or the next row's first
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int p = 0; p < 25; ++p) {
+            const int tap = 2 * p, off = (tap / 7) * PS + tap % 7;
+            const bool cross = (tap % 7 == 6) && p < 24;        // p = 24: the partner is the pad tap (weight 0)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[p], cross ? bx[off] : bn[off], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co >= c_out) continue;
+            const long o = (b * c_out + co) * 256 + 32 * m + j;
+            float v = acc[r];
+            bool s;
+            if (REFRACTORY) {
+                float ar = arp_g[o];
+                v = refractory(acc[r], ar, alpharp, wrp, s);
+                arp_g[o] = ar;
+            } else {
+                s = v > 0.0f;
+            }
+            out_s[o] = s ? 1.0f : 0.0f;
+            out_pv[o] = sigmoidf_dev(v);
+            if (out_v) out_v[o] = v;
+        }
+    }
+}
+
 extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
                                   const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
                                   float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
@@ -2147,16 +2215,24 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const long per = (long)d->c_in * d->h * d->w, nin = per * B;
     const long nconv = (long)B * d->c_out * ch * cw, npool = (long)B * d->c_out * ph * pw;
     const int K = d->c_out * ph * pw;
-    if (d->c_in == 32 && d->c_out == 32 && d->h == 16 && d->w == 16 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 &&
-        d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b) {
+    const bool plane16 = d->h == 16 && d->w == 16 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 &&
+                         d->pool_h == 1 && d->pool_w == 1 && b;
+    if ((d->c_in == 32 && d->c_out == 32 && plane16) || (d->c_in == 1 && d->c_out <= 32 && plane16)) {
         // the whole layer step in one MFMA kernel (traces, conv in the pinned order, refractory, threshold, sigmoid)
-        if (d->refractory)
+        if (d->c_in == 1) {
+            if (d->refractory)
+                hipLaunchKernelGGL(k_lif_step_c1<true>, dim3(B), dim3(256), 0, st, d->c_out, x, W, b, alpha, tau_m, alphas,
+                                   tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
+            else
+                hipLaunchKernelGGL(k_lif_step_c1<false>, dim3(B), dim3(256), 0, st, d->c_out, x, W, b, alpha, tau_m, alphas,
+                                   tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
+        } else if (d->refractory)
             hipLaunchKernelGGL(k_lif_step_c32<true>, dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
                                d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
         else
             hipLaunchKernelGGL(k_lif_step_c32<false>, dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
                                d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
-        HIP_CHECK_LAUNCH("k_lif_step_c32");
+        HIP_CHECK_LAUNCH("k_lif_step_c32 / k_lif_step_c1");
         if (i2o_W && out_p) {
             rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
             if (rc) return rc;
