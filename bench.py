@@ -52,6 +52,41 @@ def build_net(batch, device):
     return net, convs
 
 
+def per_step_paths(dev, batch=512, steps=48):
+    """The reference's per-timestep protocol on the same network, reported beside the headline (not part of `value`):
+    `net.test(x[t])` (test_radio_ml.py:142-146) and `net.learn(x[t], labels)` (train.py:249-251: SmoothL1Loss, Adam
+    betas (0, .95), weight_decay 10) at the reference scripts' batch 512, wall time per timestep over `steps` steps after
+    the burn-in / warm-up (HIP kernels only in the loop; the learning step replays its captured hipGraph)."""
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(args, (1, R, R), batch, convs, N_CLASSES, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                      opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0},
+                      learning_rates=[2.5e-10], burnin=2)
+    net.reset(True)
+    n = steps + 8
+    x = torch.zeros(n, batch, 1, R * R, device=dev)
+    x.scatter_(3, torch.randint(0, R * R, (n, batch), device=dev)[:, :, None, None], 1.0)
+    x = x.reshape(n, batch, 1, R, R)
+    y = torch.zeros(batch, N_CLASSES, device=dev)
+    y[torch.arange(batch), torch.randint(0, N_CLASSES, (batch,))] = 1
+    out = {"batch": batch, "timesteps_timed": steps}
+    for name, fn in (("test", lambda t: net.test(x[t])), ("learn", lambda t: net.learn(x[t], y))):
+        net.reset()
+        for t in range(8):                     # (learn: burn-in, two eager learning steps, the graph capture)
+            fn(t)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for t in range(8, n):
+            fn(t)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        out[name + "_ms_per_timestep"] = 1e3 * dt
+        out[name + "_windows_per_s_at_T128"] = batch / (dt * T_STEPS)
+    return out
+
+
 def bench_ref_network(a):
     """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code, so
     parity is unpinned): radio_ml_conv_ref.yaml — 7 x (64 channels, (1,3) kernels, (1,2) pooling) — on a Q=16 x I=128 I/Q
@@ -233,6 +268,9 @@ def main():
     ap.add_argument("--overlap-readout", type=int, default=None,
                     help="1: readouts / statistics / votes on a second stream under the next layer's kernel "
                          "(default: DCLL_OVERLAP_READOUT)")
+    ap.add_argument("--per-step", type=int, default=1,
+                    help="1 (default, N=1 only): also time the per-timestep protocol net.test / net.learn at batch 512 and "
+                         "report it as `per_step_paths` (a second or two; not part of `value`)")
     ap.add_argument("--network", default="radio", choices=["radio", "ref"],
                     help="radio = radio_ml_conv.yaml (headline); ref = radio_ml_conv_ref.yaml with int8 weights (config 5)")
     a = ap.parse_args()
@@ -376,6 +414,8 @@ def main():
                 "bytes_per_launch": pv_bytes, "ms": kernel_ms["readout"], "GBps": pv_bytes / kernel_ms["readout"] / 1e6,
                 "frac_of_peak": pv_bytes / kernel_ms["readout"] / 1e6 / PEAK_HBM_GBS}
         out["hbm_bound_kernels"] = hb
+        if world == 1 and R == 16 and a.per_step:
+            out["per_step_paths"] = per_step_paths(dev)
         if world == 1 and a.cpu_windows > 0:
             cells = enc(iq, T_STEPS, t0=0)          # the same quantisation as a separate kernel, for the CPU leg
             out["cpu_baseline"] = cpu_baseline(net, convs, cells.cpu(), res["vote"][-1].cpu().numpy(),

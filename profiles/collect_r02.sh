@@ -19,12 +19,12 @@ OUT=$PWD/gpurun_out/r02prof_b$B
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py --steps 10 --warmup 2 --batch $B > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --steps 4 --warmup 1 --batch $B --cpu-windows 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --steps 4 --warmup 1 --batch $B --cpu-windows 0 --per-step 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_LDS"; do
     i=$((i+1))
-    rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -o p -- python3 bench.py --steps 1 --warmup 0 --batch $B --cpu-windows 0 > /dev/null 2> "$OUT/pmc$i.err"
+    rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -o p -- python3 bench.py --steps 1 --warmup 0 --batch $B --cpu-windows 0 --per-step 0 > /dev/null 2> "$OUT/pmc$i.err"
     echo "pmc pass $i done" >&2
 done
 python3 experiments/pmc_summary.py "$OUT/pmc.json" "$OUT/pmc1" "$OUT/pmc2" "$OUT/pmc3" "$OUT/pmc4" > "$OUT/pmc_summary.txt"
