@@ -213,6 +213,51 @@ def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
     assert 0.01 < spk_d[1:].mean() < 0.9, "degenerate test: spikes all equal"
 
 
+@pytest.mark.parametrize("wrp,cout,scalar_tau,B", [(1.0, 32, False, 5), (0.0, 32, True, 3), (1.0, 8, True, 4),
+                                                   (0.0, 20, False, 2), (1.0, 32, False, 300)])
+def test_first_layer_step_mfma_vs_oracle(dev, wrp, cout, scalar_tau, B):
+    """k_lif_step_c1 (the per-step forward of a 1 -> c_out <= 32 layer on the 16x16 plane, behind dcll_conv_lif_step) ==
+    C oracle stepping bit for bit over several steps from a non-zero state — arbitrary fp32 input maps (not only one-hot
+    planes), (1,H,W) tensor or scalar time constants, fewer than 32 channels, both variants, logits through the readout."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(23)
+    hw = (16, 16)
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 1, cout, gain=3.0)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    if scalar_tau:
+        for k, a in (("i2h.alpha", alpha), ("i2h.tau_m__dt", tau_m), ("i2h.alphas", alphas), ("i2h.tau_s__dt", tau_s)):
+            sd[k] = a[:1].copy()
+    orc = C.OracleConvLayer(sd, hw, 3, 1, wrp)
+    orc.init_state(B)
+    orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape) * (rng.uniform(size=orc.state[0].shape) < 0.3)
+    orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape) * (rng.uniform(size=orc.state[1].shape) < 0.3)
+    if wrp > 0:
+        orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+    d = ops.make_conv_desc(1, cout, hw, 7, 3, 1, 24, False, not scalar_tau, wrp)
+    t = {k: cu(v, dev) for k, v in sd.items()}
+    eps0, eps1 = cu(orc.state[0].copy(), dev), cu(orc.state[1].copy(), dev)
+    arp = cu(orc.state[2].copy(), dev) if wrp > 0 else torch.zeros((B, cout, 16, 16), device=dev)
+    n_spk = 0
+    for step in range(4):
+        x = (rng.uniform(0, 2, size=(B, 1, 16, 16)) * (rng.uniform(size=(B, 1, 16, 16)) < 0.2)).astype(np.float32)
+        if step == 0:
+            x[0, 0, 0, 0], x[0, 0, 15, 15] = 1.0, 1.0
+        s, p, o, pv, v = ops.conv_lif_step(d, cu(x, dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
+                                           t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1, arp,
+                                           t["i2o.weight"], t["i2o.bias"])
+        oo, op, opv, ov, os_ = orc.forward(x)
+        assert bits_equal(eps0.cpu().numpy(), orc.state[0]) and bits_equal(eps1.cpu().numpy(), orc.state[1])
+        assert bits_equal(v.cpu().numpy(), ov), (step, np.abs(v.cpu().numpy() - ov).max())
+        assert np.array_equal(s.cpu().numpy(), os_)
+        if wrp > 0:
+            assert bits_equal(arp.cpu().numpy(), orc.state[2])
+        np.testing.assert_allclose(pv.cpu().numpy(), opv, atol=PV_TOL, rtol=0)
+        np.testing.assert_allclose(p.cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
+        n_spk += int(os_.sum())
+    assert n_spk > 0, "degenerate test: no spikes"
+
+
 @pytest.mark.parametrize("wrp,cout,hw", [(1.0, 32, (16, 16)), (0.0, 32, (16, 16)), (1.0, 8, (16, 16)),
                                          (1.0, 32, (32, 32)), (0.0, 8, (24, 64)), (1.0, 32, (128, 128))])
 def test_sequence_c1_vs_oracle(dev, wrp, cout, hw):
