@@ -2117,6 +2117,169 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_lif_step_c32t — k_lif_step_c32 for planes larger than 16x16 (h % 16 == 0, w % 16 == 0; the reference's argparse
+// default is 128x128): one workgroup per 16x16 tile of a sample, the same pair of MFMA tiles per wave, the same weight
+// chunks through LDS.  Differences: the eps1 image is staged per channel PAIR (the 22x22 region of the tile with its real
+// halo, zero outside the plane; double-buffered with the weight chunk: 7.7 + 25.5 KB of LDS instead of the whole
+// 32-channel image), and the traces are read from a SNAPSHOT of the state taken before the launch (eps0_old / eps1_old):
+// a tile recomputes the new eps1 of its halo pixels, which a neighbouring workgroup owns and may already have written —
+// only interior pixels are stored.  (Before: the all-T kernel k_lif_seq_c32t at T = 1 with pack / unpack around it,
+// 1.63 + 0.13 ms per layer step at B = 64 on the 128x128 plane.)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int ST_RF = 22, ST_CF = 22 * 22, ST_PAIR = 2 * ST_CF;     // region row stride, floats per channel / per pair
+template <bool REFRACTORY>
+__global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__ x, const float *__restrict__ W,
+                                                        const float *__restrict__ bias, const float *__restrict__ alpha,
+                                                        const float *__restrict__ tau_m, const float *__restrict__ alphas,
+                                                        const float *__restrict__ tau_s, int tau_is_tensor,
+                                                        const float *__restrict__ eps0_old,
+                                                        const float *__restrict__ eps1_old, float *__restrict__ eps0_g,
+                                                        float *__restrict__ eps1_g, float *__restrict__ arp_g,
+                                                        float *__restrict__ out_s, float *__restrict__ out_pv,
+                                                        float *__restrict__ out_v, int H, int Wd, float alpharp, float wrp)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * ST_PAIR + 2 * STEP_WCH + 32];
+    float *img = lds, *wch = lds + 2 * ST_PAIR, *sbias = wch + 2 * STEP_WCH;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // my tile pair: tile rows 4w..4w+3
+    const int tpr = Wd >> 4, tps = (H >> 4) * tpr;               // 16x16 tiles per row / per sample
+    const long b = blockIdx.x / tps;
+    const int tile = blockIdx.x % tps, y0 = (tile / tpr) * 16, x0 = (tile % tpr) * 16;
+    const long HW = (long)H * Wd;
+    if (tid < 32) sbias[tid] = bias[tid];
+    // weight chunks exactly as in k_lif_step_c32
+    constexpr int NW = 13;
+    float wreg[NW];
+    int goff[NW], loff[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
+        goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
+        loff[i] = (r % 49) * STEP_WTS + (r / 49) * 32 + co;
+    }
+    auto fetch_w = [&](int cp) {
+        const float *wc = W + cp * 98;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wreg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
+    };
+    // traces of one channel pair over the tile's 22x22 region: element e = tid + 256 i of the 2 x 484
+    constexpr int NT = 4;
+    int toff[NT];               // offset inside a channel plane, -1: outside the plane (zero padding) or no element
+    int tl[NT];                 // LDS offset inside the pair buffer
+    bool town[NT];              // interior pixel: this workgroup owns its state
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int e = tid + 256 * i, r = e % ST_CF, ry = r / ST_RF, rx = r % ST_RF;
+        const int gy = y0 + ry - 3, gx = x0 + rx - 3;
+        const bool in = e < ST_PAIR && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
+        toff[i] = in ? gy * Wd + gx : -1;
+        tl[i] = e < ST_PAIR ? e : -1;
+        town[i] = in && ry >= 3 && ry < 19 && rx >= 3 && rx < 19;
+    }
+    float tx[NT], te0[NT], te1[NT], ta[NT], ttm[NT], tas[NT], tts[NT];
+    auto fetch_t = [&](int cp) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (toff[i] < 0) continue;
+            const int c = 2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0);
+            const long gidx = (b * 32 + c) * HW + toff[i];
+            const long ti = tau_is_tensor ? c * HW + toff[i] : 0;
+            tx[i] = x[gidx];
+            te0[i] = eps0_old[gidx];
+            te1[i] = eps1_old[gidx];
+            ta[i] = alpha[ti];
+            ttm[i] = tau_m[ti];
+            tas[i] = alphas[ti];
+            tts[i] = tau_s[ti];
+        }
+    };
+    auto finish_t = [&](int cp) {
+        float *dst = img + (cp & 1) * ST_PAIR;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (tl[i] < 0) continue;
+            float e1 = 0.0f;
+            if (toff[i] >= 0) {
+                trace_update(tx[i], ta[i], ttm[i], tas[i], tts[i], te0[i], te1[i]);
+                e1 = te1[i];
+                if (town[i]) {
+                    const int c = 2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0);
+                    const long gidx = (b * 32 + c) * HW + toff[i];
+                    eps0_g[gidx] = te0[i];
+                    eps1_g[gidx] = e1;
+                }
+            }
+            dst[tl[i]] = e1;
+        }
+    };
+    fetch_w(0);
+    fetch_t(0);
+    finish_t(0);
+    store_w(0);
+    __syncthreads();        // channel pair 0 of the image, bias and chunk 0 in place
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
+    const int bbase = h * ST_CF + ((j >> 4) + 4 * w) * ST_RF + (j & 15);
+    for (int cp = 0; cp < 16; ++cp) {
+        if (cp + 1 < 16) {                                 // land during the MFMAs below
+            fetch_w(cp + 1);
+            fetch_t(cp + 1);
+        }
+        const float *wa = wch + (cp & 1) * STEP_WCH + lane;
+        const float *ib = img + (cp & 1) * ST_PAIR + bbase;
+        float wr[3][7];
+#pragma unroll
+        for (int rho = 0; rho < 9; ++rho) {
+            float bq[7];
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) bq[kx] = ib[rho * ST_RF + kx];
+            if (rho <= 6) {
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[(rho * 7 + kx) * STEP_WTS];
+            }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                if (rho <= 6) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[rho % 3][kx], bq[kx], accA, 0, 0, 0);
+                if (rho >= 2) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[(rho - 2) % 3][kx], bq[kx], accB, 0, 0, 0);
+            }
+        }
+        if (cp + 1 < 16) {
+            store_w((cp + 1) & 1);                         // the other buffers: nobody reads them in this iteration
+            finish_t(cp + 1);
+        }
+        __syncthreads();
+    }
+    // epilogue of my two MFMA tiles: channel (r&3) + 8(r>>2) + 4h, tile pixel 32(2w + tl) + j
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int p = 32 * (2 * w + tq) + j;
+            const long o = (b * 32 + co) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15);
+            const float pvm = tq ? accB[r] : accA[r];
+            float v = pvm;
+            bool s;
+            if (REFRACTORY) {
+                float ar = arp_g[o];
+                v = refractory(pvm, ar, alpharp, wrp, s);
+                arp_g[o] = ar;
+            } else {
+                s = v > 0.0f;
+            }
+            out_s[o] = s ? 1.0f : 0.0f;
+            out_pv[o] = sigmoidf_dev(v);
+            if (out_v) out_v[o] = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_lif_step_c1 — ONE timestep of the first layer (c_in = 1 -> c_out <= 32 channels, 7x7 pad 3, 16x16 plane, pool 1)
 // for the per-step drop-in and the forward of a learning step: the MFMA form of k_lif_seq_c1 (25 MFMAs per 32-pixel tile,
 // taps paired over the k lanes in their pinned linear order, the pad tap with weight 0) on a dense fp32 input map and
@@ -2215,8 +2378,38 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const long per = (long)d->c_in * d->h * d->w, nin = per * B;
     const long nconv = (long)B * d->c_out * ch * cw, npool = (long)B * d->c_out * ph * pw;
     const int K = d->c_out * ph * pw;
-    const bool plane16 = d->h == 16 && d->w == 16 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 &&
-                         d->pool_h == 1 && d->pool_w == 1 && b;
+    const bool k7 = d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b;
+    const bool plane16 = d->h == 16 && d->w == 16 && k7;
+    if (d->c_in == 32 && d->c_out == 32 && k7 && !plane16 && d->h % 16 == 0 && d->w % 16 == 0 && scratch) {
+        // larger planes: one workgroup per 16x16 tile; the traces are read from a snapshot (a tile recomputes its halo)
+        const size_t nbytes = (size_t)nin * sizeof(float);
+        if (hipMemcpyAsync(scratch, eps0, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(scratch + nin, eps1, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(DCLL_ERR_LAUNCH, "dcll_conv_lif_step: state snapshot copy failed");
+        }
+        const long njob = (long)B * (d->h / 16) * (d->w / 16);
+        if (njob > 0x7fffffffL) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_step: more than 2^31 tiles");
+        if (d->refractory)
+            hipLaunchKernelGGL(k_lif_step_c32t<true>, dim3((unsigned)njob), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas,
+                               tau_s, d->tau_is_tensor, scratch, scratch + nin, eps0, eps1, arp, out_s, out_pv, out_v,
+                               d->h, d->w, d->alpharp, d->wrp);
+        else
+            hipLaunchKernelGGL(k_lif_step_c32t<false>, dim3((unsigned)njob), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas,
+                               tau_s, d->tau_is_tensor, scratch, scratch + nin, eps0, eps1, arp, out_s, out_pv, out_v,
+                               d->h, d->w, d->alpharp, d->wrp);
+        HIP_CHECK_LAUNCH("k_lif_step_c32t");
+        if (i2o_W && out_p) {
+            rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
+            if (rc) return rc;
+        }
+        if (d->output_layer) {
+            if (!out_W || !out_o) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: output layer needs out_W and out_o");
+            rc = launch_readout(out_pv, out_W, out_b, out_o, B, K, d->target, st);
+            if (rc) return rc;
+        }
+        return DCLL_OK;
+    }
     if ((d->c_in == 32 && d->c_out == 32 && plane16) || (d->c_in == 1 && d->c_out <= 32 && plane16)) {
         // the whole layer step in one MFMA kernel (traces, conv in the pinned order, refractory, threshold, sigmoid)
         if (d->c_in == 1) {

@@ -250,44 +250,12 @@ class ContinuousConv2D(nn.Module):
                               output_ is not None)
         st = self.state
         arp = st.arp if len(st) > 2 else None
-        if getattr(self, 'binary_input', False) and self._fast_step_ok(input, pooling):
-            return self._step_packed(desc, input, st, arp, i2o, output_)
         with torch.no_grad():
             return ops.conv_lif_step(
                 desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt,
                 st.eps0, st.eps1, arp,
                 None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
                 None if output_ is None else output_.weight, None if output_ is None else output_.bias, out=out)
-
-    def _fast_step_ok(self, input, pooling):
-        """32->32, 7x7 pad 3, pool 1, per-channel time constants, on a plane with H % 8 == 0 and W % 32 == 0: the tiled
-        MFMA sequence kernel (k_lif_seq_c32t) serves one step.  (On the 16x16 plane dcll_conv_lif_step itself runs the
-        single-step MFMA kernel k_lif_step_c32 for any fp32 input.  The (1,3) layers of radio_ml_conv_ref.yaml stay on
-        the generic per-step kernels: k_lif_seq_w3 at T = 1 with pack / unpack around it was measured SLOWER — 869 vs
-        1211 windows/s at B = 256 — its per-launch set-up of 96 weight registers per wave and the state round trip
-        outweigh a K = 192 chain.)"""
-        H, W = tuple(input.shape[2:4])
-        return (self.in_channels == 32 and self.out_channels == 32 and self.kernel_size == (7, 7) and
-                self.padding == (3, 3) and (H % 8 == 0 and W % 32 == 0) and
-                tuple(pooling) == (1, 1) and self.stride == 1 and self.dilation == 1 and self.groups == 1 and
-                self.bias is not None and self.tau_per_channel() is not None)
-
-    def _step_packed(self, desc, input, st, arp, i2o, output_):
-        """One step through a weight-stationary MFMA sequence kernel (T = 1, state in HBM) for layers whose input is
-        known to be a binary spike map (`binary_input`, set by ConvNetwork for every layer fed by another layer): bit-pack
-        -> k_lif_seq_c32t / k_lif_seq_w3 -> unpack; bit-identical to the generic per-step kernels."""
-        B, C, H, W = input.shape
-        _, _, ph, pw = ops.conv_out_shape(desc)
-        with torch.no_grad():
-            spk_in = ops.pack_spikes(input.reshape(B, C, H * W)).reshape(1, B, C, H * W // 32)
-            spk, pv, v = ops.conv_lif_sequence(desc, spk_in, self.weight, self.bias, self.tau_per_channel(), st.eps0,
-                                               st.eps1, arp, 1, B, want_v=True)
-            s = ops.unpack_spikes(spk.reshape(B, self.out_channels, ph * pw // 32)).reshape(B, self.out_channels, ph, pw)
-            pv, v = pv[0], v[0]
-            flat = pv.reshape(B, -1)
-            p = ops.readout(flat, i2o.weight, i2o.bias) if i2o is not None else None
-            o = ops.readout(flat, output_.weight, output_.bias) if output_ is not None else None
-        return s, p, o, pv, v
 
     def forward(self, input):
         """-> (output spikes, pv, pvmem), un-pooled (reference :407-426)."""

@@ -51,9 +51,6 @@ class ConvNetwork(torch.nn.Module):
                                     alpha=args.alpha, alphas=args.alphas, alpharp=args.alpharp, wrp=args.arp,
                                     act=act, lc_ampl=args.lc_ampl, random_tau=args.random_tau, spiking=True,
                                     lc_dropout=False, output_layer=last).to(dev).init_hiddens(batch_size)
-            # layers fed by another layer only ever see binary spike maps: lets their per-step forward use the
-            # bit-packed MFMA kernel (the first layer takes whatever the caller passes and stays on the generic path)
-            layer.i2h.binary_input = (i > 0)
             shape = (layer.out_channels,) + tuple(layer.output_shape)
             layer_opt = dict(opt_param)
             if learning_rates is not None:

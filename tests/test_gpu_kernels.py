@@ -213,6 +213,62 @@ def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
     assert 0.01 < spk_d[1:].mean() < 0.9, "degenerate test: spikes all equal"
 
 
+@pytest.mark.parametrize("wrp,hw,scalar_tau,B", [(1.0, (32, 48), False, 3), (0.0, (16, 32), True, 2),
+                                                 (1.0, (128, 128), False, 2), (0.0, (48, 16), False, 5)])
+def test_tiled_step_mfma_vs_oracle(dev, wrp, hw, scalar_tau, B):
+    """k_lif_step_c32t (per-step forward of a 32 -> 32 layer on planes of several 16x16 tiles, incl. the argparse default
+    128x128; behind dcll_conv_lif_step) == C oracle stepping bit for bit over several steps from a non-zero state: every
+    tile recomputes the traces of its halo from the snapshot and stores only its interior — state, v and spikes must
+    agree everywhere, in particular along the tile borders; arbitrary fp32 input; a second call without the scratch runs
+    the generic kernels and must give the same bits."""
+    import ctypes
+    from snn_modulation_classification_amd import ops, _lib as lib
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(29)
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
+    sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    if scalar_tau:
+        for k, a in (("i2h.alpha", alpha), ("i2h.tau_m__dt", tau_m), ("i2h.alphas", alphas), ("i2h.tau_s__dt", tau_s)):
+            sd[k] = a[:1].copy()
+    orc = C.OracleConvLayer(sd, hw, 3, 1, wrp)
+    orc.init_state(B)
+    orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape) * (rng.uniform(size=orc.state[0].shape) < 0.3)
+    orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape) * (rng.uniform(size=orc.state[1].shape) < 0.3)
+    if wrp > 0:
+        orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+    d = ops.make_conv_desc(32, 32, hw, 7, 3, 1, 24, False, not scalar_tau, wrp)
+    t = {k: cu(v, dev) for k, v in sd.items()}
+    eps0, eps1 = cu(orc.state[0].copy(), dev), cu(orc.state[1].copy(), dev)
+    arp = cu(orc.state[2].copy(), dev) if wrp > 0 else torch.zeros((B, 32) + hw, device=dev)
+    n_spk = 0
+    for step in range(3):
+        x = ((rng.uniform(size=(B, 32) + hw) < 0.15) * rng.choice([1.0, 1.0, 0.5], size=(B, 32) + hw)).astype(np.float32)
+        if step == 1:       # the same step through the generic kernels (no scratch -> no tiled kernel) on a copy
+            e0c, e1c, arc = eps0.clone(), eps1.clone(), arp.clone()
+            sg, pvg, vg = (torch.empty((B, 32) + hw, device=dev) for _ in range(3))
+            rc = lib.get().dcll_conv_lif_step(ctypes.byref(d), lib.ptr(cu(x, dev)), lib.ptr(t["i2h.weight"]),
+                                              lib.ptr(t["i2h.bias"]), lib.ptr(t["i2h.alpha"]), lib.ptr(t["i2h.tau_m__dt"]),
+                                              lib.ptr(t["i2h.alphas"]), lib.ptr(t["i2h.tau_s__dt"]), lib.ptr(e0c),
+                                              lib.ptr(e1c), lib.ptr(arc), None, None, None, None, lib.ptr(sg), None, None,
+                                              lib.ptr(pvg), lib.ptr(vg), None, B, lib.stream_ptr())
+            assert rc == 0
+        s, p, o, pv, v = ops.conv_lif_step(d, cu(x, dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
+                                           t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1, arp,
+                                           t["i2o.weight"], t["i2o.bias"])
+        oo, op, opv, ov, os_ = orc.forward(x)
+        assert bits_equal(eps0.cpu().numpy(), orc.state[0]) and bits_equal(eps1.cpu().numpy(), orc.state[1])
+        assert bits_equal(v.cpu().numpy(), ov), (step, np.abs(v.cpu().numpy() - ov).max())
+        assert np.array_equal(s.cpu().numpy(), os_)
+        if wrp > 0:
+            assert bits_equal(arp.cpu().numpy(), orc.state[2])
+        np.testing.assert_allclose(pv.cpu().numpy(), opv, atol=PV_TOL, rtol=0)
+        np.testing.assert_allclose(p.cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
+        if step == 1:
+            assert torch.equal(vg, v) and torch.equal(sg, s) and torch.equal(e1c, eps1) and torch.equal(e0c, eps0)
+        n_spk += int(os_.sum())
+    assert n_spk > 0, "degenerate test: no spikes"
+
+
 @pytest.mark.parametrize("wrp,cout,scalar_tau,B", [(1.0, 32, False, 5), (0.0, 32, True, 3), (1.0, 8, True, 4),
                                                    (0.0, 20, False, 2), (1.0, 32, False, 300)])
 def test_first_layer_step_mfma_vs_oracle(dev, wrp, cout, scalar_tau, B):
