@@ -524,26 +524,46 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
 // wave of a 128-thread workgroup; per sample g (32 x 256, row stride 257) and the zero-padded plane (row stride ROWF) are
 // staged in LDS.  Partial sums go to part[workgroup][co][49 + 1] (k_bwd_reduce adds them in order).  (The generic
 // k_bwd_wgrad needs 78 us for this layer at B = 512: 0.4 GFLOP spread over 2048 workgroups with a 49-value tree each.)
-constexpr int WG1_IMG = 432;        // >= (15 + 6) * ROWF + 15 + 6 + 1 + 1
+// TILED: planes of several 16x16 tiles (h % 16 == 0, w % 16 == 0) — one tile of a sample per job, its 22x22 eps1 region
+// with the real halo (zero outside the plane) staged at row stride 22 (the generic k_bwd_wgrad needs 637 us for this
+// layer on the 128x128 plane at B = 64).
+template <int RF, bool TILED>
 __global__ __launch_bounds__(128) void k_bwd_wgrad_c1(const float *__restrict__ gvf, const float *__restrict__ eps1,
-                                                       float *__restrict__ part, int B)
+                                                       float *__restrict__ part, int B, int H, int Wd)
 {
-    __shared__ __attribute__((aligned(16))) float lds[WG1_IMG + 32 * WG32_GLD];
-    float *img = lds, *gl = lds + WG1_IMG;
+    constexpr int IMG = (21 * RF + 21 + 2 + 3) & ~3;            // >= offset of (row 21, column 21) + 1 + the k lane
+    __shared__ __attribute__((aligned(16))) float lds[IMG + 32 * WG32_GLD];
+    float *img = lds, *gl = lds + IMG;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < WG1_IMG; i += 128) img[i] = 0.0f;
+    for (int i = tid; i < IMG; i += 128) img[i] = 0.0f;
     const int n = w * 32 + j;                                   // my column = tap index (valid below 49)
     const int tap = n < 49 ? n : 0;
-    const int bbase = (tap / 7) * ROWF + (tap % 7) + h;
+    const int bbase = (tap / 7) * RF + (tap % 7) + h;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     float bsum = 0.0f;                                          // wave w: co = 16 w + lane / 4, pixels lane % 4 + 4 k
-    for (long b = blockIdx.x; b < B; b += gridDim.x) {
+    const int tpr = Wd >> 4, tps = (H >> 4) * tpr;
+    const long njob = TILED ? (long)B * tps : B, HW = (long)H * Wd;
+    for (long job = blockIdx.x; job < njob; job += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < 32 * 256; i += 128) gl[(i >> 8) * WG32_GLD + (i & 255)] = gvf[b * 8192 + i];
-        for (int p = tid; p < 256; p += 128) img[((p >> 4) + 3) * ROWF + (p & 15) + 3] = eps1[b * 256 + p];
+        if (TILED) {
+            const long b = job / tps;
+            const int tile = (int)(job % tps), y0 = (tile / tpr) * 16, x0 = (tile % tpr) * 16;
+            for (int i = tid; i < 32 * 256; i += 128) {
+                const int c = i >> 8, p = i & 255;
+                gl[c * WG32_GLD + p] = gvf[(b * 32 + c) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15)];
+            }
+            for (int i = tid; i < 22 * 22; i += 128) {
+                const int ry = i / 22, rx = i % 22, gy = y0 + ry - 3, gx = x0 + rx - 3;
+                img[ry * RF + rx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd)
+                                        ? eps1[b * HW + (long)gy * Wd + gx] : 0.0f;
+            }
+        } else {
+            for (int i = tid; i < 32 * 256; i += 128) gl[(i >> 8) * WG32_GLD + (i & 255)] = gvf[job * 8192 + i];
+            for (int p = tid; p < 256; p += 128) img[((p >> 4) + 3) * RF + (p & 15) + 3] = eps1[job * 256 + p];
+        }
         __syncthreads();
         {
             const float *gr = gl + (16 * w + (lane >> 2)) * WG32_GLD + (lane & 3);
@@ -554,7 +574,7 @@ __global__ __launch_bounds__(128) void k_bwd_wgrad_c1(const float *__restrict__ 
 #pragma unroll 8
         for (int pp = 0; pp < 128; ++pp) {
             const int p = 2 * pp;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[p], img[bbase + (p >> 4) * ROWF + (p & 15)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[p], img[bbase + (p >> 4) * RF + (p & 15)], acc, 0, 0, 0);
         }
     }
     float *pw = part + (long)blockIdx.x * 32 * 50;
@@ -2673,8 +2693,17 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
                d->w == 16) {                                   // first layer of radio_ml_conv.yaml: MFMA, two column tiles
         if (nchunk > 512) nchunk = 512;
         if (nchunk > B) nchunk = B;
-        hipLaunchKernelGGL(k_bwd_wgrad_c1, dim3((unsigned)nchunk), dim3(128), 0, st, scratch, eps1, part, B);
+        hipLaunchKernelGGL((k_bwd_wgrad_c1<ROWF, false>), dim3((unsigned)nchunk), dim3(128), 0, st, scratch, eps1, part, B,
+                           16, 16);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c1");
+    } else if (d->c_in == 1 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 &&
+               d->h % 16 == 0 && d->w % 16 == 0) {             // first layer on large planes: one 16x16 tile per job
+        const long njob = (long)B * (d->h / 16) * (d->w / 16);
+        if (nchunk > 1024) nchunk = 1024;
+        if (nchunk > njob) nchunk = njob;
+        hipLaunchKernelGGL((k_bwd_wgrad_c1<22, true>), dim3((unsigned)nchunk), dim3(128), 0, st, scratch, eps1, part, B,
+                           d->h, d->w);
+        HIP_CHECK_LAUNCH("k_bwd_wgrad_c1 (tiled)");
     } else if (c32 && d->h % 16 == 0 && d->w % 16 == 0) {     // large planes: one 16x16 tile of a sample per job
         const long njob = (long)B * (d->h / 16) * (d->w / 16);
         if (nchunk > 256) nchunk = 256;

@@ -157,7 +157,7 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
     # tile jobs, so small batches still fill the chip); the same area then holds the batch chunks of the output_ gradient
     jobs = B * max(1, (desc.h // 16) * (desc.w // 16))
     per_chunk = desc.c_out * (desc.c_in * desc.kh * desc.kw + 1)
-    nchunk = min(jobs, 256)
+    nchunk = min(jobs, 1024 if desc.c_in == 1 else 256)      # (first layer: 128-thread workgroups, 6 KB partial rows)
     part = nchunk * per_chunk
     if want_out:
         part = max(part, min(B, 8) * desc.target * (K + 1))
