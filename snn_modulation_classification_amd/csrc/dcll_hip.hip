@@ -2146,8 +2146,11 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 // only interior pixels are stored.  (Before: the all-T kernel k_lif_seq_c32t at T = 1 with pack / unpack around it,
 // 1.63 + 0.13 ms per layer step at B = 64 on the 128x128 plane.)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int ST_RF = 22, ST_CF = 22 * 22, ST_PAIR = 2 * ST_CF;     // region row stride, floats per channel / per pair
-template <bool REFRACTORY>
+// TH = tile height: 16 (a wave = two MFMA tiles, image rows 4w..4w+3 of the tile) or 8 (a wave = one MFMA tile, rows 2w,
+// 2w+1): with 8-row tiles a 16x16 plane is TWO workgroups per sample — used when the batch has fewer samples than half
+// the CUs (one workgroup per sample runs 69 us however small the batch is).
+constexpr int ST_RF = 22;                                          // region row stride
+template <bool REFRACTORY, int TH>
 __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__ x, const float *__restrict__ W,
                                                         const float *__restrict__ bias, const float *__restrict__ alpha,
                                                         const float *__restrict__ tau_m, const float *__restrict__ alphas,
@@ -2158,13 +2161,14 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
                                                         float *__restrict__ out_s, float *__restrict__ out_pv,
                                                         float *__restrict__ out_v, int H, int Wd, float alpharp, float wrp)
 {
+    constexpr int ST_CF = (TH + 6) * ST_RF, ST_PAIR = 2 * ST_CF;   // floats per channel / per channel pair of the region
     __shared__ __attribute__((aligned(16))) float lds[2 * ST_PAIR + 2 * STEP_WCH + 32];
     float *img = lds, *wch = lds + 2 * ST_PAIR, *sbias = wch + 2 * STEP_WCH;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // my tile pair: tile rows 4w..4w+3
-    const int tpr = Wd >> 4, tps = (H >> 4) * tpr;               // 16x16 tiles per row / per sample
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // my MFMA tile(s): tile rows (TH/4) w ...
+    const int tpr = Wd >> 4, tps = (H / TH) * tpr;               // TH x 16 tiles per row / per sample
     const long b = blockIdx.x / tps;
-    const int tile = blockIdx.x % tps, y0 = (tile / tpr) * 16, x0 = (tile % tpr) * 16;
+    const int tile = blockIdx.x % tps, y0 = (tile / tpr) * TH, x0 = (tile % tpr) * 16;
     const long HW = (long)H * Wd;
     if (tid < 32) sbias[tid] = bias[tid];
     // weight chunks exactly as in k_lif_step_c32
@@ -2187,8 +2191,8 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
         for (int i = 0; i < NW; ++i)
             if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
     };
-    // traces of one channel pair over the tile's 22x22 region: element e = tid + 256 i of the 2 x 484
-    constexpr int NT = 4;
+    // traces of one channel pair over the tile's (TH+6) x 22 region: element e = tid + 256 i of the 2 x ST_CF
+    constexpr int NT = (ST_PAIR + 255) / 256;
     int toff[NT];               // offset inside a channel plane, -1: outside the plane (zero padding) or no element
     int tl[NT];                 // LDS offset inside the pair buffer
     bool town[NT];              // interior pixel: this workgroup owns its state
@@ -2199,7 +2203,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
         const bool in = e < ST_PAIR && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
         toff[i] = in ? gy * Wd + gx : -1;
         tl[i] = e < ST_PAIR ? e : -1;
-        town[i] = in && ry >= 3 && ry < 19 && rx >= 3 && rx < 19;
+        town[i] = in && ry >= 3 && ry < TH + 3 && rx >= 3 && rx < 19;
     }
     float tx[NT], te0[NT], te1[NT], ta[NT], ttm[NT], tas[NT], tts[NT];
     auto fetch_t = [&](int cp) {
@@ -2245,7 +2249,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
-    const int bbase = h * ST_CF + ((j >> 4) + 4 * w) * ST_RF + (j & 15);
+    const int bbase = h * ST_CF + ((j >> 4) + (TH / 4) * w) * ST_RF + (j & 15);
     for (int cp = 0; cp < 16; ++cp) {
         if (cp + 1 < 16) {                                 // land during the MFMAs below
             fetch_w(cp + 1);
@@ -2255,7 +2259,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
         const float *ib = img + (cp & 1) * ST_PAIR + bbase;
         float wr[3][7];
 #pragma unroll
-        for (int rho = 0; rho < 9; ++rho) {
+        for (int rho = 0; rho < (TH == 16 ? 9 : 7); ++rho) {
             float bq[7];
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) bq[kx] = ib[rho * ST_RF + kx];
@@ -2266,7 +2270,8 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
                 if (rho <= 6) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[rho % 3][kx], bq[kx], accA, 0, 0, 0);
-                if (rho >= 2) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[(rho - 2) % 3][kx], bq[kx], accB, 0, 0, 0);
+                if (TH == 16 && rho >= 2)
+                    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[(rho - 2) % 3][kx], bq[kx], accB, 0, 0, 0);
             }
         }
         if (cp + 1 < 16) {
@@ -2275,13 +2280,13 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
         }
         __syncthreads();
     }
-    // epilogue of my two MFMA tiles: channel (r&3) + 8(r>>2) + 4h, tile pixel 32(2w + tl) + j
+    // epilogue of my MFMA tile(s): channel (r&3) + 8(r>>2) + 4h, tile pixel 32((TH/8) w + tq) + j
 #pragma unroll
-    for (int tq = 0; tq < 2; ++tq)
+    for (int tq = 0; tq < TH / 8; ++tq)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int p = 32 * (2 * w + tq) + j;
+            const int p = 32 * ((TH / 8) * w + tq) + j;
             const long o = (b * 32 + co) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15);
             const float pvm = tq ? accB[r] : accA[r];
             float v = pvm;
@@ -2400,7 +2405,9 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const int K = d->c_out * ph * pw;
     const bool k7 = d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b;
     const bool plane16 = d->h == 16 && d->w == 16 && k7;
-    if (d->c_in == 32 && d->c_out == 32 && k7 && !plane16 && d->h % 16 == 0 && d->w % 16 == 0 && scratch) {
+    // (16x16 plane: two workgroups per sample — 8-row tiles — when the batch alone would leave half the CUs idle)
+    const bool split16 = plane16 && B <= 128;
+    if (d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16) && d->h % 16 == 0 && d->w % 16 == 0 && scratch) {
         // larger planes: one workgroup per 16x16 tile; the traces are read from a snapshot (a tile recomputes its halo)
         const size_t nbytes = (size_t)nin * sizeof(float);
         if (hipMemcpyAsync(scratch, eps0, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -2408,16 +2415,17 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
             (void)hipGetLastError();
             return fail(DCLL_ERR_LAUNCH, "dcll_conv_lif_step: state snapshot copy failed");
         }
-        const long njob = (long)B * (d->h / 16) * (d->w / 16);
+        const long njob = (long)B * (d->h / (split16 ? 8 : 16)) * (d->w / 16);
         if (njob > 0x7fffffffL) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_step: more than 2^31 tiles");
-        if (d->refractory)
-            hipLaunchKernelGGL(k_lif_step_c32t<true>, dim3((unsigned)njob), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas,
-                               tau_s, d->tau_is_tensor, scratch, scratch + nin, eps0, eps1, arp, out_s, out_pv, out_v,
-                               d->h, d->w, d->alpharp, d->wrp);
-        else
-            hipLaunchKernelGGL(k_lif_step_c32t<false>, dim3((unsigned)njob), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas,
-                               tau_s, d->tau_is_tensor, scratch, scratch + nin, eps0, eps1, arp, out_s, out_pv, out_v,
-                               d->h, d->w, d->alpharp, d->wrp);
+#define DCLL_STEP_T(R_, TH_) hipLaunchKernelGGL((k_lif_step_c32t<R_, TH_>), dim3((unsigned)njob), dim3(256), 0, st, x, W, b,    \
+                                                alpha, tau_m, alphas, tau_s, d->tau_is_tensor, scratch, scratch + nin, eps0,  \
+                                                eps1, arp, out_s, out_pv, out_v, d->h, d->w, d->alpharp, d->wrp)
+        if (split16) {
+            if (d->refractory) DCLL_STEP_T(true, 8); else DCLL_STEP_T(false, 8);
+        } else {
+            if (d->refractory) DCLL_STEP_T(true, 16); else DCLL_STEP_T(false, 16);
+        }
+#undef DCLL_STEP_T
         HIP_CHECK_LAUNCH("k_lif_step_c32t");
         if (i2o_W && out_p) {
             rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);

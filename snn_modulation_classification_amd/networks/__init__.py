@@ -62,6 +62,7 @@ class ConvNetwork(torch.nn.Module):
         # captured learning timesteps (hipGraph), per input shape; see _learn_graphed
         self.graph_learn = os.environ.get('DCLL_GRAPH_LEARN', '1') != '0'
         self._learn_graphs, self._learn_eager_steps, self._learn_last_key = {}, {}, None
+        self._test_graphs, self._test_eager_steps = {}, {}
         # largest pv buffer (one layer, all T steps) the sequence path allocates; bigger batches run in chunks
         self.pv_budget_bytes = float(os.environ.get('DCLL_PV_BUDGET_GB', '24')) * 2 ** 30
 
@@ -148,7 +149,14 @@ class ConvNetwork(torch.nn.Module):
             self._learn_eager_steps[key] = 0
             return False
         if g is None:
-            g = self._learn_graphs[key] = self._capture_learn(x, labels, sig)
+            try:
+                g = self._learn_graphs[key] = self._capture_learn(x, labels, sig)
+            except RuntimeError as e:           # a capture that the runtime refuses must not stop training: eager from now on
+                import logging
+                logging.getLogger(__name__).warning('hipGraph capture of the learning step failed (%s): running the '
+                                                    'learning steps eagerly', e)
+                self.graph_learn = False
+                return False
         g['x'].copy_(x)
         g['y'].copy_(labels)
         tensors = [t for s in self.dcll_slices for t in s._adam_tensors()]            # counts the update
@@ -183,7 +191,8 @@ class ConvNetwork(torch.nn.Module):
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
         try:
-            with torch.cuda.graph(graph):
+            # (thread_local: API calls of other host threads — a data loader pinning memory — do not break the capture)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 spikes = g['x']
                 for i, s in enumerate(self.dcll_slices):
                     spikes, _, _, _, _, l = s._learn_forward_backward(spikes, g['y'], want_loss=False,
@@ -227,9 +236,93 @@ class ConvNetwork(torch.nn.Module):
                 self.learn(planes[k].reshape(B, 1, H, W), labels)
 
     def test(self, x):
+        """One inference timestep in every slice (reference :182-185).  At batches where the host's launch path sets
+        the pace the step is replayed from a captured hipGraph (see _test_graphed)."""
+        if self._graph_test_ok(x) and self._test_graphed(x):
+            return
         spikes = x
         for s in self.dcll_slices:
             spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
+        if isinstance(x, torch.Tensor):
+            key = tuple(x.shape)
+            self._test_eager_steps[key] = self._test_eager_steps.get(key, 0) + 1
+
+    # -- the inference timestep as a captured hipGraph ------------------------------------------------------------------
+    # Same idea as _learn_graphed, without an optimizer: the launches of `net.test(x[t])` (three layer steps, readouts,
+    # the per-step argmax) are captured once per input geometry on a static input buffer; a replay is followed by one
+    # copy of the three argmax rows.  Only used where the eager loop is host-bound (batch <= GRAPH_TEST_MAX_BATCH); the
+    # every-20th-step pv statistics run eagerly.
+    GRAPH_TEST_MAX_BATCH = 256
+
+    def _graph_test_ok(self, x):
+        if not (self.graph_learn and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and
+                x.shape[0] <= self.GRAPH_TEST_MAX_BATCH):
+            return False
+        if self._test_eager_steps.get(tuple(x.shape), 0) < 2:      # state and lazily built caches exist after eager steps
+            return False
+        for s in self.dcll_slices:
+            if not isinstance(s, DCLLClassification) or not isinstance(s.dclllayer, Conv2dDCLLlayer):
+                return False
+            if s.collect_stats and (s.iter + 1) % 20 == 0:
+                return False
+        return True
+
+    def _test_signature(self):
+        sig = []
+        for s in self.dcll_slices:
+            L = s.dclllayer
+            sig += [t.data_ptr() for t in L.i2h.state]
+            sig += [t.data_ptr() for t in (L.i2h.weight, L.i2h.bias, L.i2h.alpha, L.i2h.tau_m__dt, L.i2h.alphas,
+                                           L.i2h.tau_s__dt, L.i2o.weight, L.i2o.bias)]
+            if L.output_layer:
+                sig += [L.output_.weight.data_ptr(), L.output_.bias.data_ptr()]
+        return tuple(sig)
+
+    @torch.no_grad()
+    def _test_graphed(self, x):
+        key = tuple(x.shape)
+        sig = self._test_signature()
+        g = self._test_graphs.get(key)
+        if g is not None and g['sig'] != sig:
+            del self._test_graphs[key]
+            self._test_eager_steps[key] = 0
+            return False
+        if g is None:
+            g = dict(sig=sig, x=torch.empty_like(x), n=0)
+            g['x'].copy_(x)
+            iters = [s.iter for s in self.dcll_slices]
+            hist = [len(s.activity_hist) for s in self.dcll_slices]
+            lens = [len(s._clout) for s in self.dcll_slices]
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(x.device)
+            try:
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    spikes, rows = g['x'], []
+                    for s in self.dcll_slices:
+                        spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
+                        rows.append(s._clout[-1])
+                    g['clout'] = torch.stack(rows)
+            except RuntimeError as e:
+                import logging
+                logging.getLogger(__name__).warning('hipGraph capture of the inference step failed (%s): running the '
+                                                    'steps eagerly', e)
+                self.GRAPH_TEST_MAX_BATCH = 0
+                return False
+            finally:                                   # capturing records the launches, it runs nothing
+                for s, it, nh, nc in zip(self.dcll_slices, iters, hist, lens):
+                    s.iter = it
+                    del s.activity_hist[nh:]
+                    del s._clout[nc:]
+            g['graph'] = graph
+            self._test_graphs[key] = g
+        g['x'].copy_(x)
+        g['graph'].replay()
+        g['n'] += 1
+        rec = g['clout'].clone()
+        for i, s in enumerate(self.dcll_slices):
+            s.iter += 1
+            s._clout.append(rec[i])
+        return True
 
     def reset(self, init_states=False):
         for s in self.dcll_slices:

@@ -214,13 +214,15 @@ def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
 
 
 @pytest.mark.parametrize("wrp,hw,scalar_tau,B", [(1.0, (32, 48), False, 3), (0.0, (16, 32), True, 2),
-                                                 (1.0, (128, 128), False, 2), (0.0, (48, 16), False, 5)])
+                                                 (1.0, (128, 128), False, 2), (0.0, (48, 16), False, 5),
+                                                 (1.0, (16, 16), False, 7), (0.0, (16, 16), True, 128)])
 def test_tiled_step_mfma_vs_oracle(dev, wrp, hw, scalar_tau, B):
     """k_lif_step_c32t (per-step forward of a 32 -> 32 layer on planes of several 16x16 tiles, incl. the argparse default
     128x128; behind dcll_conv_lif_step) == C oracle stepping bit for bit over several steps from a non-zero state: every
     tile recomputes the traces of its halo from the snapshot and stores only its interior — state, v and spikes must
     agree everywhere, in particular along the tile borders; arbitrary fp32 input; a second call without the scratch runs
-    the generic kernels and must give the same bits."""
+    the other kernels (generic, or k_lif_step_c32 on the 16x16 plane) and must give the same bits.  The 16x16 cases:
+    batches <= 128 run two workgroups per sample on 8-row tiles."""
     import ctypes
     from snn_modulation_classification_amd import ops, _lib as lib
     from oracle import c_oracle as C

@@ -873,6 +873,38 @@ def test_graph_captured_learning_steps_equal_eager_steps():
             assert torch.equal(sta["exp_avg_sq"], stb["exp_avg_sq"]) and torch.equal(sta["exp_avg"], stb["exp_avg"])
 
 
+def test_graph_captured_inference_steps_equal_eager_steps():
+    """net.test(x[t]) replayed from its captured hipGraph (ConvNetwork._test_graphed; batches <= 256) == the eager step:
+    clout, iteration count, pv statistics and the neuron state after 47 steps bit for bit, incl. a reset in between; the
+    graph was used."""
+    B, R_, T = 6, 16, 47
+    rng = np.random.RandomState(9)
+    x = np.zeros((T, B, R_ * R_), np.float32)
+    x[np.arange(T)[:, None], np.arange(B)[None, :], rng.randint(0, R_ * R_, size=(T, B))] = 1
+    x = torch.from_numpy(x.reshape(T, B, 1, R_, R_)).cuda()
+    nets = {}
+    for graph in (True, False):
+        net = nets[graph] = _radio_net(B, R_)
+        net.graph_learn = graph
+        net.reset()
+        for t in range(20):
+            net.test(x[t])
+        first = [np.asarray(s_.clout).copy() for s_ in net.dcll_slices]
+        net.reset()                                        # clout / iter cleared, state carried over (Q3)
+        for t in range(20, T):
+            net.test(x[t])
+        nets[(graph, "first")] = first
+    a, b = nets[True], nets[False]
+    assert sum(g["n"] for g in a._test_graphs.values()) >= T - 2 - 3 and not b._test_graphs
+    for sa, sb, fa, fb in zip(a.dcll_slices, b.dcll_slices, nets[(True, "first")], nets[(False, "first")]):
+        assert np.array_equal(fa, fb) and fa.shape == (20, B)
+        assert sa.iter == sb.iter == T - 20
+        assert np.array_equal(np.asarray(sa.clout), np.asarray(sb.clout)) and len(sa.clout) == T - 20
+        assert np.array_equal(sa._activity_rows(), sb._activity_rows()) and len(sa.activity_hist) == 1
+        for ta, tb in zip(sa.dclllayer.i2h.state, sb.dclllayer.i2h.state):
+            assert torch.equal(ta, tb)
+
+
 def test_graph_capture_survives_checkpoint_round_trip_and_batch_change():
     """What invalidates a captured learning step is detected and the step re-captured: train.py's checkpoint
     `net.cpu().state_dict(); net.to(device)` moves parameters and gradients to new addresses, a ragged batch re-allocates
