@@ -96,10 +96,11 @@ class ConvNetwork(torch.nn.Module):
 
     # -- the learning timestep as a captured hipGraph ------------------------------------------------------------------
     # At the reference's small batches (argparse default 64) a learning timestep is ~25 kernel launches of a few
-    # microseconds each: the host's launch path, not the GPU, sets the pace (0.50 ms per timestep at B = 64..256).  The
-    # launches of a step in which EVERY slice learns are the same from step to step except for Adam's step-dependent
-    # scalars, so they are captured once (torch.cuda.CUDAGraph = hipGraph) on static input buffers and replayed: the
-    # step-dependent scalars are read on the device (dcll_adam_step_dyn), refreshed from the host before each replay.
+    # microseconds each, and the host's launch path sets the pace (0.43 ms per timestep at B = 64 against 0.31 ms of GPU
+    # work; at B = 512 the GPU is the limit and a graph changes nothing).  The launches of a step in which EVERY slice
+    # learns are the same from step to step except for Adam's step-dependent scalars, so they are captured once
+    # (torch.cuda.CUDAGraph = hipGraph) on static input buffers and replayed: the step-dependent scalars are read on the
+    # device (dcll_adam_step_dyn), refreshed from the host before each replay.
     _DYN_RING = 32
 
     def _graph_learn_ok(self, x, labels, key):
