@@ -56,7 +56,7 @@ def per_step_paths(dev, batch=512, steps=48):
     """The reference's per-timestep protocol on the same network, reported beside the headline (not part of `value`):
     `net.test(x[t])` (test_radio_ml.py:142-146) and `net.learn(x[t], labels)` (train.py:249-251: SmoothL1Loss, Adam
     betas (0, .95), weight_decay 10) at the reference scripts' batch 512, wall time per timestep over `steps` steps after
-    the burn-in / warm-up (HIP kernels only in the loop; the learning step replays its captured hipGraph)."""
+    the burn-in / warm-up (HIP kernels only in the loop; at this batch eager launches — hipGraph replays are used up to batch 128)."""
     convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
     args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
     torch.manual_seed(1)

@@ -102,9 +102,12 @@ class ConvNetwork(torch.nn.Module):
     # (torch.cuda.CUDAGraph = hipGraph) on static input buffers and replayed: the step-dependent scalars are read on the
     # device (dcll_adam_step_dyn), refreshed from the host before each replay.
     _DYN_RING = 32
+    GRAPH_MAX_BATCH = 128       # graphs only where the eager loop is host-bound (learn: 0.46 -> 0.34 ms at B = 128, but
+                                # 0.48 -> 0.49 at B = 256 and 0.73 -> 0.76 at B = 512)
 
     def _graph_learn_ok(self, x, labels, key):
-        if not (self.graph_learn and x.is_cuda and x.dtype == torch.float32 and labels.dtype == torch.float32):
+        if not (self.graph_learn and x.is_cuda and x.dtype == torch.float32 and labels.dtype == torch.float32 and
+                x.shape[0] <= self.GRAPH_MAX_BATCH):
             return False
         if self._learn_eager_steps.get(key, 0) < 2:            # buffers, .grad and Adam state exist after eager steps
             return False
@@ -251,13 +254,13 @@ class ConvNetwork(torch.nn.Module):
     # -- the inference timestep as a captured hipGraph ------------------------------------------------------------------
     # Same idea as _learn_graphed, without an optimizer: the launches of `net.test(x[t])` (three layer steps, readouts,
     # the per-step argmax) are captured once per input geometry on a static input buffer; a replay is followed by one
-    # copy of the three argmax rows.  Only used where the eager loop is host-bound (batch <= GRAPH_TEST_MAX_BATCH); the
+    # copy of the three argmax rows.  Only used where the eager loop is host-bound (batch <= GRAPH_MAX_BATCH: measured
+    # 0.25 -> 0.21 ms per timestep at B = 128, but 0.24 -> 0.25 at B = 256, profiles/r02_per_step_small_batches.txt); the
     # every-20th-step pv statistics run eagerly.
-    GRAPH_TEST_MAX_BATCH = 256
 
     def _graph_test_ok(self, x):
         if not (self.graph_learn and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and
-                x.shape[0] <= self.GRAPH_TEST_MAX_BATCH):
+                x.shape[0] <= self.GRAPH_MAX_BATCH):
             return False
         if self._test_eager_steps.get(tuple(x.shape), 0) < 2:      # state and lazily built caches exist after eager steps
             return False
@@ -307,7 +310,7 @@ class ConvNetwork(torch.nn.Module):
                 import logging
                 logging.getLogger(__name__).warning('hipGraph capture of the inference step failed (%s): running the '
                                                     'steps eagerly', e)
-                self.GRAPH_TEST_MAX_BATCH = 0
+                self.graph_learn = False
                 return False
             finally:                                   # capturing records the launches, it runs nothing
                 for s, it, nh, nc in zip(self.dcll_slices, iters, hist, lens):
