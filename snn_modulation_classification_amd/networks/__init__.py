@@ -102,12 +102,16 @@ class ConvNetwork(torch.nn.Module):
     # (torch.cuda.CUDAGraph = hipGraph) on static input buffers and replayed: the step-dependent scalars are read on the
     # device (dcll_adam_step_dyn), refreshed from the host before each replay.
     _DYN_RING = 32
-    GRAPH_MAX_BATCH = 128       # graphs only where the eager loop is host-bound (learn: 0.46 -> 0.34 ms at B = 128, but
-                                # 0.48 -> 0.49 at B = 256 and 0.73 -> 0.76 at B = 512)
+    # graphs only where the eager loop is host-bound: up to 128 samples of a 16x16 plane (learn: 0.46 -> 0.34 ms at
+    # B = 128, but 0.48 -> 0.49 at B = 256 and 0.73 -> 0.76 at B = 512; larger planes are GPU-bound at any batch)
+    GRAPH_MAX_PIXELS = 128 * 256
+
+    def _graph_small(self, x):
+        return x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] <= self.GRAPH_MAX_PIXELS
 
     def _graph_learn_ok(self, x, labels, key):
         if not (self.graph_learn and x.is_cuda and x.dtype == torch.float32 and labels.dtype == torch.float32 and
-                x.shape[0] <= self.GRAPH_MAX_BATCH):
+                self._graph_small(x)):
             return False
         if self._learn_eager_steps.get(key, 0) < 2:            # buffers, .grad and Adam state exist after eager steps
             return False
@@ -254,13 +258,13 @@ class ConvNetwork(torch.nn.Module):
     # -- the inference timestep as a captured hipGraph ------------------------------------------------------------------
     # Same idea as _learn_graphed, without an optimizer: the launches of `net.test(x[t])` (three layer steps, readouts,
     # the per-step argmax) are captured once per input geometry on a static input buffer; a replay is followed by one
-    # copy of the three argmax rows.  Only used where the eager loop is host-bound (batch <= GRAPH_MAX_BATCH: measured
+    # copy of the three argmax rows.  Only used where the eager loop is host-bound (_graph_small: measured
     # 0.25 -> 0.21 ms per timestep at B = 128, but 0.24 -> 0.25 at B = 256, profiles/r02_per_step_small_batches.txt); the
     # every-20th-step pv statistics run eagerly.
 
     def _graph_test_ok(self, x):
         if not (self.graph_learn and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and
-                x.shape[0] <= self.GRAPH_MAX_BATCH):
+                self._graph_small(x)):
             return False
         if self._test_eager_steps.get(tuple(x.shape), 0) < 2:      # state and lazily built caches exist after eager steps
             return False
