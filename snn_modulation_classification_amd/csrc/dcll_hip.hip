@@ -439,34 +439,45 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
     const int tpr = Wd >> 4, tps = (H >> 4) * tpr;            // 16x16 tiles per row / per sample
     const long njob = TILED ? (long)B * tps : B;
     const long HW = (long)H * Wd;
-    // 16x16 plane: the next sample's g and eps1 (16 + 16 floats per thread) are fetched into registers while the MFMAs of
-    // this one run; only the LDS copy and two barriers stay between the samples of a workgroup
-    float pg[16], pe[16];
+    // the next job's g and eps1 (16 + 16 floats per thread on the 16x16 plane, 16 + 32 for a tile with its halo: thread =
+    // one position of the 22x22 region for all 32 channels) are fetched into registers while the MFMAs of this one run;
+    // only the LDS copy and two barriers stay between the jobs of a workgroup
+    constexpr int NPE = TILED ? 32 : 16;
+    float pg[16], pe[NPE];
     auto fetch = [&](long job) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            pg[k] = gvf[job * 8192 + tid + 512 * k];
-            pe[k] = eps1[job * 8192 + tid + 512 * k];
-        }
-    };
-    if (!TILED && (long)blockIdx.x < njob) fetch(blockIdx.x);
-    for (long job = blockIdx.x; job < njob; job += gridDim.x) {
-        __syncthreads();
         if (TILED) {
             const long b = job / tps;
             const int tile = (int)(job % tps), y0 = (tile / tpr) * 16, x0 = (tile % tpr) * 16;
-            for (int i = tid; i < 32 * 256; i += 512) {
-                const int c = i >> 8, p = i & 255;
-                gl[c * WG32_GLD + p] = gvf[(b * 32 + c) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15)];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = tid + 512 * k, c = i >> 8, p = i & 255;
+                pg[k] = gvf[(b * 32 + c) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15)];
             }
-            // thread = one position of the 22x22 region, for all 32 channels: one div / mod per job instead of one per
-            // element (the index arithmetic of 30 elements per thread was ~10 % of the job), 32 loads in flight
+            const int gy = y0 + tid / RF - 3, gx = x0 + tid % RF - 3;
+            const bool in = tid < CF && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
+            const float *src = eps1 + b * 32 * HW + (long)gy * Wd + gx;
+#pragma unroll
+            for (int c = 0; c < NPE; ++c) pe[c] = in ? src[c * HW] : 0.0f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                pg[k] = gvf[job * 8192 + tid + 512 * k];
+                pe[k] = eps1[job * 8192 + tid + 512 * k];
+            }
+        }
+    };
+    if ((long)blockIdx.x < njob) fetch(blockIdx.x);
+    for (long job = blockIdx.x; job < njob; job += gridDim.x) {
+        __syncthreads();
+        if (TILED) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = tid + 512 * k;
+                gl[(i >> 8) * WG32_GLD + (i & 255)] = pg[k];
+            }
             if (tid < CF) {
-                const int gy = y0 + tid / RF - 3, gx = x0 + tid % RF - 3;
-                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
-                const float *src = eps1 + b * 32 * HW + (long)gy * Wd + gx;
-#pragma unroll 8
-                for (int c = 0; c < 32; ++c) img[c * CF + tid] = in ? src[c * HW] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < NPE; ++c) img[c * CF + tid] = pe[c];
             }
         } else {
 #pragma unroll
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
             }
         }
         __syncthreads();
-        if (!TILED && job + gridDim.x < njob) fetch(job + gridDim.x);
+        if (job + gridDim.x < njob) fetch(job + gridDim.x);
         {   // bias gradient: co = 4w + lane/16, pixels lane%16 + 16*k
             const float *gr = gl + (4 * w + (lane >> 4)) * WG32_GLD + (lane & 15);
 #pragma unroll
