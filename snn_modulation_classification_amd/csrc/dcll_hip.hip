@@ -2219,17 +2219,21 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
         tl[i] = e < ST_PAIR ? e : -1;
         town[i] = in && ry >= 3 && ry < TH + 3 && rx >= 3 && rx < 19;
     }
+    // (addresses: wave-uniform base of the sample + a 32-bit offset inside the sample's 32 planes, which is also the
+    // index into (C,H,W) time-constant tensors)
+    const float *xb = x + b * 32 * HW, *e0b = eps0_old + b * 32 * HW, *e1b = eps1_old + b * 32 * HW;
+    float *e0w = eps0_g + b * 32 * HW, *e1w = eps1_g + b * 32 * HW;
+    const unsigned hw32 = (unsigned)HW;
     float tx[NT], te0[NT], te1[NT], ta[NT], ttm[NT], tas[NT], tts[NT];
     auto fetch_t = [&](int cp) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             if (toff[i] < 0) continue;
-            const int c = 2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0);
-            const long gidx = (b * 32 + c) * HW + toff[i];
-            const long ti = tau_is_tensor ? c * HW + toff[i] : 0;
-            tx[i] = x[gidx];
-            te0[i] = eps0_old[gidx];
-            te1[i] = eps1_old[gidx];
+            const unsigned off = (unsigned)(2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0)) * hw32 + (unsigned)toff[i];
+            const unsigned ti = tau_is_tensor ? off : 0u;
+            tx[i] = xb[off];
+            te0[i] = e0b[off];
+            te1[i] = e1b[off];
             ta[i] = alpha[ti];
             ttm[i] = tau_m[ti];
             tas[i] = alphas[ti];
@@ -2246,10 +2250,9 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
                 trace_update(tx[i], ta[i], ttm[i], tas[i], tts[i], te0[i], te1[i]);
                 e1 = te1[i];
                 if (town[i]) {
-                    const int c = 2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0);
-                    const long gidx = (b * 32 + c) * HW + toff[i];
-                    eps0_g[gidx] = te0[i];
-                    eps1_g[gidx] = e1;
+                    const unsigned off = (unsigned)(2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0)) * hw32 + (unsigned)toff[i];
+                    e0w[off] = te0[i];
+                    e1w[off] = e1;
                 }
             }
             dst[tl[i]] = e1;
@@ -2421,7 +2424,8 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const bool plane16 = d->h == 16 && d->w == 16 && k7;
     // (16x16 plane: two workgroups per sample — 8-row tiles — when the batch alone would leave half the CUs idle)
     const bool split16 = plane16 && B <= 128;
-    if (d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16) && d->h % 16 == 0 && d->w % 16 == 0 && scratch) {
+    if (d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16) && d->h % 16 == 0 && d->w % 16 == 0 && scratch &&
+        per < (1L << 31)) {                                     // (32-bit offsets inside a sample's planes)
         // larger planes: one workgroup per 16x16 tile; the traces are read from a snapshot (a tile recomputes its halo)
         const size_t nbytes = (size_t)nin * sizeof(float);
         if (hipMemcpyAsync(scratch, eps0, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
