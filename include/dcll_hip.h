@@ -84,9 +84,7 @@ int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *conv_h, int32_t *conv_
  *   i2o_W (target, c_out*ph*pw), i2o_b (target)        out_W,out_b: output_ layer, NULL unless output_layer
  *   out_s  (B,c_out,ph,pw) pooled spikes          out_p (B,target) local readout      out_o (B,target) or NULL
  *   out_pv (B,c_out,ph,pw) pooled sigmoid         out_v (B,c_out,ch,cw) = pvmem (+arp) before pooling, may be NULL
- *   scratch 2*B*c_out*ch*cw floats, required iff pooling != 1 (un-pooled spikes and sigmoid), else may be NULL; when
- *           given for a 32 -> 32 channel 7x7 layer without pooling on a plane of 16x16 tiles (larger than 16x16), the
- *           step runs as one MFMA kernel per tile with the traces read from a snapshot kept there (else generic kernels)
+ *   scratch 2*B*c_out*ch*cw floats, required iff pooling != 1 (un-pooled spikes and sigmoid), else may be NULL
  *   i2o_W / out_p may be NULL to skip the local readout (then the call is ContinuousConv2D.forward + pool).
  */
 int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,

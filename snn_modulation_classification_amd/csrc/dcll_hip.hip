@@ -2151,27 +2151,23 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_lif_step_c32t — k_lif_step_c32 for planes larger than 16x16 (h % 16 == 0, w % 16 == 0; the reference's argparse
-// default is 128x128): one workgroup per 16x16 tile of a sample, the same pair of MFMA tiles per wave, the same weight
-// chunks through LDS.  Differences: the eps1 image is staged per channel PAIR (the 22x22 region of the tile with its real
-// halo, zero outside the plane; double-buffered with the weight chunk: 7.7 + 25.5 KB of LDS instead of the whole
-// 32-channel image), and the traces are read from a SNAPSHOT of the state taken before the launch (eps0_old / eps1_old):
-// a tile recomputes the new eps1 of its halo pixels, which a neighbouring workgroup owns and may already have written —
-// only interior pixels are stored.  (Before: the all-T kernel k_lif_seq_c32t at T = 1 with pack / unpack around it,
-// 1.63 + 0.13 ms per layer step at B = 64 on the 128x128 plane.)
-// ------------------------------------------------------------------------------------------------------------
+// k_lif_step_c32t — the conv + neuron part of one step of a 32 -> 32 layer on planes larger than 16x16 (h % 16 == 0,
+// w % 16 == 0; the reference's argparse default is 128x128): one workgroup per 16x16 tile of a sample, the same pair of
+// MFMA tiles per wave and the same weight chunks through LDS as k_lif_step_c32.  The traces are advanced by a separate
+// elementwise pass BEFORE this kernel (k_trace4, in place): a tile needs the new eps1 of its 3-pixel halo, which belongs to
+// neighbouring workgroups — fused into this kernel that meant a snapshot of the state (2 x 134 MB copied per layer step
+// at B = 64, 128x128), seven loads per region element (x, eps0, eps1, four time constants) and a 1.9x redundant trace
+// update; measured 1.19 ms + 0.21 ms of copies per layer step against 0.17 + 0.8 ms for the two-pass form.  Here the eps1
+// image is staged per channel PAIR (the 22x22 region of the tile, zero outside the plane; double-buffered with the
+// weight chunk: 7.7 + 25.5 KB of LDS): one load per region element.
 // TH = tile height: 16 (a wave = two MFMA tiles, image rows 4w..4w+3 of the tile) or 8 (a wave = one MFMA tile, rows 2w,
 // 2w+1): with 8-row tiles a 16x16 plane is TWO workgroups per sample — used when the batch has fewer samples than half
 // the CUs (one workgroup per sample runs 69 us however small the batch is).
+// ------------------------------------------------------------------------------------------------------------
 constexpr int ST_RF = 22;                                          // region row stride
 template <bool REFRACTORY, int TH>
-__global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__ x, const float *__restrict__ W,
-                                                        const float *__restrict__ bias, const float *__restrict__ alpha,
-                                                        const float *__restrict__ tau_m, const float *__restrict__ alphas,
-                                                        const float *__restrict__ tau_s, int tau_is_tensor,
-                                                        const float *__restrict__ eps0_old,
-                                                        const float *__restrict__ eps1_old, float *__restrict__ eps0_g,
-                                                        float *__restrict__ eps1_g, float *__restrict__ arp_g,
+__global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__ W, const float *__restrict__ bias,
+                                                        const float *__restrict__ eps1_g, float *__restrict__ arp_g,
                                                         float *__restrict__ out_s, float *__restrict__ out_pv,
                                                         float *__restrict__ out_v, int H, int Wd, float alpharp, float wrp)
 {
@@ -2205,62 +2201,33 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
         for (int i = 0; i < NW; ++i)
             if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
     };
-    // traces of one channel pair over the tile's (TH+6) x 22 region: element e = tid + 256 i of the 2 x ST_CF
+    // eps1 of one channel pair over the tile's (TH+6) x 22 region: element e = tid + 256 i of the 2 x ST_CF; addresses:
+    // wave-uniform base of the sample + a 32-bit offset inside its 32 planes
     constexpr int NT = (ST_PAIR + 255) / 256;
-    int toff[NT];               // offset inside a channel plane, -1: outside the plane (zero padding) or no element
-    int tl[NT];                 // LDS offset inside the pair buffer
-    bool town[NT];              // interior pixel: this workgroup owns its state
+    int toff[NT];               // offset inside the channel pair's two planes, -1: outside the plane (zero) or no element
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int e = tid + 256 * i, r = e % ST_CF, ry = r / ST_RF, rx = r % ST_RF;
         const int gy = y0 + ry - 3, gx = x0 + rx - 3;
         const bool in = e < ST_PAIR && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
-        toff[i] = in ? gy * Wd + gx : -1;
-        tl[i] = e < ST_PAIR ? e : -1;
-        town[i] = in && ry >= 3 && ry < TH + 3 && rx >= 3 && rx < 19;
+        toff[i] = in ? (e >= ST_CF ? (int)HW : 0) + gy * Wd + gx : -1;
     }
-    // (addresses: wave-uniform base of the sample + a 32-bit offset inside the sample's 32 planes, which is also the
-    // index into (C,H,W) time-constant tensors)
-    const float *xb = x + b * 32 * HW, *e0b = eps0_old + b * 32 * HW, *e1b = eps1_old + b * 32 * HW;
-    float *e0w = eps0_g + b * 32 * HW, *e1w = eps1_g + b * 32 * HW;
-    const unsigned hw32 = (unsigned)HW;
-    float tx[NT], te0[NT], te1[NT], ta[NT], ttm[NT], tas[NT], tts[NT];
+    const float *e1b = eps1_g + b * 32 * HW;
+    const unsigned pair32 = 2u * (unsigned)HW;
+    float te1[NT];
     auto fetch_t = [&](int cp) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            if (toff[i] < 0) continue;
-            const unsigned off = (unsigned)(2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0)) * hw32 + (unsigned)toff[i];
-            const unsigned ti = tau_is_tensor ? off : 0u;
-            tx[i] = xb[off];
-            te0[i] = e0b[off];
-            te1[i] = e1b[off];
-            ta[i] = alpha[ti];
-            ttm[i] = tau_m[ti];
-            tas[i] = alphas[ti];
-            tts[i] = tau_s[ti];
-        }
+        for (int i = 0; i < NT; ++i) te1[i] = toff[i] >= 0 ? e1b[(unsigned)cp * pair32 + (unsigned)toff[i]] : 0.0f;
     };
-    auto finish_t = [&](int cp) {
+    auto store_t = [&](int cp) {
         float *dst = img + (cp & 1) * ST_PAIR;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            if (tl[i] < 0) continue;
-            float e1 = 0.0f;
-            if (toff[i] >= 0) {
-                trace_update(tx[i], ta[i], ttm[i], tas[i], tts[i], te0[i], te1[i]);
-                e1 = te1[i];
-                if (town[i]) {
-                    const unsigned off = (unsigned)(2 * cp + (tid + 256 * i >= ST_CF ? 1 : 0)) * hw32 + (unsigned)toff[i];
-                    e0w[off] = te0[i];
-                    e1w[off] = e1;
-                }
-            }
-            dst[tl[i]] = e1;
-        }
+        for (int i = 0; i < NT; ++i)
+            if (tid + 256 * i < ST_PAIR) dst[tid + 256 * i] = te1[i];
     };
     fetch_w(0);
     fetch_t(0);
-    finish_t(0);
+    store_t(0);
     store_w(0);
     __syncthreads();        // channel pair 0 of the image, bias and chunk 0 in place
     f32x16 accA, accB;
@@ -2293,7 +2260,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
         }
         if (cp + 1 < 16) {
             store_w((cp + 1) & 1);                         // the other buffers: nobody reads them in this iteration
-            finish_t(cp + 1);
+            store_t(cp + 1);
         }
         __syncthreads();
     }
@@ -2319,6 +2286,42 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
             out_pv[o] = sigmoidf_dev(v);
             if (out_v) out_v[o] = v;
         }
+}
+
+// The trace update of a whole state tensor, four elements per thread (n % 4 == 0, per_sample % 4 == 0): the pass in
+// front of k_lif_step_c32t.
+__global__ __launch_bounds__(256) void k_trace4(const f32x4 *__restrict__ x, const float *__restrict__ alpha,
+                                                 const float *__restrict__ tau_m, const float *__restrict__ alphas,
+                                                 const float *__restrict__ tau_s, f32x4 *__restrict__ eps0,
+                                                 f32x4 *__restrict__ eps1, long n4, unsigned per_sample4, int tau_is_tensor)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a, tm, as, ts;
+    if (tau_is_tensor) {
+        const unsigned q = (unsigned)(i % per_sample4);
+        a = ((const f32x4 *)alpha)[q];
+        tm = ((const f32x4 *)tau_m)[q];
+        as = ((const f32x4 *)alphas)[q];
+        ts = ((const f32x4 *)tau_s)[q];
+    } else {
+        a = tm = as = ts = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a += alpha[0];
+        tm += tau_m[0];
+        as += alphas[0];
+        ts += tau_s[0];
+    }
+    const f32x4 xv = x[i];
+    f32x4 e0 = eps0[i], e1 = eps1[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float p0 = e0[k], p1 = e1[k];
+        trace_update(xv[k], a[k], tm[k], as[k], ts[k], p0, p1);
+        e0[k] = p0;
+        e1[k] = p1;
+    }
+    eps0[i] = e0;
+    eps1[i] = e1;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2424,20 +2427,18 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const bool plane16 = d->h == 16 && d->w == 16 && k7;
     // (16x16 plane: two workgroups per sample — 8-row tiles — when the batch alone would leave half the CUs idle)
     const bool split16 = plane16 && B <= 128;
-    if (d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16) && d->h % 16 == 0 && d->w % 16 == 0 && scratch &&
+    const bool ptr16 = ((((uintptr_t)x | (uintptr_t)eps0 | (uintptr_t)eps1) & 15) == 0) &&
+                       (!d->tau_is_tensor || (((uintptr_t)alpha | (uintptr_t)tau_m | (uintptr_t)alphas | (uintptr_t)tau_s) & 15) == 0);
+    if (d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16) && d->h % 16 == 0 && d->w % 16 == 0 && ptr16 &&
         per < (1L << 31)) {                                     // (32-bit offsets inside a sample's planes)
-        // larger planes: one workgroup per 16x16 tile; the traces are read from a snapshot (a tile recomputes its halo)
-        const size_t nbytes = (size_t)nin * sizeof(float);
-        if (hipMemcpyAsync(scratch, eps0, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(scratch + nin, eps1, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(DCLL_ERR_LAUNCH, "dcll_conv_lif_step: state snapshot copy failed");
-        }
+        // larger planes: the traces in an elementwise pass, then one MFMA workgroup per 16x16 tile
+        hipLaunchKernelGGL(k_trace4, dim3(nblk(nin / 4, 256)), dim3(256), 0, st, (const f32x4 *)x, alpha, tau_m, alphas, tau_s,
+                           (f32x4 *)eps0, (f32x4 *)eps1, nin / 4, (unsigned)(per / 4), d->tau_is_tensor);
+        HIP_CHECK_LAUNCH("k_trace4");
         const long njob = (long)B * (d->h / (split16 ? 8 : 16)) * (d->w / 16);
         if (njob > 0x7fffffffL) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_step: more than 2^31 tiles");
-#define DCLL_STEP_T(R_, TH_) hipLaunchKernelGGL((k_lif_step_c32t<R_, TH_>), dim3((unsigned)njob), dim3(256), 0, st, x, W, b,    \
-                                                alpha, tau_m, alphas, tau_s, d->tau_is_tensor, scratch, scratch + nin, eps0,  \
-                                                eps1, arp, out_s, out_pv, out_v, d->h, d->w, d->alpharp, d->wrp)
+#define DCLL_STEP_T(R_, TH_) hipLaunchKernelGGL((k_lif_step_c32t<R_, TH_>), dim3((unsigned)njob), dim3(256), 0, st, W, b, eps1,  \
+                                                arp, out_s, out_pv, out_v, d->h, d->w, d->alpharp, d->wrp)
         if (split16) {
             if (d->refractory) DCLL_STEP_T(true, 8); else DCLL_STEP_T(false, 8);
         } else {

@@ -102,12 +102,7 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     v = buf('v', (B, desc.c_out, ch, cw), want_v)
     p = buf('p', (B, desc.target), i2o_W is not None)
     o = buf('o', (B, desc.target), bool(desc.output_layer))
-    # 32 -> 32 channel 7x7 layers on planes of several 16x16 tiles: one MFMA kernel per tile, which reads the traces from
-    # a snapshot kept in the scratch (k_lif_step_c32t)
-    # (also the 16x16 plane at batches <= 128: two workgroups per sample on 8-row tiles)
-    tiled = (not pooled and desc.c_in == 32 and desc.c_out == 32 and (desc.kh, desc.kw, desc.pad_h, desc.pad_w) == (7, 7, 3, 3)
-             and desc.h % 16 == 0 and desc.w % 16 == 0 and ((desc.h, desc.w) != (16, 16) or B <= 128) and b is not None)
-    scratch = buf('scratch', (2, B, desc.c_out, ch, cw), pooled or tiled)
+    scratch = buf('scratch', (2, B, desc.c_out, ch, cw), pooled)
     if (i2o_W is not None and B <= 2048 and _lib.get().dcll_readout_splitk_scratch(B, K_ro, desc.target) > 0 and
             pv.data_ptr() % 16 == 0 and i2o_W.data_ptr() % 16 == 0 and
             (not desc.output_layer or out_W.data_ptr() % 16 == 0)):

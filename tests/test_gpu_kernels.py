@@ -217,14 +217,12 @@ def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
                                                  (1.0, (128, 128), False, 2), (0.0, (48, 16), False, 5),
                                                  (1.0, (16, 16), False, 7), (0.0, (16, 16), True, 128)])
 def test_tiled_step_mfma_vs_oracle(dev, wrp, hw, scalar_tau, B):
-    """k_lif_step_c32t (per-step forward of a 32 -> 32 layer on planes of several 16x16 tiles, incl. the argparse default
-    128x128; behind dcll_conv_lif_step) == C oracle stepping bit for bit over several steps from a non-zero state: every
-    tile recomputes the traces of its halo from the snapshot and stores only its interior — state, v and spikes must
-    agree everywhere, in particular along the tile borders; arbitrary fp32 input; a second call without the scratch runs
-    the other kernels (generic, or k_lif_step_c32 on the 16x16 plane) and must give the same bits.  The 16x16 cases:
-    batches <= 128 run two workgroups per sample on 8-row tiles."""
-    import ctypes
-    from snn_modulation_classification_amd import ops, _lib as lib
+    """k_trace4 + k_lif_step_c32t (per-step forward of a 32 -> 32 layer on planes of several 16x16 tiles, incl. the argparse
+    default 128x128; behind dcll_conv_lif_step) == C oracle stepping bit for bit over several steps from a non-zero state: every
+    tile reads the new eps1 of its halo, advanced by the elementwise pass in front (k_trace4) — state, v and spikes must
+    agree everywhere, in particular along the tile borders; arbitrary fp32 input.  The 16x16 cases: batches <= 128 run two
+    workgroups per sample on 8-row tiles."""
+    from snn_modulation_classification_amd import ops
     from oracle import c_oracle as C
     rng = np.random.RandomState(29)
     W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 32, 32, gain=3.0)
@@ -245,15 +243,6 @@ def test_tiled_step_mfma_vs_oracle(dev, wrp, hw, scalar_tau, B):
     n_spk = 0
     for step in range(3):
         x = ((rng.uniform(size=(B, 32) + hw) < 0.15) * rng.choice([1.0, 1.0, 0.5], size=(B, 32) + hw)).astype(np.float32)
-        if step == 1:       # the same step through the generic kernels (no scratch -> no tiled kernel) on a copy
-            e0c, e1c, arc = eps0.clone(), eps1.clone(), arp.clone()
-            sg, pvg, vg = (torch.empty((B, 32) + hw, device=dev) for _ in range(3))
-            rc = lib.get().dcll_conv_lif_step(ctypes.byref(d), lib.ptr(cu(x, dev)), lib.ptr(t["i2h.weight"]),
-                                              lib.ptr(t["i2h.bias"]), lib.ptr(t["i2h.alpha"]), lib.ptr(t["i2h.tau_m__dt"]),
-                                              lib.ptr(t["i2h.alphas"]), lib.ptr(t["i2h.tau_s__dt"]), lib.ptr(e0c),
-                                              lib.ptr(e1c), lib.ptr(arc), None, None, None, None, lib.ptr(sg), None, None,
-                                              lib.ptr(pvg), lib.ptr(vg), None, B, lib.stream_ptr())
-            assert rc == 0
         s, p, o, pv, v = ops.conv_lif_step(d, cu(x, dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
                                            t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1, arp,
                                            t["i2o.weight"], t["i2o.bias"])
@@ -265,8 +254,6 @@ def test_tiled_step_mfma_vs_oracle(dev, wrp, hw, scalar_tau, B):
             assert bits_equal(arp.cpu().numpy(), orc.state[2])
         np.testing.assert_allclose(pv.cpu().numpy(), opv, atol=PV_TOL, rtol=0)
         np.testing.assert_allclose(p.cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
-        if step == 1:
-            assert torch.equal(vg, v) and torch.equal(sg, s) and torch.equal(e1c, eps1) and torch.equal(e0c, eps0)
         n_spk += int(os_.sum())
     assert n_spk > 0, "degenerate test: no spikes"
 
