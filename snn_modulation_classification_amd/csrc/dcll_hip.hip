@@ -2426,7 +2426,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const bool k7 = d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b;
     const bool plane16 = d->h == 16 && d->w == 16 && k7;
     // (16x16 plane: two workgroups per sample — 8-row tiles — when the batch alone would leave half the CUs idle)
-    const bool split16 = plane16 && B <= 128;
+    const bool split16 = plane16 && B <= 256;
     const bool ptr16 = ((((uintptr_t)x | (uintptr_t)eps0 | (uintptr_t)eps1) & 15) == 0) &&
                        (!d->tau_is_tensor || (((uintptr_t)alpha | (uintptr_t)tau_m | (uintptr_t)alphas | (uintptr_t)tau_s) & 15) == 0);
     if (d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16) && d->h % 16 == 0 && d->w % 16 == 0 && ptr16 &&

@@ -220,7 +220,7 @@ def test_tiled_step_mfma_vs_oracle(dev, wrp, hw, scalar_tau, B):
     """k_trace4 + k_lif_step_c32t (per-step forward of a 32 -> 32 layer on planes of several 16x16 tiles, incl. the argparse
     default 128x128; behind dcll_conv_lif_step) == C oracle stepping bit for bit over several steps from a non-zero state: every
     tile reads the new eps1 of its halo, advanced by the elementwise pass in front (k_trace4) — state, v and spikes must
-    agree everywhere, in particular along the tile borders; arbitrary fp32 input.  The 16x16 cases: batches <= 128 run two
+    agree everywhere, in particular along the tile borders; arbitrary fp32 input.  The 16x16 cases: batches <= 256 run two
     workgroups per sample on 8-row tiles."""
     from snn_modulation_classification_amd import ops
     from oracle import c_oracle as C
