@@ -2332,7 +2332,9 @@ __global__ __launch_bounds__(256) void k_trace4(const f32x4 *__restrict__ x, con
 // = image rows 4w..4w+3 = two tiles).  The kernel is bound by its maps (160 KB per sample); the generic pair
 // k_trace + k_conv_lif_tiled it replaces ran 98 VALU FMAs per output with LDS weight broadcasts (41 us at B = 512).
 // ------------------------------------------------------------------------------------------------------------
-template <bool REFRACTORY>
+// TILED: planes of several 16x16 tiles (h % 16 == 0, w % 16 == 0): one workgroup per tile of a sample; the traces have
+// been advanced by k_trace4 before (the tile reads the new eps1 of its 3-pixel halo, x / eps0 are not touched here).
+template <bool REFRACTORY, bool TILED>
 __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__restrict__ x, const float *__restrict__ W,
                                                       const float *__restrict__ bias, const float *__restrict__ alpha,
                                                       const float *__restrict__ tau_m, const float *__restrict__ alphas,
@@ -2340,21 +2342,19 @@ __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__r
                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
                                                       float *__restrict__ arp_g, float *__restrict__ out_s,
                                                       float *__restrict__ out_pv, float *__restrict__ out_v,
-                                                      float alpharp, float wrp)
+                                                      float alpharp, float wrp, int H, int Wd)
 {
     constexpr int PS = 24;                      // plane row stride: 16 + 2*3 padding + the pad tap's column
     __shared__ float plane[22 * PS + 8];
     __shared__ float sbias[32];
-    const long b = blockIdx.x;
     const int pix = threadIdx.x, y = pix >> 4, xx = pix & 15, lane = pix & 63;
     const int w = __builtin_amdgcn_readfirstlane(pix >> 6);
     const int h = lane >> 5, j = lane & 31;
-    for (int i = pix; i < 22 * PS + 8; i += 256) plane[i] = 0.0f;
+    const int tpr = TILED ? Wd >> 4 : 1, tps = TILED ? (H >> 4) * tpr : 1;
+    const long b = blockIdx.x / tps;
+    const int tile = blockIdx.x % tps, y0 = (tile / tpr) * 16, x0 = (tile % tpr) * 16;
+    const long HW = TILED ? (long)H * Wd : 256;
     if (pix < 32) sbias[pix] = pix < c_out ? bias[pix] : 0.0f;
-    const int ti = tau_is_tensor ? pix : 0;
-    float e0 = eps0_g[b * 256 + pix], e1 = eps1_g[b * 256 + pix];
-    const float xin = x[b * 256 + pix];
-    const float al = alpha[ti], tm = tau_m[ti], as = alphas[ti], ts = tau_s[ti];
     // weight fragments: pair p: lane (co = j, tap = 2p + h); the pad tap and channels >= c_out carry 0
     float wf[25];
 #pragma unroll
@@ -2362,11 +2362,24 @@ __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__r
         const int tap = 2 * p + h;
         wf[p] = (tap < 49 && j < c_out) ? W[j * 49 + tap] : 0.0f;
     }
-    __syncthreads();                            // plane zeroed
-    trace_update(xin, al, tm, as, ts, e0, e1);  // dcll/pytorch_libdcll.py:493-494
-    eps0_g[b * 256 + pix] = e0;
-    eps1_g[b * 256 + pix] = e1;
-    plane[(y + 3) * PS + xx + 3] = e1;
+    if (TILED) {
+        for (int i = pix; i < 22 * PS + 8; i += 256) {
+            const int ry = i / PS, rx = i % PS, gy = y0 + ry - 3, gx = x0 + rx - 3;
+            plane[i] = (ry < 22 && rx < 22 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd)
+                           ? eps1_g[b * HW + (long)gy * Wd + gx] : 0.0f;
+        }
+    } else {
+        for (int i = pix; i < 22 * PS + 8; i += 256) plane[i] = 0.0f;
+        const int ti = tau_is_tensor ? pix : 0;
+        float e0 = eps0_g[b * 256 + pix], e1 = eps1_g[b * 256 + pix];
+        const float xin = x[b * 256 + pix];
+        const float al = alpha[ti], tm = tau_m[ti], as = alphas[ti], ts = tau_s[ti];
+        __syncthreads();                            // plane zeroed
+        trace_update(xin, al, tm, as, ts, e0, e1);  // dcll/pytorch_libdcll.py:493-494
+        eps0_g[b * 256 + pix] = e0;
+        eps1_g[b * 256 + pix] = e1;
+        plane[(y + 3) * PS + xx + 3] = e1;
+    }
     __syncthreads();
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl) {
@@ -2386,7 +2399,8 @@ __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__r
         for (int r = 0; r < 16; ++r) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
             if (co >= c_out) continue;
-            const long o = (b * c_out + co) * 256 + 32 * m + j;
+            const int p = 32 * m + j;
+            const long o = (b * c_out + co) * HW + (TILED ? (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15) : (long)p);
             float v = acc[r];
             bool s;
             if (REFRACTORY) {
@@ -2429,8 +2443,9 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const bool split16 = plane16 && B <= 256;
     const bool ptr16 = ((((uintptr_t)x | (uintptr_t)eps0 | (uintptr_t)eps1) & 15) == 0) &&
                        (!d->tau_is_tensor || (((uintptr_t)alpha | (uintptr_t)tau_m | (uintptr_t)alphas | (uintptr_t)tau_s) & 15) == 0);
-    if (d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16) && d->h % 16 == 0 && d->w % 16 == 0 && ptr16 &&
-        per < (1L << 31)) {                                     // (32-bit offsets inside a sample's planes)
+    const bool c1t = d->c_in == 1 && d->c_out <= 32 && k7 && !plane16;
+    if (((d->c_in == 32 && d->c_out == 32 && k7 && (!plane16 || split16)) || c1t) && d->h % 16 == 0 && d->w % 16 == 0 &&
+        ptr16 && per < (1L << 31)) {                            // (32-bit offsets inside a sample's planes)
         // larger planes: the traces in an elementwise pass, then one MFMA workgroup per 16x16 tile
         hipLaunchKernelGGL(k_trace4, dim3(nblk(nin / 4, 256)), dim3(256), 0, st, (const f32x4 *)x, alpha, tau_m, alphas, tau_s,
                            (f32x4 *)eps0, (f32x4 *)eps1, nin / 4, (unsigned)(per / 4), d->tau_is_tensor);
@@ -2439,13 +2454,22 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
         if (njob > 0x7fffffffL) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_step: more than 2^31 tiles");
 #define DCLL_STEP_T(R_, TH_) hipLaunchKernelGGL((k_lif_step_c32t<R_, TH_>), dim3((unsigned)njob), dim3(256), 0, st, W, b, eps1,  \
                                                 arp, out_s, out_pv, out_v, d->h, d->w, d->alpharp, d->wrp)
-        if (split16) {
+        if (c1t) {
+            if (d->refractory)
+                hipLaunchKernelGGL((k_lif_step_c1<true, true>), dim3((unsigned)njob), dim3(256), 0, st, d->c_out, x, W, b, alpha,
+                                   tau_m, alphas, tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp,
+                                   d->wrp, d->h, d->w);
+            else
+                hipLaunchKernelGGL((k_lif_step_c1<false, true>), dim3((unsigned)njob), dim3(256), 0, st, d->c_out, x, W, b, alpha,
+                                   tau_m, alphas, tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp,
+                                   d->wrp, d->h, d->w);
+        } else if (split16) {
             if (d->refractory) DCLL_STEP_T(true, 8); else DCLL_STEP_T(false, 8);
         } else {
             if (d->refractory) DCLL_STEP_T(true, 16); else DCLL_STEP_T(false, 16);
         }
 #undef DCLL_STEP_T
-        HIP_CHECK_LAUNCH("k_lif_step_c32t");
+        HIP_CHECK_LAUNCH("k_lif_step_c32t / k_lif_step_c1 (tiled)");
         if (i2o_W && out_p) {
             rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
             if (rc) return rc;
@@ -2461,11 +2485,13 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
         // the whole layer step in one MFMA kernel (traces, conv in the pinned order, refractory, threshold, sigmoid)
         if (d->c_in == 1) {
             if (d->refractory)
-                hipLaunchKernelGGL(k_lif_step_c1<true>, dim3(B), dim3(256), 0, st, d->c_out, x, W, b, alpha, tau_m, alphas,
-                                   tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
+                hipLaunchKernelGGL((k_lif_step_c1<true, false>), dim3(B), dim3(256), 0, st, d->c_out, x, W, b, alpha, tau_m,
+                                   alphas, tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp,
+                                   16, 16);
             else
-                hipLaunchKernelGGL(k_lif_step_c1<false>, dim3(B), dim3(256), 0, st, d->c_out, x, W, b, alpha, tau_m, alphas,
-                                   tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
+                hipLaunchKernelGGL((k_lif_step_c1<false, false>), dim3(B), dim3(256), 0, st, d->c_out, x, W, b, alpha, tau_m,
+                                   alphas, tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp,
+                                   16, 16);
         } else if (d->refractory)
             hipLaunchKernelGGL(k_lif_step_c32<true>, dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
                                d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);

@@ -258,16 +258,18 @@ def test_tiled_step_mfma_vs_oracle(dev, wrp, hw, scalar_tau, B):
     assert n_spk > 0, "degenerate test: no spikes"
 
 
-@pytest.mark.parametrize("wrp,cout,scalar_tau,B", [(1.0, 32, False, 5), (0.0, 32, True, 3), (1.0, 8, True, 4),
-                                                   (0.0, 20, False, 2), (1.0, 32, False, 300)])
-def test_first_layer_step_mfma_vs_oracle(dev, wrp, cout, scalar_tau, B):
+@pytest.mark.parametrize("wrp,cout,scalar_tau,B,hw", [(1.0, 32, False, 5, (16, 16)), (0.0, 32, True, 3, (16, 16)),
+                                                      (1.0, 8, True, 4, (16, 16)), (0.0, 20, False, 2, (16, 16)),
+                                                      (1.0, 32, False, 300, (16, 16)), (1.0, 32, False, 3, (32, 48)),
+                                                      (0.0, 8, True, 2, (128, 128)), (1.0, 20, False, 2, (16, 64))])
+def test_first_layer_step_mfma_vs_oracle(dev, wrp, cout, scalar_tau, B, hw):
     """k_lif_step_c1 (the per-step forward of a 1 -> c_out <= 32 layer on the 16x16 plane, behind dcll_conv_lif_step) ==
     C oracle stepping bit for bit over several steps from a non-zero state — arbitrary fp32 input maps (not only one-hot
-    planes), (1,H,W) tensor or scalar time constants, fewer than 32 channels, both variants, logits through the readout."""
+    planes), (1,H,W) tensor or scalar time constants, fewer than 32 channels, both variants, logits through the readout;
+    larger planes: the tiled form (k_trace4 + one workgroup per 16x16 tile)."""
     from snn_modulation_classification_amd import ops
     from oracle import c_oracle as C
     rng = np.random.RandomState(23)
-    hw = (16, 16)
     W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 1, cout, gain=3.0)
     sd = _sd_from(W, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
     if scalar_tau:
@@ -282,12 +284,12 @@ def test_first_layer_step_mfma_vs_oracle(dev, wrp, cout, scalar_tau, B):
     d = ops.make_conv_desc(1, cout, hw, 7, 3, 1, 24, False, not scalar_tau, wrp)
     t = {k: cu(v, dev) for k, v in sd.items()}
     eps0, eps1 = cu(orc.state[0].copy(), dev), cu(orc.state[1].copy(), dev)
-    arp = cu(orc.state[2].copy(), dev) if wrp > 0 else torch.zeros((B, cout, 16, 16), device=dev)
+    arp = cu(orc.state[2].copy(), dev) if wrp > 0 else torch.zeros((B, cout) + hw, device=dev)
     n_spk = 0
     for step in range(4):
-        x = (rng.uniform(0, 2, size=(B, 1, 16, 16)) * (rng.uniform(size=(B, 1, 16, 16)) < 0.2)).astype(np.float32)
+        x = (rng.uniform(0, 2, size=(B, 1) + hw) * (rng.uniform(size=(B, 1) + hw) < 0.2)).astype(np.float32)
         if step == 0:
-            x[0, 0, 0, 0], x[0, 0, 15, 15] = 1.0, 1.0
+            x[0, 0, 0, 0], x[0, 0, hw[0] - 1, hw[1] - 1] = 1.0, 1.0
         s, p, o, pv, v = ops.conv_lif_step(d, cu(x, dev), t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"],
                                            t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"], eps0, eps1, arp,
                                            t["i2o.weight"], t["i2o.bias"])
