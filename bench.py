@@ -415,7 +415,10 @@ def main():
                 "frac_of_peak": pv_bytes / kernel_ms["readout"] / 1e6 / PEAK_HBM_GBS}
         out["hbm_bound_kernels"] = hb
         if world == 1 and R == 16 and a.per_step:
-            out["per_step_paths"] = per_step_paths(dev)
+            try:                                    # an extra, never at the price of the headline line
+                out["per_step_paths"] = per_step_paths(dev)
+            except Exception as e:                  # noqa: BLE001
+                out["per_step_paths"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and a.cpu_windows > 0:
             cells = enc(iq, T_STEPS, t0=0)          # the same quantisation as a separate kernel, for the CPU leg
             out["cpu_baseline"] = cpu_baseline(net, convs, cells.cpu(), res["vote"][-1].cpu().numpy(),
