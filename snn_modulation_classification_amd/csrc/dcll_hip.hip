@@ -1999,6 +1999,37 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
 // which at a stride of 64 floats would be 64 writes into one LDS bank — measured 1.4 us per chunk, during which the
 // operand reads of the MFMA stream wait (experiments/ablate_step.hip)
 constexpr int STEP_WTS = 65, STEP_WCH = 49 * STEP_WTS + 3;
+// Weight chunk cp (input-channel pair cp) of a 32 -> 32 7x7 layer as MFMA A fragments in LDS:
+// wch[tap*STEP_WTS + hh*32 + co] = W[co][2cp+hh][tap].  In global memory the 98 floats of (co, channel pair cp) are
+// contiguous: thread t of the 256 moves elements t, t+256, ... of the 32 x 98 block through registers (fetched while the
+// MFMAs of the previous chunk run); the index arithmetic is done once per kernel.
+struct step_wchunk {
+    static constexpr int NW = 13;
+    float reg[NW];
+    int goff[NW], loff[NW];
+    __device__ __forceinline__ void init(int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
+            goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
+            loff[i] = (r % 49) * STEP_WTS + (r / 49) * 32 + co;
+        }
+    }
+    __device__ __forceinline__ void fetch(const float *__restrict__ W, int cp)
+    {
+        const float *wc = W + cp * 98;          // wave-uniform base of the chunk
+#pragma unroll
+        for (int i = 0; i < NW; ++i) reg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
+    }
+    __device__ __forceinline__ void store(float *wch, int buf) const
+    {
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = reg[i];
+    }
+};
+
 // DBG (experiments/ablate_step.hip only; 0 in the product): 1 no MFMAs, 2 no epilogue stores, 4 no state traffic,
 // 8 no weight streaming, 16 no barrier per chunk (8, 16: wrong results, timing only)
 template <bool REFRACTORY, int DBG = 0>
@@ -2019,28 +2050,10 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 
     for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
-    // weight chunk cp as A fragments: wch[tap*STEP_WTS + hh*32 + co] = W[co][2cp+hh][tap]; in global memory the 98 floats of
-    // (co, channel pair cp) are contiguous.  Thread t moves elements t, t+256, ... of the 32 x 98 block; the index
-    // arithmetic is done once (inside the chunk loop it would be issued against the MFMA stream).
-    constexpr int NW = 13;
-    float wreg[NW];
-    int goff[NW], loff[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
-        goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
-        loff[i] = (r % 49) * STEP_WTS + (r / 49) * 32 + co;
-    }
-    auto fetch_w = [&](int cp) {
-        const float *wc = W + cp * 98;          // wave-uniform base of the chunk
-#pragma unroll
-        for (int i = 0; i < NW; ++i) wreg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-            if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
-    };
+    step_wchunk wc;
+    wc.init(tid);
+    auto fetch_w = [&](int cp) { wc.fetch(W, cp); };
+    auto store_w = [&](int buf) { wc.store(wch, buf); };
     // traces of this step (dcll/pytorch_libdcll.py:493-494), state updated in HBM, eps1 -> image — one channel PAIR at a
     // time (thread t owns pixel t of both channels): pair cp + 1 is fetched while the MFMAs of pair cp run and finished
     // (trace arithmetic, state stores, image write) behind them, so that the 160 KB of state traffic per sample is spread
@@ -2181,26 +2194,10 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__
     const int tile = blockIdx.x % tps, y0 = (tile / tpr) * TH, x0 = (tile % tpr) * 16;
     const long HW = (long)H * Wd;
     if (tid < 32) sbias[tid] = bias[tid];
-    // weight chunks exactly as in k_lif_step_c32
-    constexpr int NW = 13;
-    float wreg[NW];
-    int goff[NW], loff[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
-        goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
-        loff[i] = (r % 49) * STEP_WTS + (r / 49) * 32 + co;
-    }
-    auto fetch_w = [&](int cp) {
-        const float *wc = W + cp * 98;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) wreg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-            if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = wreg[i];
-    };
+    step_wchunk wc;                                              // weight chunks exactly as in k_lif_step_c32
+    wc.init(tid);
+    auto fetch_w = [&](int cp) { wc.fetch(W, cp); };
+    auto store_w = [&](int buf) { wc.store(wch, buf); };
     // eps1 of one channel pair over the tile's (TH+6) x 22 region: element e = tid + 256 i of the 2 x ST_CF; addresses:
     // wave-uniform base of the sample + a 32-bit offset inside its 32 planes
     constexpr int NT = (ST_PAIR + 255) / 256;
