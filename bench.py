@@ -87,19 +87,15 @@ def per_step_paths(dev, batch=512, steps=48):
     return out
 
 
-def bench_ref_network(a):
+def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
     """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code, so
     parity is unpinned): radio_ml_conv_ref.yaml — 7 x (64 channels, (1,3) kernels, (1,2) pooling) — on a Q=16 x I=128 I/Q
-    plane, per-output-channel int8 conv weights (dequantised for the kernels), T=128, batch `--batch` (default 256).
-    Runs the fused sequence path (k_lif_seq_w3 per layer) — or, for a geometry without one, the per-step path (one C-ABI
-    call per layer and step on device-built spike planes).  `--gpus N`: batch shards like the headline benchmark.  One
-    JSON line (no CPU leg: the torch-CPU port needs ~1 s per window here)."""
+    plane, per-output-channel int8 conv weights handed to the kernels AS INT8 through the C ABI (dcll_layer_opts), 1-bit
+    packed spikes between the layers, T=128, `B` windows per GPU.  Fused sequence path (k_lif_seq_w3 per layer; v in the pv
+    buffer, the sigmoid in the readout GEMMs) — or, for a geometry without one, the per-step path.
+    -> the fields of a bench line (value, ms_per_step, roofline of k_lif_seq_w3<64>, first-layer stream, ...)."""
     from snn_modulation_classification_amd import ops, quant
-    rank, local_rank, world = parallel.init_process_group()
-    assert world == a.gpus, "torchrun --nproc-per-node must equal --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
-    dev = torch.device("cuda", parallel.local_device(local_rank))
-    torch.cuda.set_device(dev)
-    H, W, B = 16, 128, (a.batch or 1024)          # windows per GPU (weak scaling: batch shards, no data-path collective)
+    H, W = 16, 128
     convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks",
                                            "radio_ml_conv_ref.yaml"))
     args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
@@ -109,6 +105,7 @@ def bench_ref_network(a):
                       learning_rates=None, burnin=20)
     net.reset(True)
     quant.apply_int8_weights(net)
+    int8_abi = all(s.dclllayer.i2h.int8_weights() is not None for s in net.dcll_slices)
     # one pv buffer for the whole batch (33.5 MB per window: 137 GB at batch 4096 of the 288 GB): the narrow late layers
     # have only B / 8 ... B workgroups, chunks of the default 24 GB budget (767 windows) would leave the chip half empty
     net.pv_budget_bytes = float(os.environ.get("DCLL_PV_BUDGET_GB", "150")) * 2 ** 30
@@ -137,52 +134,77 @@ def bench_ref_network(a):
         parallel.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
+    if parallel.is_distributed():
         parallel.all_reduce_(torch.zeros(1, device=dev))          # communicator up before the timed region
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     fence()
     prof.clear()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if parallel.is_distributed():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     flop = sum(2 * 64 * (1 if i == 0 else 64) * 3 * H * (W >> i) for i in range(7)) * T_STEPS * B
     # dominant kernel: k_lif_seq_w3<64> (layers 1..6), HIP-event time of its launches on the launch stream
     w3_ms = [s_.elapsed_time(e_) for s_, e_ in prof.get("lif_c32", [])]
-    flop_w3 = sum(2 * 64 * 64 * 3 * H * (W >> i) for i in range(1, 7)) * T_STEPS * B * a.steps
+    flop_w3 = sum(2 * 64 * 64 * 3 * H * (W >> i) for i in range(1, 7)) * T_STEPS * B * steps
     roof = None
     if w3_ms:
         ach = flop_w3 / (sum(w3_ms) / 1e3) / 1e12
         roof = {"kernel": "k_lif_seq_w3<64> (six 64->64 layers; sum over their launches)", "bound": "mfma", "achieved": ach,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                "launch_ms_per_step": sum(w3_ms) / a.steps, "launches_per_step": len(w3_ms) / a.steps}
-    kernel_ms = {k: float(np.sum([s_.elapsed_time(e_) for s_, e_ in v])) / a.steps for k, v in prof.items()}
-    if world > 1:
-        parallel.barrier()
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    print(json.dumps({
-        "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": world * B * a.steps / dt, "unit": "IQ windows/s",
-        "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "launch_ms_per_step": sum(w3_ms) / steps, "launches_per_step": len(w3_ms) / steps,
+                "algorithmic_flop_per_step": flop_w3 / steps}
+    kernel_ms = {k: float(np.sum([s_.elapsed_time(e_) for s_, e_ in v])) / steps for k, v in prof.items()}
+    hbm = {}
+    if kernel_ms.get("lif_c1"):
+        # first layer (k_lif_seq_w3<1>): an HBM write stream — pooled pv / v (T*B*64*16*64 floats) + packed pooled spikes
+        byt = T_STEPS * B * 64 * H * (W // 2) * 4 * (1 + 1 / 32.0)
+        hbm["first_layer (k_lif_seq_w3<1> + statistics pass)"] = {
+            "bytes_per_launch": byt, "ms": kernel_ms["lif_c1"], "GBps": byt / kernel_ms["lif_c1"] / 1e6,
+            "frac_of_peak": byt / kernel_ms["lif_c1"] / 1e6 / PEAK_HBM_GBS}
+    if kernel_ms.get("readout"):
+        byt = sum(T_STEPS * B * 64 * H * (W >> (i + 1)) * 4 for i in range(7))
+        hbm["readouts (seven k_readout_t16 launches over the pooled maps)"] = {
+            "bytes_per_step": byt, "ms": kernel_ms["readout"], "GBps": byt / kernel_ms["readout"] / 1e6,
+            "frac_of_peak": byt / kernel_ms["readout"] / 1e6 / PEAK_HBM_GBS}
+    return {
+        "value": world * B * steps / dt, "unit": "IQ windows/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps, "dtype": "f32 arithmetic on int8 weights (one fp32 scale per output channel)",
         "config": {"workload": "radio_ml_conv_ref.yaml (7 x 64 ch, (1,3) kernels, (1,2) pooling), Q=16 x I=128 I/Q plane, "
-                               "T=128, int8 per-channel conv weights (dequantised) + 1-bit packed spikes, batch %d, %s; "
+                               "T=128, int8 per-channel conv weights %s + 1-bit packed spikes, batch %d, %s; "
                                "parity unpinned (no reference quantisation code)" %
-                               (B, "fused sequence kernels" if fused else "per-step path (7 layer calls per timestep)"),
+                               ("read as int8 by the kernels (dcll_layer_opts)" if int8_abi else "(dequantised)", B,
+                                "fused sequence kernels" if fused else "per-step path (7 layer calls per timestep)"),
                    "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [H, W],
-                   "path": "sequence" if fused else "per-step",
+                   "path": "sequence" if fused else "per-step", "int8_weights_through_abi": int8_abi,
+                   "pv_presigmoid": bool(net.presigmoid),
                    "parallelism": "batch shards, %d rank(s), tally all-reduce only" % world},
-        "roofline": roof, "kernel_ms_per_step": kernel_ms, "conv_tflops_per_gpu": flop * a.steps / dt / 1e12}))
-    if world > 1:
+        "roofline": roof, "kernel_ms_per_step": kernel_ms, "hbm_bound_kernels": hbm,
+        "conv_tflops_per_gpu": flop * steps / dt / 1e12}
+
+
+def bench_ref_network(a):
+    """`bench.py --network ref [--gpus N]`: config 5 (run_ref_network) as a bench line of its own; batch shards like the
+    headline benchmark.  (No CPU leg: the torch-CPU port needs ~1 s per window here.)"""
+    rank, local_rank, world = parallel.init_process_group()
+    assert world == a.gpus, "torchrun --nproc-per-node must equal --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
+    dev = torch.device("cuda", parallel.local_device(local_rank))
+    torch.cuda.set_device(dev)
+    rec = run_ref_network(dev, a.batch or 1024, a.steps, a.warmup, rank, world)
+    if parallel.is_distributed():
+        parallel.barrier()
+    if rank == 0:
+        out = {"metric": "IQ windows/sec (RadioML 2x128, T=128)", "n_gpus": world, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+        out.update(rec)
+        print(json.dumps(out))
+    if parallel.is_distributed():
         dist.destroy_process_group()
 
 
@@ -205,10 +227,12 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(net, convs, cells_cpu, gpu_votes, n_windows):
+def cpu_baseline(net, convs, cells_cpu, gpu_votes, n_windows, gpu_spikes=None):
     """The reference's CPU PyTorch path (oracle/torch_ref.py: same eager op sequence, fixture-verified against the
-    imported reference) on this host's cores: reset -> T-loop of test(x[t]) -> votes, on a bounded sample."""
-    from oracle import torch_ref
+    imported reference) on this host's cores: reset -> T-loop of test(x[t]) -> votes, on a bounded sample.
+    gpu_spikes: packed spike trains of all layers of the GPU run on the same windows -> `spike_flips_vs_cpu` (flip counts,
+    first flips inside the rounding band; oracle/flip_count.py)."""
+    from oracle import flip_count, torch_ref
     sds = [{k: v.detach().cpu() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
     ref = torch_ref.RefConvNetwork(sds, convs, wrp=1.0)
     cells = cells_cpu[:, :n_windows].long()
@@ -243,8 +267,13 @@ def cpu_baseline(net, convs, cells_cpu, gpu_votes, n_windows):
             dts.append(time.perf_counter() - t0)
             log("cpu baseline rep %d: %.2f s for %d windows" % (rep, dts[-1], n_windows))
         dt = min(dts)
+        flips = None
+        if gpu_spikes is not None:          # one more (untimed) pass: every spike of the three layers, CPU vs GPU
+            ref.reset(True)
+            flips = flip_count.spike_flips(ref, x, [flip_count.unpack_words(s_[:, :n_windows], (R, R)) for s_ in gpu_spikes])
+            log("spike flips vs the CPU path on %d windows: %s" % (n_windows, flips["flips_per_layer"]))
     agree = float(np.mean(votes[-1] == gpu_votes[:n_windows]))
-    return {"value": n_windows / dt, "unit": "IQ windows/s", "cores": cores, "kind": "port",
+    return {"value": n_windows / dt, "unit": "IQ windows/s", "cores": cores, "kind": "port", "spike_flips_vs_cpu": flips,
             "sample": "batch of %d windows x T=%d, %dx%d plane, reset -> T x test(x[t]) -> votes, best of 3 (%.1f s "
                       "each), torch %s CPU, %d threads (fastest of the calibrated counts <= cgroup quota)" %
                       (n_windows, T, R, R, dt, torch.__version__, torch.get_num_threads()),
@@ -271,6 +300,9 @@ def main():
     ap.add_argument("--per-step", type=int, default=1,
                     help="1 (default, N=1 only): also time the per-timestep protocol net.test / net.learn at batch 512 and "
                          "report it as `per_step_paths` (a second or two; not part of `value`)")
+    ap.add_argument("--config5", type=int, default=1,
+                    help="1 (default, N=1 headline run only): also run BASELINE config 5 (radio_ml_conv_ref.yaml, int8 weights "
+                         "through the ABI, batch 4096, 3 steps) and report it as the `config5` sub-record")
     ap.add_argument("--network", default="radio", choices=["radio", "ref"],
                     help="radio = radio_ml_conv.yaml (headline); ref = radio_ml_conv_ref.yaml with int8 weights (config 5)")
     a = ap.parse_args()
@@ -320,7 +352,7 @@ def main():
         torch.cuda.synchronize()
 
     net._sequence_buffers(T_STEPS, min(B, max(1, int(net.pv_budget_bytes // (4 * T_STEPS * 32 * R * R)))), dev)  # allocate once, outside the timed region
-    if world > 1:
+    if parallel.is_distributed():
         # create the RCCL communicator now (lazy otherwise: it would land in the first step, timed when --warmup 0)
         parallel.all_reduce_(torch.zeros(1, device=dev))
         torch.cuda.synchronize()
@@ -335,7 +367,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     log("timed region done: %.3f s for %d steps" % (dt, a.steps))
-    if world > 1:
+    if parallel.is_distributed():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -385,7 +417,7 @@ def main():
                        "parallelism": "batch shards, %d rank(s) on %d GPU(s)%s, tally all-reduce only (backend %s)" %
                                       (world, min(world, torch.cuda.device_count()),
                                        " — REHEARSAL: ranks share a device" if world > torch.cuda.device_count() else "",
-                                       dist.get_backend() if world > 1 else "none")},
+                                       dist.get_backend() if parallel.is_distributed() else "none")},
             "roofline": {"kernel": hot_kernel, "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)",
@@ -419,13 +451,31 @@ def main():
                 out["per_step_paths"] = per_step_paths(dev)
             except Exception as e:                  # noqa: BLE001
                 out["per_step_paths"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and R == 16 and a.config5 and B == 4096:
+            # BASELINE config 5 beside the headline (never at its price): its own network, 3 steps at batch 4096
+            try:
+                net._seq_buffers.clear()            # the headline's pv / spike buffers: config 5 needs 137 GB of pv
+                torch.cuda.empty_cache()
+                out["config5"] = run_ref_network(dev, 4096, 3, 1)
+            except Exception as e:                  # noqa: BLE001
+                out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
         if world == 1 and a.cpu_windows > 0:
             cells = enc(iq, T_STEPS, t0=0)          # the same quantisation as a separate kernel, for the CPU leg
-            out["cpu_baseline"] = cpu_baseline(net, convs, cells.cpu(), res["vote"][-1].cpu().numpy(),
-                                               min(a.cpu_windows, B))
+            nw = min(a.cpu_windows, B)
+            spikes = None
+            if R == 16:                             # the GPU's spike trains of the same windows, for the flip count
+                # (one more untimed pass over the WHOLE batch: a different batch size would re-allocate the state, and the
+                #  refractory variant re-draws its time constants whenever it does — reference quirk Q4)
+                net.zero_states()
+                net.reset()
+                sub = net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False, keep_spikes=True)
+                spikes = [s_[:, :nw].cpu().numpy() for s_ in sub["spikes"]]
+                del sub
+            out["cpu_baseline"] = cpu_baseline(net, convs, cells.cpu(), res["vote"][-1].cpu().numpy(), nw, spikes)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if parallel.is_distributed():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -21,8 +21,8 @@ static float run(int B, int T, bool want_pv)
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
-        if (want_pv) hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0, AB, PRIO, BASES>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
-        else hipLaunchKernelGGL((k_lif_seq_c32<true, 0, 0, AB, PRIO, BASES>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        if (want_pv) hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0, AB, PRIO, BASES>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        else hipLaunchKernelGGL((k_lif_seq_c32<true, 0, 0, AB, PRIO, BASES>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;
@@ -57,7 +57,7 @@ int main()
         hipMalloc(&e0, ns * 4); hipMalloc(&e1, ns * 4); hipMalloc(&arp, ns * 4);
         hipMemset(e0, 0, ns * 4); hipMemset(e1, 0, ns * 4); hipMemset(arp, 0, ns * 4);
         hipMalloc(&pv, (size_t)T * ns * 4); hipMalloc(&dbg, 4096); hipMemset(dbg, 0, 4096);
-        hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0, 8>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
+        hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0, 8>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
         unsigned long long h[64];
         hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
         printf("wave: total Mcyc | barrier-wait %% | epilogue %% | trace %% | chain+handoff %%   (s_memtime ticks, 100 MHz?)\n");

@@ -39,7 +39,7 @@ int main(int argc, char **argv)
     };
     for (int rep = 0; rep < 3 && !co; ++rep) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
+        hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("k_lif_seq_c32d B=%d T=%d: %.2f ms (ideal at 157.3 TF: %.2f)\n", B, T, ms, 2.0 * 32 * 1568 * 256 * (double)T * B / 157.3e12 * 1e3);
@@ -49,12 +49,12 @@ int main(int argc, char **argv)
         // 16 instead of 19 floats behind the first (conflict free, WRONG data — timing only), same stamps.
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(a);
-            hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 2>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
+            hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 2>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             printf("k_lif_seq_c32d, conflict-free B reads (wrong data): %.2f ms\n", ms);
         }
-        hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 3>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
+        hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 3>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
         unsigned long long h2[64];
         hipMemcpy(h2, dbg, 512, hipMemcpyDeviceToHost);
         const double nst2 = 4.0 * T + 8;
@@ -69,7 +69,7 @@ int main(int argc, char **argv)
         launch_side(40);                            // far longer than the layer kernel
         hipEventRecord(a, hot);
     }
-    hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 1>), dim3(B), dim3(512), 0, hot, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
+    hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 1>), dim3(B), dim3(512), 0, hot, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg, T, B, 0.65f, 1.0f);
     if (co) {
         hipEventRecord(b, hot); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);

@@ -8,7 +8,7 @@ static float run(int B, float *x, float *W, float *bias, float *tau, float *e0, 
     float best = 1e9f;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k_lif_step_c32<true, DBG>), dim3(B), dim3(256), 0, 0, x, W, bias, tau, tau + 8192, tau + 2 * 8192, tau + 3 * 8192, 1, e0, e1, arp, s, pv, v, 0.65f, 1.0f);
+        hipLaunchKernelGGL((k_lif_step_c32<true, DBG>), dim3(B), dim3(256), 0, 0, x, dcll_wsrc{W, nullptr, nullptr}, bias, tau, tau + 8192, tau + 2 * 8192, tau + 3 * 8192, 1, e0, e1, arp, s, pv, v, 0.65f, 1.0f);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (rep && ms < best) best = ms;

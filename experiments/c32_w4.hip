@@ -199,7 +199,7 @@ int main()
     for (int rep = 0; rep < 3; ++rep) {
         for (int i = 0; i < 6; ++i) hipMemset(st[i], 0, ns * 4);
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, W, bias, tau4, st[0], st[1], st[2], spk_a, pv,
+        hipLaunchKernelGGL((k_lif_seq_c32<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, st[0], st[1], st[2], spk_a, pv,
                            (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, T, B, 0.65f, 1.0f);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms8 = ms < ms8 ? ms : ms8;

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCLL_ABI_VERSION 2
+#define DCLL_ABI_VERSION 3
 
 enum {
     DCLL_OK = 0,
@@ -69,6 +69,32 @@ typedef struct dcll_dense_desc {
     float alpharp, wrp;
 } dcll_dense_desc;
 
+/*
+ * Optional per-call extras of the layer calls (ABI v3).  NULL = all defaults (fp32 weights, pv = sigmoid(v)).
+ *
+ *   w_q8 / w_scale   BASELINE config 5 ("int8 weights"; no reference code — the build's definition): when w_q8 != NULL the
+ *                    conv weight is read as int8 (c_out,c_in,kh,kw) with one fp32 scale per OUTPUT channel, w_scale
+ *                    (c_out), and the fp32 `W` argument of the call is ignored (may be NULL).  Every kernel converts a
+ *                    weight exactly once, where it would have loaded the fp32 value: w = (float)q * w_scale[co] — ONE
+ *                    rounded fp32 multiply — and then runs the pinned fmaf chain on it, so the results are bit-identical to
+ *                    the same call on the dequantised fp32 tensor.  The weight-stationary sequence kernels convert in their
+ *                    prologue (once per launch); the per-step kernels where they stage the weights (1 byte per weight
+ *                    through L2 instead of 4).  Not accepted by dcll_conv_lif_backward (learning updates fp32 weights).
+ *   pv_presigmoid    sequence calls only.  != 0: pv_out receives v = pvmem + arp' — what the threshold saw (:498-499),
+ *                    max-pooled where the layer pools — INSTEAD of pv = sigmoid(v).  The sigmoid then runs in the consumer:
+ *                    dcll_readout_act(..., DCLL_ACT_SIGMOID) applies it to every value it stages (the readout is HBM-bound
+ *                    and has the vector slots; the layer kernels share their vector pipe with the fp32 MFMAs), and the pv
+ *                    statistics (pv_lowhigh) are counted on sigmoid(v) as before.  sigmoid is monotone, so
+ *                    max-pool(sigmoid(v)) == sigmoid(max-pool(v)) up to the last ulp of the (not bit-pinned) sigmoid.
+ *                    Not combined with the fused readout (n_ro > 0).
+ */
+typedef struct dcll_layer_opts {
+    const int8_t *w_q8;         /* int8 conv weights (c_out,c_in,kh,kw), or NULL: the call's fp32 W is used */
+    const float *w_scale;       /* (c_out) fp32, required with w_q8                                          */
+    int32_t pv_presigmoid;      /* sequence calls: pv_out = v (pooled by max) instead of sigmoid(v)          */
+    int32_t reserved;           /* must be 0                                                                 */
+} dcll_layer_opts;
+
 int dcll_version(void);                 /* DCLL_ABI_VERSION of the loaded library                        */
 const char *dcll_last_error(void);      /* thread-local message of the last failing call ("" if none)    */
 
@@ -86,13 +112,14 @@ int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *conv_h, int32_t *conv_
  *   out_pv (B,c_out,ph,pw) pooled sigmoid         out_v (B,c_out,ch,cw) = pvmem (+arp) before pooling, may be NULL
  *   scratch 2*B*c_out*ch*cw floats, required iff pooling != 1 (un-pooled spikes and sigmoid), else may be NULL
  *   i2o_W / out_p may be NULL to skip the local readout (then the call is ContinuousConv2D.forward + pool).
+ *   opts     NULL, or int8 weights (dcll_layer_opts; pv_presigmoid must be 0 here: the drop-in returns pv).
  */
 int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
                        const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
                        float *eps0, float *eps1, float *arp,
                        const float *i2o_W, const float *i2o_b, const float *out_W, const float *out_b,
                        float *out_s, float *out_p, float *out_o, float *out_pv, float *out_v, float *scratch,
-                       int32_t B, void *stream);
+                       const dcll_layer_opts *opts, int32_t B, void *stream);
 
 /*
  * Backward of one Conv2dDCLLlayer step for local learning — what loss.backward() reaches in DCLLBase.train_dcll
@@ -184,13 +211,14 @@ int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W
  *                  with (iter0 + t + 1) % 20 == 0 — DCLLBase.forward's histogram steps, :658-661 — the number of pv
  *                  values in the first and in the last of the 19 bins of np.linspace(0, 1, 20) (what write_stats
  *                  reports, :678-688).  iter0 = the slice's iteration count before the call.  Needs pv_out.
+ *   opts           NULL, or int8 weights / pv_presigmoid (dcll_layer_opts above).
  */
 int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
                            const float *tau4, float *eps0, float *eps1, float *arp,
                            uint32_t *spk_out, float *pv_out, float *v_out,
                            const float *ro_Wp, const float *ro_b, float *ro_out, int32_t n_ro,
                            float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
-                           int32_t T, int32_t B, void *stream);
+                           const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream);
 
 /* Re-lay-out a readout matrix Wt (N, 32*16*16) [n][co][pix] for the fused epilogue of dcll_conv_lif_sequence:
  * Wp[me][wq][n][lane][rr] with co = rr + 8*wq + 4*(lane>>5), pix = 32*me + (lane&31).  Wp has N*8192 floats. */
@@ -206,7 +234,7 @@ int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, 
                                  const float *tau4, float *eps0, float *eps1, float *arp,
                                  uint32_t *spk_out, float *pv_out, float *v_out,
                                  float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
-                                 int32_t T, int32_t B, void *stream);
+                                 const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream);
 
 /*
  * Same kernel with iq2spiketrain's quantisation (data/utils.py:60-82) fused in: the input is the raw IQ window
@@ -217,7 +245,7 @@ int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const fl
                               int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
                               float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
                               float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
-                              int32_t T, int32_t B, void *stream);
+                              const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream);
 
 /*
  * The pv statistics of DCLLBase.forward (:658-661) as a call of its own (the per-step path uses it with T = 1):
@@ -225,6 +253,10 @@ int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const fl
  * pv_lowhigh above, uint64 [dcll_pv_lowhigh_steps(iter0, T)][2].  Steps that are not histogram steps are not read.
  */
 int dcll_pv_lowhigh(const float *pv, int64_t per_step, int32_t T, int32_t iter0, uint64_t *counts, void *stream);
+/* The same counters for a buffer written with pv_presigmoid (act = DCLL_ACT_SIGMOID: sigmoid(v) is what is counted). */
+enum { DCLL_ACT_NONE = 0, DCLL_ACT_SIGMOID = 1 };
+int dcll_pv_lowhigh_act(const float *pv, int64_t per_step, int32_t T, int32_t iter0, uint64_t *counts, int32_t act,
+                        void *stream);
 int32_t dcll_pv_lowhigh_steps(int32_t iter0, int32_t T);    /* (iter0 + T) / 20 - iter0 / 20 */
 
 /*
@@ -233,6 +265,20 @@ int32_t dcll_pv_lowhigh_steps(int32_t iter0, int32_t T);    /* (iter0 + T) / 20 
  */
 int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out,
                  int64_t rows, int32_t K, int32_t N, void *stream);
+/*
+ * The readout of the whole-sequence path (rows = T x a chunk of the batch), optionally on a pv_presigmoid buffer:
+ *     out[r, n] = sum_k act(pv[r,k])*Wt[n,k] + bias[n]
+ * act = DCLL_ACT_SIGMOID applies the layer kernels' sigmoid (v_exp_f32 + v_rcp_f32) to every staged value: the logits equal
+ * those of the pv = sigmoid(v) form up to the readout's summation order.  Always the LDS-staged 16x16x4 kernel: whole for
+ * K < 65536, in eight K-slices (partials in caller scratch, summed in slice order) for longer rows — chosen by K alone, so
+ * a row's logits do not depend on the row count, i.e. on how the caller chunks a batch (dcll_readout / dcll_readout_splitk
+ * choose by row count: they serve the per-step calls).  Needs K % 32 == 0 (K % 256 == 0 when split), N <= 64, 16-byte
+ * aligned pv / Wt — else DCLL_ERR_UNSUPPORTED (the caller keeps pv = sigmoid(v) and dcll_readout for such shapes);
+ * scratch_floats >= dcll_readout_act_scratch(rows, K, N) (0: scratch may be NULL).
+ */
+int64_t dcll_readout_act_scratch(int64_t rows, int32_t K, int32_t N);
+int dcll_readout_act(const float *pv, const float *Wt, const float *bias, float *out, float *scratch,
+                     int64_t scratch_floats, int64_t rows, int32_t K, int32_t N, int32_t act, void *stream);
 
 /*
  * The same readout with the kernel form chosen by the caller:

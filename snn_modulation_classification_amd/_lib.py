@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_PKG, "libdcll_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class DCLLHipError(RuntimeError):
@@ -46,6 +46,13 @@ class AdamTensor(ctypes.Structure):
                 ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
+class LayerOpts(ctypes.Structure):
+    """dcll_layer_opts (ABI v3): int8 conv weights + per-output-channel scale, pv written before the sigmoid"""
+    _fields_ = [("w_q8", ctypes.c_void_p), ("w_scale", ctypes.c_void_p), ("pv_presigmoid", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+ACT_NONE, ACT_SIGMOID = 0, 1
 ADAM_MAX_TENSORS = 8
 LOSS_SMOOTH_L1, LOSS_MSE = 0, 1
 
@@ -54,24 +61,28 @@ _F32 = ctypes.c_float
 _DP = ctypes.POINTER(ConvDesc)
 _DDP = ctypes.POINTER(DenseDesc)
 _IP = ctypes.POINTER(ctypes.c_int32)
+_OP = ctypes.POINTER(LayerOpts)
 
 # every symbol include/dcll_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "dcll_version": (_I32, []),
     "dcll_last_error": (ctypes.c_char_p, []),
     "dcll_conv_out_shape": (_I32, [_DP, _IP, _IP, _IP, _IP]),
-    "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_I32, _P]),
+    "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_OP, _I32, _P]),
     "dcll_conv_lif_backward": (_I32, [_DP] + [_P] * 13 + [_I64, _I32, _P]),
     "dcll_local_loss_grad": (_I32, [_P] * 7 + [_I32, _I32, _I32, _P]),
     "dcll_adam_step": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P]),
     "dcll_adam_step_dyn": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P, _P]),
     "dcll_cells_to_planes": (_I32, [_P, _P, _I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
-    "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _P, _P, _I32, _I32, _I32, _P]),
+    "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _P, _P, _I32, _OP, _I32, _I32, _P]),
     "dcll_permute_readout": (_I32, [_P, _P, _I32, _P]),
-    "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_P, _P, _I32, _I32, _I32, _P]),
-    "dcll_conv_lif_sequence_iq": (_I32, [_DP, _P, _P, _P, _I32, _I32] + [_P] * 9 + [_P, _P, _I32, _I32, _I32, _P]),
+    "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_P, _P, _I32, _OP, _I32, _I32, _P]),
+    "dcll_conv_lif_sequence_iq": (_I32, [_DP, _P, _P, _P, _I32, _I32] + [_P] * 9 + [_P, _P, _I32, _OP, _I32, _I32, _P]),
     "dcll_pv_lowhigh": (_I32, [_P, _I64, _I32, _I32, _P, _P]),
+    "dcll_pv_lowhigh_act": (_I32, [_P, _I64, _I32, _I32, _P, _I32, _P]),
+    "dcll_readout_act_scratch": (_I64, [_I64, _I32, _I32]),
+    "dcll_readout_act": (_I32, [_P] * 5 + [_I64, _I64, _I32, _I32, _I32, _P]),
     "dcll_pv_lowhigh_steps": (_I32, [_I32, _I32]),
     "dcll_readout": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
     "dcll_readout_mode": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),

@@ -97,7 +97,7 @@ __global__ void k_trace(const float *__restrict__ x, const float *__restrict__ a
 
 // one thread per conv output element (b, co, y, x); pinned fmaf chain (cp, ky, kx, h).
 __global__ void k_conv_lif(dcll_conv_desc d, int ch, int cw, const float *__restrict__ eps1,
-                           const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ arp,
+                           const dcll_wsrc W, const float *__restrict__ bias, float *__restrict__ arp,
                            float *__restrict__ s_full, float *__restrict__ pv_full, float *__restrict__ v_out, long n)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +109,7 @@ __global__ void k_conv_lif(dcll_conv_desc d, int ch, int cw, const float *__rest
     int co = (int)(r % d.c_out);
     long b = r / d.c_out;
     const float *e = eps1 + b * d.c_in * d.h * d.w;
-    const float *w = W + (long)co * d.c_in * d.kh * d.kw;
+    const long wbase = (long)co * d.c_in * d.kh * d.kw;
     float acc = bias ? bias[co] : 0.0f;
     const int npair = (d.c_in + 1) >> 1;
     for (int cp = 0; cp < npair; ++cp)
@@ -124,7 +124,7 @@ __global__ void k_conv_lif(dcll_conv_desc d, int ch, int cw, const float *__rest
                     int ci = 2 * cp + hh;
                     if (ci < d.c_in) {
                         float ev = in ? e[((long)ci * d.h + yy) * d.w + xq] : 0.0f;
-                        acc = __builtin_fmaf(ev, w[((long)ci * d.kh + ky) * d.kw + kx], acc);
+                        acc = __builtin_fmaf(ev, W.at(wbase + ((long)ci * d.kh + ky) * d.kw + kx, co), acc);
                     }
                 }
             }
@@ -150,7 +150,7 @@ __global__ void k_conv_lif(dcll_conv_desc d, int ch, int cw, const float *__rest
 // broadcasts, inputs from registers).  Out-of-image taps and channels beyond c_in contribute fmaf(0, w, acc).
 template <int KH, int KW, int COG>
 __global__ __launch_bounds__(256) void k_conv_lif_tiled(dcll_conv_desc d, int ch, int cw, const float *__restrict__ eps1,
-                                                         const float *__restrict__ W, const float *__restrict__ bias,
+                                                         const dcll_wsrc W, const float *__restrict__ bias,
                                                          float *__restrict__ arp, float *__restrict__ s_full,
                                                          float *__restrict__ pv_full, float *__restrict__ v_out)
 {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_conv_lif_tiled(dcll_conv_desc d, int ch
         }
         for (int i = tid; i < COG * KK * 2; i += 256) {
             const int hh = i & 1, tap = (i >> 1) % KK, c = (i >> 1) / KK, ci = 2 * cp + hh;
-            wl[i] = (co0 + c < d.c_out && ci < d.c_in) ? W[((long)(co0 + c) * d.c_in + ci) * KK + tap] : 0.0f;
+            wl[i] = (co0 + c < d.c_out && ci < d.c_in) ? W.at(((long)(co0 + c) * d.c_in + ci) * KK + tap, co0 + c) : 0.0f;
         }
         __syncthreads();
         float win[2][KK];
@@ -1077,12 +1077,14 @@ constexpr int C1_MAXT = 4096;       // longest window the fused IQ encoder of k_
 // are parked in lanes r and 32 + r of one VGPR with v_writelane (immediate lane, SGPR source: two VALU instructions per
 // value, no select masks — the select chain of round 1 kept 16 64-bit masks and spilled ~100 SGPRs).
 // FAST: c_out == 32 and exactly the outputs spk_out + pv_out — the benchmark's configuration: no per-value channel /
-// pointer guards, and stores as uniform base + 32-bit lane offset.
-template <bool REFRACTORY, bool FAST, bool IQ>
+// pointer guards, and stores as uniform base + 32-bit lane offset.  FAST == 2: pv_out receives v instead of sigmoid(v)
+// (dcll_layer_opts pv_presigmoid: the readout applies the sigmoid) — 4 of the ~10 VALU instructions per value, two of them
+// quarter-rate transcendentals, leave the pipe this kernel shares with its MFMAs.
+template <bool REFRACTORY, int FAST, bool IQ>
 __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
                                                     const float *__restrict__ iq, const float *__restrict__ thr_i,
                                                     const float *__restrict__ thr_q, int L, int t0,
-                                                    const float *__restrict__ W, const float *__restrict__ bias,
+                                                    const dcll_wsrc W, const float *__restrict__ bias,
                                                     const float *__restrict__ tau4, float *__restrict__ eps0_g,
                                                     float *__restrict__ eps1_g, float *__restrict__ arp_g,
                                                     uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
 #pragma unroll
     for (int p = 0; p < 25; ++p) {
         const int tap = 2 * p + h;
-        wf[p] = (tap < 49 && j < c_out) ? W[j * 49 + tap] : 0.0f;
+        wf[p] = (tap < 49 && j < c_out) ? W.at(j * 49 + tap, j) : 0.0f;
     }
     // refractory trace of my two tiles: arp[tl][r] <-> channel (r&3)+8(r>>2)+4h, pixel 32*(2w+tl) + j
     float arp[2][16];
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
                 asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
                     : "+v"(myword) : "s"((uint32_t)mk), "s"((uint32_t)(mk >> 32)), "n"(r), "n"(32 + r));
                 if (FAST) {
-                    (pvb + ((r & 3) + 8 * (r >> 2)) * 256)[loff] = sigmoidf_dev(v);
+                    (pvb + ((r & 3) + 8 * (r >> 2)) * 256)[loff] = FAST == 2 ? v : sigmoidf_dev(v);
                 } else if (co < c_out) {
                     if (pv_out) pv_out[(obase + co) * 256 + 32 * m + j] = sigmoidf_dev(v);
                     if (v_out) v_out[(obase + co) * 256 + 32 * m + j] = v;
@@ -1230,7 +1232,7 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
 // PRIO: s_setprio of the wave that carries the stage's non-MFMA work (bits 0-1: level, bit 2: keep it through the chain).
 // Measured (experiments/ablate_c32.hip, B=1024): 0 -> 25.56 ms, 1 -> 25.18 ms, 5 -> 25.13 ms.
 template <bool REFRACTORY, int OUT = 3, int NRO = 0, int ABLATE = 0, int PRIO = 5, int BASES = 1>  // OUT bit0: pv, bit1: v
-__global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
+__global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict__ spk_in, const dcll_wsrc W,
                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
                                                       float *__restrict__ eps0_g, float *__restrict__ eps1_g,
                                                       float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
@@ -1265,7 +1267,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
 #pragma unroll
     for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-        for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
+        for (int k = 0; k < 49; ++k) wf[cp][k] = W.at(((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k, j);
 
     // trace state of my 4 channels: element (c, ii): channel 4w+c, pixel ii*64 + lane.  eps0 in registers, eps1 in
     // the LDS images at float offset ioff + c*CHF + ii*4*ROWF.
@@ -1572,7 +1574,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
 // ------------------------------------------------------------------------------------------------------------
 // DBG is a diagnostic knob for experiments/ablate_c32d.hip only (s_memtime stamps of workgroup 0 into v_out).
 template <bool REFRACTORY, int OUT, int DBG = 0>     // OUT bit0: pv, bit1: v
-__global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
+__global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict__ spk_in, const dcll_wsrc W,
                                                        const float *__restrict__ bias, const float *__restrict__ tau4,
                                                        float *__restrict__ eps0_g, float *__restrict__ eps1_g,
                                                        float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
@@ -1599,7 +1601,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
 #pragma unroll
     for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-        for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
+        for (int k = 0; k < 49; ++k) wf[cp][k] = W.at(((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k, j);
 
     // eps0 of my 4 channels: register group grp holds channel (grp - w) & 3 (see the header), element ii = pixel
     // ii*64 + lane; eps1 lives in the LDS images at float offset ioff + c*CHF + ii*4*ROWF
@@ -1981,6 +1983,35 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
     return DCLL_OK;
 }
 
+// The readout of the whole-sequence path (rows = T x chunk of the batch): the LDS-staged 16x16x4 kernel, whole for K < 65536,
+// in EIGHT K-slices + k_readout_sum for longer rows (large planes) — chosen by K alone, never by the row count, so a row's
+// logits do not depend on how a batch is chunked (dcll_readout / dcll_readout_splitk pick by row count: per-step calls).
+// act = DCLL_ACT_SIGMOID: pv holds v (dcll_layer_opts pv_presigmoid), the sigmoid is applied to the staged values.
+extern "C" int64_t dcll_readout_act_scratch(int64_t rows, int32_t K, int32_t N)
+{
+    return (rows > 0 && N > 0 && K >= 65536 && K % 256 == 0) ? 8 * rows * N : 0;
+}
+
+extern "C" int dcll_readout_act(const float *pv, const float *Wt, const float *bias, float *out, float *scratch,
+                                int64_t scratch_floats, int64_t rows, int32_t K, int32_t N, int32_t act, void *stream)
+{
+    if (rows == 0 || N == 0) return DCLL_OK;
+    if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1 || (act != DCLL_ACT_NONE && act != DCLL_ACT_SIGMOID))
+        return fail(DCLL_ERR_INVALID, "dcll_readout_act: bad argument");
+    if (!(K % RO_KC == 0 && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0))
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_readout_act: needs K % 32 == 0, N <= 64, 16-byte aligned pv / Wt");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t need = dcll_readout_act_scratch(rows, K, N);
+    if (need == 0) return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, 0, st, act);
+    if (!scratch || scratch_floats < need)
+        return fail(DCLL_ERR_INVALID, "dcll_readout_act: K >= 65536 is split over K and needs scratch (dcll_readout_act_scratch)");
+    int rc = dcll_launch_readout_t16(pv, Wt, nullptr, scratch, rows, K, N, K / 8, st, act);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_readout_sum, dim3(nblk(rows * N, 64)), dim3(256), 0, st, scratch, bias, out, rows * N, N, 8);
+    HIP_CHECK_LAUNCH("k_readout_sum");
+    return DCLL_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_lif_step_c32 — ONE timestep of a 32 -> 32 channel 7x7 layer on the 16x16 plane (the per-step drop-in and the
 // forward of a local-learning step), one sample per 256-thread workgroup, state through HBM.
@@ -2016,9 +2047,15 @@ struct step_wchunk {
             loff[i] = (r % 49) * STEP_WTS + (r / 49) * 32 + co;
         }
     }
-    __device__ __forceinline__ void fetch(const float *__restrict__ W, int cp)
+    __device__ __forceinline__ void fetch(const dcll_wsrc &W, int cp)
     {
-        const float *wc = W + cp * 98;          // wave-uniform base of the chunk
+        if (W.q) {                              // int8 weights (dcll_layer_opts): one rounded multiply per weight, here
+            const int8_t *wc = W.q + cp * 98;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) reg[i] = goff[i] >= 0 ? (float)wc[goff[i]] * W.scale[goff[i] / 1568] : 0.0f;
+            return;
+        }
+        const float *wc = W.f + cp * 98;        // wave-uniform base of the chunk
 #pragma unroll
         for (int i = 0; i < NW; ++i) reg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
     }
@@ -2033,7 +2070,7 @@ struct step_wchunk {
 // DBG (experiments/ablate_step.hip only; 0 in the product): 1 no MFMAs, 2 no epilogue stores, 4 no state traffic,
 // 8 no weight streaming, 16 no barrier per chunk (8, 16: wrong results, timing only)
 template <bool REFRACTORY, int DBG = 0>
-__global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ x, const float *__restrict__ W,
+__global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ x, const dcll_wsrc W,
                                                        const float *__restrict__ bias, const float *__restrict__ alpha,
                                                        const float *__restrict__ tau_m, const float *__restrict__ alphas,
                                                        const float *__restrict__ tau_s, int tau_is_tensor,
@@ -2179,7 +2216,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 // ------------------------------------------------------------------------------------------------------------
 constexpr int ST_RF = 22;                                          // region row stride
 template <bool REFRACTORY, int TH>
-__global__ __launch_bounds__(256) void k_lif_step_c32t(const float *__restrict__ W, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const float *__restrict__ bias,
                                                         const float *__restrict__ eps1_g, float *__restrict__ arp_g,
                                                         float *__restrict__ out_s, float *__restrict__ out_pv,
                                                         float *__restrict__ out_v, int H, int Wd, float alpharp, float wrp)
@@ -2332,7 +2369,7 @@ __global__ __launch_bounds__(256) void k_trace4(const f32x4 *__restrict__ x, con
 // TILED: planes of several 16x16 tiles (h % 16 == 0, w % 16 == 0): one workgroup per tile of a sample; the traces have
 // been advanced by k_trace4 before (the tile reads the new eps1 of its 3-pixel halo, x / eps0 are not touched here).
 template <bool REFRACTORY, bool TILED>
-__global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__restrict__ x, const float *__restrict__ W,
+__global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__restrict__ x, const dcll_wsrc W,
                                                       const float *__restrict__ bias, const float *__restrict__ alpha,
                                                       const float *__restrict__ tau_m, const float *__restrict__ alphas,
                                                       const float *__restrict__ tau_s, int tau_is_tensor,
@@ -2357,7 +2394,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__r
 #pragma unroll
     for (int p = 0; p < 25; ++p) {
         const int tap = 2 * p + h;
-        wf[p] = (tap < 49 && j < c_out) ? W[j * 49 + tap] : 0.0f;
+        wf[p] = (tap < 49 && j < c_out) ? W.at(j * 49 + tap, j) : 0.0f;
     }
     if (TILED) {
         for (int i = pix; i < 22 * PS + 8; i += 256) {
@@ -2414,16 +2451,20 @@ __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__r
     }
 }
 
-extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, const float *b,
+extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *Wf, const float *b,
                                   const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
                                   float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
                                   const float *out_W, const float *out_b, float *out_s, float *out_p, float *out_o,
-                                  float *out_pv, float *out_v, float *scratch, int32_t B, void *stream)
+                                  float *out_pv, float *out_v, float *scratch, const dcll_layer_opts *opts, int32_t B,
+                                  void *stream)
 {
     int rc = check_desc(d);
     if (rc) return rc;
     if (B == 0) return DCLL_OK;
-    if (!x || !W || !alpha || !tau_m || !alphas || !tau_s || !eps0 || !eps1 || !out_s || !out_pv)
+    rc = check_opts(Wf, opts, false, "dcll_conv_lif_step");
+    if (rc) return rc;
+    const dcll_wsrc W = make_wsrc(Wf, opts);
+    if (!x || !alpha || !tau_m || !alphas || !tau_s || !eps0 || !eps1 || !out_s || !out_pv)
         return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: null pointer");
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: refractory layer needs arp");
     if (B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_step: negative batch");
@@ -2814,6 +2855,10 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
 // smallest float32 >= edge — counted in one pass over the sampled steps' pv planes (wave ballots + popcount, one
 // atomic pair per workgroup).  counts[k][0..1], k = index of the sampled step inside the call.
 // ------------------------------------------------------------------------------------------------------------
+// SIG: the buffer holds v (dcll_layer_opts pv_presigmoid): the counted value is sigmoid(v), the same device function the
+// layer kernels would have applied — identical counters by construction (this pass reads 6 of 128 steps: the
+// transcendentals are free here).
+template <bool SIG>
 __global__ __launch_bounds__(256) void k_pv_lowhigh(const float *__restrict__ pv, long per_step, int iter0,
                                                      float thr_low, float thr_high,
                                                      unsigned long long *__restrict__ counts)
@@ -2833,15 +2878,16 @@ __global__ __launch_bounds__(256) void k_pv_lowhigh(const float *__restrict__ pv
             if (in) v = ((const f32x4 *)p)[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                lo += __popcll(__ballot(in && v[e] < thr_low));
-                hi += __popcll(__ballot(in && v[e] >= thr_high));
+                const float q = SIG ? sigmoidf_dev(v[e]) : v[e];
+                lo += __popcll(__ballot(in && q < thr_low));
+                hi += __popcll(__ballot(in && q >= thr_high));
             }
         }
         i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x;                  // scalar tail (per_step % 4 floats)
     }
     for (; i < per_step + stride - 1 - (per_step + stride - 1) % stride; i += stride) {
         const bool in = i < per_step;
-        const float v = in ? p[i] : 0.5f;
+        const float v = in ? (SIG ? sigmoidf_dev(p[i]) : p[i]) : 0.5f;
         lo += __popcll(__ballot(in && v < thr_low));
         hi += __popcll(__ballot(in && v >= thr_high));
     }
@@ -2865,7 +2911,7 @@ static float f32_ceil(double e)
 static inline int n_sampled_steps(int iter0, int T) { return (iter0 + T) / 20 - iter0 / 20; }
 
 static int launch_pv_lowhigh(const float *pv, long per_step, int T, int iter0, unsigned long long *counts,
-                             hipStream_t st, const char *who)
+                             hipStream_t st, const char *who, bool presig = false)
 {
     if (iter0 < 0) return fail(DCLL_ERR_INVALID, "negative iteration count", who);
     const int ns = n_sampled_steps(iter0, T);
@@ -2879,19 +2925,31 @@ static int launch_pv_lowhigh(const float *pv, long per_step, int T, int iter0, u
     long nb = (per_step / 4 + 255) / 256;
     if (nb < 1) nb = 1;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(k_pv_lowhigh, dim3((unsigned)nb, (unsigned)ns), dim3(256), 0, st, pv, per_step, iter0,
-                       f32_ceil(e1), f32_ceil(e18), counts);
+    if (presig)
+        hipLaunchKernelGGL(k_pv_lowhigh<true>, dim3((unsigned)nb, (unsigned)ns), dim3(256), 0, st, pv, per_step, iter0,
+                           f32_ceil(e1), f32_ceil(e18), counts);
+    else
+        hipLaunchKernelGGL(k_pv_lowhigh<false>, dim3((unsigned)nb, (unsigned)ns), dim3(256), 0, st, pv, per_step, iter0,
+                           f32_ceil(e1), f32_ceil(e18), counts);
     HIP_CHECK_LAUNCH("k_pv_lowhigh");
     return DCLL_OK;
+}
+
+extern "C" int dcll_pv_lowhigh_act(const float *pv, int64_t per_step, int32_t T, int32_t iter0, uint64_t *counts,
+                                   int32_t act, void *stream)
+{
+    if (T < 0 || per_step < 0 || iter0 < 0 || (act != DCLL_ACT_NONE && act != DCLL_ACT_SIGMOID))
+        return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: bad argument");
+    if (T == 0 || per_step == 0 || n_sampled_steps(iter0, T) == 0) return DCLL_OK;     // no histogram step: counts may be NULL
+    if (!counts) return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: null counters");
+    return launch_pv_lowhigh(pv, per_step, T, iter0, (unsigned long long *)counts, (hipStream_t)stream, "dcll_pv_lowhigh",
+                             act == DCLL_ACT_SIGMOID);
 }
 
 extern "C" int dcll_pv_lowhigh(const float *pv, int64_t per_step, int32_t T, int32_t iter0, uint64_t *counts,
                                void *stream)
 {
-    if (T < 0 || per_step < 0 || iter0 < 0) return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: bad argument");
-    if (T == 0 || per_step == 0 || n_sampled_steps(iter0, T) == 0) return DCLL_OK;     // no histogram step: counts may be NULL
-    if (!counts) return fail(DCLL_ERR_INVALID, "dcll_pv_lowhigh: null counters");
-    return launch_pv_lowhigh(pv, per_step, T, iter0, (unsigned long long *)counts, (hipStream_t)stream, "dcll_pv_lowhigh");
+    return dcll_pv_lowhigh_act(pv, per_step, T, iter0, counts, DCLL_ACT_NONE, stream);
 }
 
 extern "C" int32_t dcll_pv_lowhigh_steps(int32_t iter0, int32_t T) { return (iter0 < 0 || T < 0) ? 0 : n_sampled_steps(iter0, T); }
@@ -2920,14 +2978,27 @@ extern "C" int dcll_permute_readout(const float *Wt, float *Wp, int32_t N, void 
 
 constexpr int DCLL_C32D_MIN_T = 8;      // shorter sequences: k_lif_seq_c32 (half the pipeline fill)
 
-static int dcll_conv_lif_sequence_run(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
-                                      const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
-                                      float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
-                                      float *ro_out, int32_t n_ro, float *state_scratch, int32_t T, int32_t B,
-                                      void *stream);
+// In presigmoid mode a 7x7 kernel writes v through its v output: (pv_out, v_out) as the kernel gets them.  Both wanted
+// (tests): the kernel writes v_out, a stream-ordered copy fills pv_out afterwards.
+struct seq_outs { float *pv, *v, *copy_dst; };
+static inline seq_outs presig_outs(float *pv_out, float *v_out, bool presig)
+{
+    if (!presig || !pv_out) return {pv_out, v_out, nullptr};
+    if (!v_out) return {nullptr, pv_out, nullptr};
+    return {nullptr, v_out, pv_out};
+}
+static int presig_copy(const seq_outs &o, long n, hipStream_t st, const char *who)
+{
+    if (!o.copy_dst) return DCLL_OK;
+    if (hipMemcpyAsync(o.copy_dst, o.v, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DCLL_ERR_LAUNCH, "copy of v into pv_out failed", who);
+    }
+    return DCLL_OK;
+}
 
 template <bool R, int NRO>
-static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, const float *W, const float *b,
+static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, dcll_wsrc W, const float *b,
                        const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
                        float *v_out, const float *ro_Wp, const float *ro_b, float *ro_out, int T, float alpharp,
                        float wrp)
@@ -2944,51 +3015,15 @@ static void launch_c32(int out, int B, hipStream_t st, const uint32_t *spk_in, c
 #undef DCLL_LAUNCH_C32
 }
 
-extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
-                                      const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
-                                      float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
-                                      float *ro_out, int32_t n_ro, float *state_scratch, uint64_t *pv_lowhigh,
-                                      int32_t iter0, int32_t T, int32_t B, void *stream)
-{
-    int rc = check_desc(d);
-    if (rc) return rc;
-    const bool w3 = dcll_seq_w3_geometry(d) && d->c_in == 64;
-    if (!w3) {
-        rc = check_seq_geometry(d, 32, "dcll_conv_lif_sequence");
-        if (rc) return rc;
-    }
-    if (w3) {       // radio_ml_conv_ref.yaml geometry: pooled outputs (dcll_seq_w3.hip)
-        if (T == 0 || B == 0) return DCLL_OK;
-        if (!spk_in || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: null pointer");
-        if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: refractory layer needs arp");
-        if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: negative size");
-        if (n_ro) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout only for the 7x7 layers on the 16x16 plane");
-        rc = dcll_launch_seq_w3(d, spk_in, nullptr, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (hipStream_t)stream);
-        if (rc || !pv_lowhigh) return rc;
-        return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * (d->w / 2), T, iter0, (unsigned long long *)pv_lowhigh,
-                                 (hipStream_t)stream, "dcll_conv_lif_sequence");
-    }
-    rc = dcll_conv_lif_sequence_run(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, ro_Wp, ro_b, ro_out,
-                                    n_ro, state_scratch, T, B, stream);
-    if (rc || !pv_lowhigh || T <= 0 || B <= 0) return rc;
-    return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * d->w, T, iter0, (unsigned long long *)pv_lowhigh,
-                             (hipStream_t)stream, "dcll_conv_lif_sequence");
-}
-
-static int dcll_conv_lif_sequence_run(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+static int dcll_conv_lif_sequence_run(const dcll_conv_desc *d, const uint32_t *spk_in, dcll_wsrc W, const float *b,
                                       const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
                                       float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
                                       float *ro_out, int32_t n_ro, float *state_scratch, int32_t T, int32_t B,
-                                      void *stream)
+                                      hipStream_t st)
 {
-    if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
-    if (!spk_in || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: null pointer");
-    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: refractory layer needs arp");
-    if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: negative size");
     if (n_ro != 0 && n_ro != 24 && n_ro != 48)
         return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout supports 24 or 48 rows (target 24)");
     if (n_ro && (!ro_Wp || !ro_b || !ro_out)) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence: fused readout needs ro_Wp, ro_b, ro_out");
-    hipStream_t st = (hipStream_t)stream;
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
     if (d->h != 16 || d->w != 16) {         // large plane: k_lif_seq_c32t, one workgroup per (sample, 8 x 32 tile)
         if (n_ro) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence: fused readout only on the 16x16 plane");
@@ -3032,33 +3067,84 @@ static int dcll_conv_lif_sequence_run(const dcll_conv_desc *d, const uint32_t *s
     return DCLL_OK;
 }
 
-static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
-                     const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4, float *eps0,
-                     float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, float *state_scratch,
-                     uint64_t *pv_lowhigh, int iter0, int T, int B, hipStream_t st)
+extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *spk_in, const float *Wf, const float *b,
+                                      const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
+                                      float *pv_out, float *v_out, const float *ro_Wp, const float *ro_b,
+                                      float *ro_out, int32_t n_ro, float *state_scratch, uint64_t *pv_lowhigh,
+                                      int32_t iter0, const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream)
 {
+    const char *who = "dcll_conv_lif_sequence";
+    int rc = check_desc(d);
+    if (rc) return rc;
+    const bool w3 = dcll_seq_w3_geometry(d) && d->c_in == 64;
+    if (!w3) {
+        rc = check_seq_geometry(d, 32, who);
+        if (rc) return rc;
+    }
+    if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
+    rc = check_opts(Wf, opts, true, who);
+    if (rc) return rc;
+    if (!spk_in || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "null pointer", who);
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "refractory layer needs arp", who);
+    if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "negative size", who);
+    const bool presig = opts && opts->pv_presigmoid;
+    if (presig && n_ro) return fail(DCLL_ERR_INVALID, "pv_presigmoid cannot be combined with the fused readout", who);
+    const dcll_wsrc W = make_wsrc(Wf, opts);
+    hipStream_t st = (hipStream_t)stream;
+    long per_step;
+    if (w3) {       // radio_ml_conv_ref.yaml geometry: pooled outputs (dcll_seq_w3.hip)
+        if (n_ro) return fail(DCLL_ERR_UNSUPPORTED, "fused readout only for the 7x7 layers on the 16x16 plane", who);
+        rc = dcll_launch_seq_w3(d, spk_in, nullptr, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, presig, T, B, st);
+        per_step = (long)B * d->c_out * d->h * (d->w / 2);
+    } else {
+        const seq_outs o = presig_outs(pv_out, v_out, presig);
+        rc = dcll_conv_lif_sequence_run(d, spk_in, W, b, tau4, eps0, eps1, arp, spk_out, o.pv, o.v, ro_Wp, ro_b, ro_out,
+                                        n_ro, state_scratch, T, B, st);
+        per_step = (long)B * d->c_out * d->h * d->w;
+        if (!rc) rc = presig_copy(o, per_step * T, st, who);
+    }
+    if (rc || !pv_lowhigh) return rc;
+    return launch_pv_lowhigh(pv_out, per_step, T, iter0, (unsigned long long *)pv_lowhigh, st, who, presig);
+}
+
+static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
+                     const float *thr_q, int L, int t0, dcll_wsrc W, const float *b, const float *tau4, float *eps0,
+                     float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, float *state_scratch,
+                     uint64_t *pv_lowhigh, int iter0, bool presig, int T, int B, hipStream_t st)
+{
+    const char *who = "dcll_conv_lif_sequence_cells/_iq";
+    const long per_step = (long)B * d->c_out * d->h * d->w;
     if (pv_lowhigh) {       // statistics pass over the sampled steps' pv planes after the layer kernel
         int rc = launch_c1(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
-                           state_scratch, nullptr, 0, T, B, st);
+                           state_scratch, nullptr, 0, presig, T, B, st);
         if (rc) return rc;
-        return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * d->w, T, iter0, (unsigned long long *)pv_lowhigh, st,
-                                 "dcll_conv_lif_sequence_cells/_iq");
+        return launch_pv_lowhigh(pv_out, per_step, T, iter0, (unsigned long long *)pv_lowhigh, st, who, presig);
+    }
+    // both the presigmoid pv_out and v_out wanted (tests): v_out is written, pv_out is a copy of it
+    if (presig && pv_out && v_out) {
+        int rc = launch_c1(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, nullptr, v_out,
+                           state_scratch, nullptr, 0, false, T, B, st);
+        if (rc) return rc;
+        return presig_copy(seq_outs{nullptr, v_out, pv_out}, per_step * T, st, who);
     }
     if (d->h != 16 || d->w != 16)       // large plane: k_lif_seq_c1t, one workgroup per (sample, 8 x 32 tile)
         return dcll_launch_seq_c1t(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
-                                   state_scratch, T, B, st);
+                                   state_scratch, T, B, st, presig);
     const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out;
+    if (presig && !fastpath) { v_out = pv_out; pv_out = nullptr; }
 #define DCLL_LAUNCH_C1(R, F, Q)                                                                                         \
     hipLaunchKernelGGL((k_lif_seq_c1<R, F, Q>), dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W,  \
                        b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp)
 #define DCLL_LAUNCH_C1Q(R, F)                                                                                           \
     do { if (iq) DCLL_LAUNCH_C1(R, F, true); else DCLL_LAUNCH_C1(R, F, false); } while (0)
     if (d->refractory) {
-        if (fastpath) DCLL_LAUNCH_C1Q(true, true);
-        else DCLL_LAUNCH_C1Q(true, false);
+        if (fastpath && presig) DCLL_LAUNCH_C1Q(true, 2);
+        else if (fastpath) DCLL_LAUNCH_C1Q(true, 1);
+        else DCLL_LAUNCH_C1Q(true, 0);
     } else {
-        if (fastpath) DCLL_LAUNCH_C1Q(false, true);
-        else DCLL_LAUNCH_C1Q(false, false);
+        if (fastpath && presig) DCLL_LAUNCH_C1Q(false, 2);
+        else if (fastpath) DCLL_LAUNCH_C1Q(false, 1);
+        else DCLL_LAUNCH_C1Q(false, 0);
     }
 #undef DCLL_LAUNCH_C1Q
 #undef DCLL_LAUNCH_C1
@@ -3066,47 +3152,56 @@ static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float 
     return DCLL_OK;
 }
 
-extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *W, const float *b,
+extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, const float *Wf, const float *b,
                                             const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out,
                                             float *pv_out, float *v_out, float *state_scratch, uint64_t *pv_lowhigh,
-                                            int32_t iter0, int32_t T, int32_t B, void *stream)
+                                            int32_t iter0, const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream)
 {
+    const char *who = "dcll_conv_lif_sequence_cells";
     int rc = check_desc(d);
     if (rc) return rc;
     const bool w3 = dcll_seq_w3_geometry(d) && d->c_in == 1;
     if (!w3) {
-        rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_cells");
+        rc = check_seq_geometry(d, 1, who);
         if (rc) return rc;
     }
     if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
-    if (!cells || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: null pointer");
-    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: refractory layer needs arp");
-    if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_cells: negative size");
+    rc = check_opts(Wf, opts, true, who);
+    if (rc) return rc;
+    if (!cells || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "null pointer", who);
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "refractory layer needs arp", who);
+    if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "negative size", who);
+    const bool presig = opts && opts->pv_presigmoid;
+    const dcll_wsrc W = make_wsrc(Wf, opts);
     if (w3) {       // first layer of radio_ml_conv_ref.yaml: pooled outputs (dcll_seq_w3.hip)
-        rc = dcll_launch_seq_w3(d, nullptr, cells, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (hipStream_t)stream);
+        rc = dcll_launch_seq_w3(d, nullptr, cells, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, presig, T, B,
+                                (hipStream_t)stream);
         if (rc || !pv_lowhigh) return rc;
         return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * (d->w / 2), T, iter0, (unsigned long long *)pv_lowhigh,
-                                 (hipStream_t)stream, "dcll_conv_lif_sequence_cells");
+                                 (hipStream_t)stream, who, presig);
     }
     return launch_c1(d, cells, nullptr, nullptr, nullptr, 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
-                     state_scratch, pv_lowhigh, iter0, T, B, (hipStream_t)stream);
+                     state_scratch, pv_lowhigh, iter0, presig, T, B, (hipStream_t)stream);
 }
 
 extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
-                                         int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
+                                         int32_t L, int32_t t0, const float *Wf, const float *b, const float *tau4,
                                          float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
                                          float *v_out, float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
-                                         int32_t T, int32_t B, void *stream)
+                                         const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream)
 {
-    int rc = check_seq_geometry(d, 1, "dcll_conv_lif_sequence_iq");
+    const char *who = "dcll_conv_lif_sequence_iq";
+    int rc = check_seq_geometry(d, 1, who);
     if (rc) return rc;
     if (T == 0 || B == 0) return DCLL_OK;      // empty input: nothing to do (its pointers may be NULL)
-    if (!iq || !thr_i || !thr_q || !W || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: null pointer");
-    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: refractory layer needs arp");
-    if (T < 0 || B < 0 || t0 < 0 || t0 + T > L) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_sequence_iq: window [t0, t0+T) outside the IQ row");
-    if (T > C1_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_sequence_iq: at most 4096 timesteps per launch");
-    return launch_c1(d, nullptr, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
-                     state_scratch, pv_lowhigh, iter0, T, B, (hipStream_t)stream);
+    rc = check_opts(Wf, opts, true, who);
+    if (rc) return rc;
+    if (!iq || !thr_i || !thr_q || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "null pointer", who);
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "refractory layer needs arp", who);
+    if (T < 0 || B < 0 || t0 < 0 || t0 + T > L) return fail(DCLL_ERR_INVALID, "window [t0, t0+T) outside the IQ row", who);
+    if (T > C1_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "at most 4096 timesteps per launch", who);
+    return launch_c1(d, nullptr, iq, thr_i, thr_q, L, t0, make_wsrc(Wf, opts), b, tau4, eps0, eps1, arp, spk_out, pv_out,
+                     v_out, state_scratch, pv_lowhigh, iter0, opts && opts->pv_presigmoid, T, B, (hipStream_t)stream);
 }
 
 extern "C" int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t T, int32_t B, int32_t N,

@@ -41,24 +41,49 @@ static inline int fail(int code, const char *msg, const char *who = nullptr)
         }                                                                                   \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------------------
+// conv weights as a kernel sees them: fp32, or int8 + one fp32 scale per output channel (dcll_layer_opts, ABI v3).
+// at(idx, co) is the ONE place a weight is converted: (float)q * scale[co], a single rounded multiply — bit for bit what
+// the dequantised fp32 tensor holds, so every chain downstream is unchanged.  The branch is wave-uniform.
+// ------------------------------------------------------------------------------------------------------------
+struct dcll_wsrc {
+    const float *f;
+    const int8_t *q;
+    const float *scale;
+    __device__ __forceinline__ float at(long idx, int co) const { return q ? (float)q[idx] * scale[co] : f[idx]; }
+};
+static inline dcll_wsrc make_wsrc(const float *W, const dcll_layer_opts *o)
+{
+    return (o && o->w_q8) ? dcll_wsrc{nullptr, o->w_q8, o->w_scale} : dcll_wsrc{W, nullptr, nullptr};
+}
+// opts of a call checked once: -> DCLL_OK, or the failure code with the message set
+static inline int check_opts(const float *W, const dcll_layer_opts *o, bool allow_presig, const char *who)
+{
+    if (!o) return W ? DCLL_OK : fail(DCLL_ERR_INVALID, "null weight pointer", who);
+    if (o->reserved != 0) return fail(DCLL_ERR_INVALID, "dcll_layer_opts.reserved must be 0", who);
+    if (o->w_q8 ? !o->w_scale : !W) return fail(DCLL_ERR_INVALID, "weights: need W (fp32) or w_q8 + w_scale (int8)", who);
+    if (o->pv_presigmoid && !allow_presig) return fail(DCLL_ERR_INVALID, "pv_presigmoid is an option of the sequence calls", who);
+    return DCLL_OK;
+}
+
 // k_lif_seq_c32t (dcll_seq_tiled.hip): the 32 -> 32 channel sequence layer on planes with h % 8 == 0, w % 32 == 0
 __attribute__((visibility("hidden")))
-int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, dcll_wsrc W, const float *b,
                          const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
                          float *v_out, float *state_scratch, int32_t T, int32_t B, hipStream_t st);
 // k_lif_seq_c1t: the first layer (c_in 1) on such planes, input as cell indices or raw IQ
 __attribute__((visibility("hidden")))
 int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
-                        const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4,
+                        const float *thr_q, int L, int t0, dcll_wsrc W, const float *b, const float *tau4,
                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
-                        float *state_scratch, int T, int B, hipStream_t st);
+                        float *state_scratch, int T, int B, hipStream_t st, bool presig = false);
 
 // k_lif_seq_w3 (dcll_seq_w3.hip): the (1,3)-kernel / 64-channel / (1,2)-pool layers of radio_ml_conv_ref.yaml, all T steps
 __attribute__((visibility("hidden"))) bool dcll_seq_w3_geometry(const dcll_conv_desc *d);
 __attribute__((visibility("hidden")))
-int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const int32_t *cells, const float *W, const float *b,
+int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const int32_t *cells, dcll_wsrc W, const float *b,
                        const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
-                       float *v_out, int32_t T, int32_t B, hipStream_t st);
+                       float *v_out, bool presigmoid, int32_t T, int32_t B, hipStream_t st);
 
 // k_readout_direct (dcll_readout.hip): LDS-free 16x16x4 readout GEMM in <= 64 VGPRs (fits beside a sequence kernel)
 __attribute__((visibility("hidden")))
@@ -68,7 +93,7 @@ int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bi
 // k_readout_t16 (dcll_readout.hip): LDS-staged 16x16x4 readout GEMM, 128 rows x 16 NT readout rows per workgroup
 __attribute__((visibility("hidden")))
 int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
-                            int kslice, hipStream_t st);
+                            int kslice, hipStream_t st, int act = DCLL_ACT_NONE);
 
 // ------------------------------------------------------------------------------------------------------------
 // shared device helpers

@@ -136,7 +136,10 @@ constexpr int T16_ROWS = 128, T16_KC = 32, T16_LD = 36;
 
 // kslice > 0 (few rows: per-step calls, rows = batch): workgroup (x, y) handles only columns [y * kslice, (y+1) * kslice)
 // of K and writes its partial tile, without the bias, to out + y * rows * N; k_readout_sum adds the slices in order.
-template <int NT>
+// SIG (dcll_readout_act, DCLL_ACT_SIGMOID): the staged pv values are v (dcll_layer_opts pv_presigmoid) and the sigmoid is
+// applied here, once per value, between the global load and the LDS write — the kernel is HBM-bound and has the vector
+// slots that the layer kernels (which share their vector pipe with the fp32 MFMAs) do not.
+template <int NT, bool SIG>
 __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ pv, const float *__restrict__ Wt,
                                                       const float *__restrict__ bias, float *__restrict__ out,
                                                       long rows, int K, int N, int kslice)
@@ -172,7 +175,13 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
     fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += T16_KC) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(f32x4 *)(sA + (rsub + 32 * q) * T16_LD + kc) = ra[q];
+        for (int q = 0; q < 4; ++q) {
+            if (SIG) {      // (rows past the end stage sigmoid(0): they are computed and never stored)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[q][e] = sigmoidf_dev(ra[q][e]);
+            }
+            *(f32x4 *)(sA + (rsub + 32 * q) * T16_LD + kc) = ra[q];
+        }
 #pragma unroll
         for (int q = 0; q < NBF; ++q)
             if (rsub + 32 * q < NT * 16) *(f32x4 *)(sB + (rsub + 32 * q) * T16_LD + kc) = rb[q];
@@ -215,13 +224,21 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
 // Requires K % 32 == 0, N <= 64, 16-byte aligned pv / Wt rows (the caller checked).  kslice > 0: split-K launch (K %
 // kslice == 0, kslice % 32 == 0), `out` = the partial tiles (K / kslice) x rows x N.
 int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
-                            int kslice, hipStream_t st)
+                            int kslice, hipStream_t st, int act)
 {
     const dim3 g((unsigned)((rows + T16_ROWS - 1) / T16_ROWS), kslice > 0 ? K / kslice : 1);
-    if (N <= 16) hipLaunchKernelGGL(k_readout_t16<1>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
-    else if (N <= 32) hipLaunchKernelGGL(k_readout_t16<2>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
-    else if (N <= 48) hipLaunchKernelGGL(k_readout_t16<3>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
-    else hipLaunchKernelGGL(k_readout_t16<4>, g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);
+#define DCLL_T16(NT_)                                                                                                   \
+    do {                                                                                                                \
+        if (act == DCLL_ACT_SIGMOID)                                                                                    \
+            hipLaunchKernelGGL((k_readout_t16<NT_, true>), g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice);  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_readout_t16<NT_, false>), g, dim3(256), 0, st, pv, Wt, bias, out, rows, K, N, kslice); \
+    } while (0)
+    if (N <= 16) DCLL_T16(1);
+    else if (N <= 32) DCLL_T16(2);
+    else if (N <= 48) DCLL_T16(3);
+    else DCLL_T16(4);
+#undef DCLL_T16
     HIP_CHECK_LAUNCH("k_readout_t16");
     return DCLL_OK;
 }

@@ -34,7 +34,7 @@ struct tgroup { int row0, nrows; };
 __device__ constexpr tgroup TG[4] = {{5, 3}, {8, 3}, {11, 3}, {0, 5}};
 
 template <bool REFRACTORY, int OUT>     // OUT bit0: pv, bit1: v
-__global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict__ spk_in, const float *__restrict__ W,
+__global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict__ spk_in, const dcll_wsrc W,
                                                        const float *__restrict__ bias, const float *__restrict__ tau4,
                                                        const float *__restrict__ eps0_in,
                                                        const float *__restrict__ eps1_in, float *__restrict__ eps0_g,
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
 #pragma unroll
     for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-        for (int k = 0; k < 49; ++k) wf[cp][k] = W[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
+        for (int k = 0; k < 49; ++k) wf[cp][k] = W.at(((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k, j);
 
     // refractory trace of my epilogue share: tiles (rows) m = 2k + wpar (k = pair index), quad wq
     float arp[4][4];
@@ -353,12 +353,12 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
 constexpr int C1T_MAXT = 4096;
 constexpr int C1T_REGION = 14 * TRW;        // 532
 
-// FAST: c_out == 32 and exactly the outputs spk_out + pv_out (see k_lif_seq_c1).
-template <bool REFRACTORY, bool FAST = false>
+// FAST: c_out == 32 and exactly the outputs spk_out + pv_out (see k_lif_seq_c1); 2: pv_out receives v (pv_presigmoid).
+template <bool REFRACTORY, int FAST = 0>
 __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *__restrict__ cells,
                                                       const float *__restrict__ iq, const float *__restrict__ thr_i,
                                                       const float *__restrict__ thr_q, int L, int t0,
-                                                      const float *__restrict__ W, const float *__restrict__ bias,
+                                                      const dcll_wsrc W, const float *__restrict__ bias,
                                                       const float *__restrict__ tau4, const float *__restrict__ eps0_in,
                                                       const float *__restrict__ eps1_in, float *__restrict__ eps0_g,
                                                       float *__restrict__ eps1_g, float *__restrict__ arp_g,
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int kx = 2 * i + h;
-            wf[ky][i] = (kx < 7 && j < c_out) ? W[j * 49 + ky * 7 + kx] : 0.0f;
+            wf[ky][i] = (kx < 7 && j < c_out) ? W.at(j * 49 + ky * 7 + kx, j) : 0.0f;
         }
     // refractory trace of my two tiles (rows y0 + 2w + tl): arp[tl][r] <-> channel (r&3)+8(r>>2)+4h, column x0 + j
     float arp[2][16];
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
                 asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
                     : "+v"(myword) : "s"((uint32_t)mk), "s"((uint32_t)(mk >> 32)), "n"(r), "n"(32 + r));
                 if (FAST) {
-                    (pvb + ((r & 3) + 8 * (r >> 2)) * HW)[loff] = sigmoidf_dev(v);
+                    (pvb + ((r & 3) + 8 * (r >> 2)) * HW)[loff] = FAST == 2 ? v : sigmoidf_dev(v);
                 } else if (co < c_out) {
                     if (pv_out) pv_out[(obase + co) * HW + opix] = sigmoidf_dev(v);
                     if (v_out) v_out[(obase + co) * HW + opix] = v;
@@ -511,9 +511,9 @@ static int snapshot_state(const float *eps0, const float *eps1, float *scratch, 
 }
 
 int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
-                        const float *thr_q, int L, int t0, const float *W, const float *b, const float *tau4,
+                        const float *thr_q, int L, int t0, dcll_wsrc W, const float *b, const float *tau4,
                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
-                        float *state_scratch, int T, int B, hipStream_t st)
+                        float *state_scratch, int T, int B, hipStream_t st, bool presig)
 {
     if (iq && T > C1T_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "fused IQ encoder: T exceeds 4096 steps");
     const long nwg = (long)B * (d->h / 8) * (d->w / 32);
@@ -523,23 +523,26 @@ int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const flo
     if (rc) return rc;
     const float *eps0_in = state_scratch, *eps1_in = state_scratch + nstate;
     const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out && (long)d->h * d->w * 32 < (1L << 30);
+    if (presig && !fastpath) { v_out = pv_out; pv_out = nullptr; }        // (the caller made sure only one of them is wanted)
 #define DCLL_LAUNCH_C1T(R, F)                                                                                           \
     hipLaunchKernelGGL((k_lif_seq_c1t<R, F>), dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q,  \
                        L, t0, W, b, tau4, eps0_in, eps1_in, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,         \
                        d->alpharp, d->wrp)
     if (d->refractory) {
-        if (fastpath) DCLL_LAUNCH_C1T(true, true);
-        else DCLL_LAUNCH_C1T(true, false);
+        if (fastpath && presig) DCLL_LAUNCH_C1T(true, 2);
+        else if (fastpath) DCLL_LAUNCH_C1T(true, 1);
+        else DCLL_LAUNCH_C1T(true, 0);
     } else {
-        if (fastpath) DCLL_LAUNCH_C1T(false, true);
-        else DCLL_LAUNCH_C1T(false, false);
+        if (fastpath && presig) DCLL_LAUNCH_C1T(false, 2);
+        else if (fastpath) DCLL_LAUNCH_C1T(false, 1);
+        else DCLL_LAUNCH_C1T(false, 0);
     }
 #undef DCLL_LAUNCH_C1T
     HIP_CHECK_LAUNCH("k_lif_seq_c1t");
     return DCLL_OK;
 }
 
-int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, const float *W, const float *b,
+int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, dcll_wsrc W, const float *b,
                          const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
                          float *v_out, float *state_scratch, int32_t T, int32_t B, hipStream_t st)
 {

@@ -28,9 +28,12 @@ constexpr int W3_CHS = 388;         // floats per channel image: 256 pixels + 25
 
 // WIDE: W >= 32 — a thread's 32 trace pixels lie in one row, their LDS offsets are immediates (for narrower planes every
 // element adds a wave-uniform row term: two more instructions per access)
-template <int CIN, bool REFRACTORY, int OUT, bool WIDE>     // OUT bit0: pooled pv, bit1: un-pooled v
+// OUT bit0: pooled pv, bit1: un-pooled v, bit2 (with bit0): the pooled map is written BEFORE the sigmoid (dcll_layer_opts
+// pv_presigmoid: max-pooled v; the readout applies the sigmoid) — two quarter-rate transcendentals and two more VALU
+// instructions per value off the pipe this kernel shares with its MFMAs
+template <int CIN, bool REFRACTORY, int OUT, bool WIDE>
 __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
-                                                     const float *__restrict__ W, const float *__restrict__ bias,
+                                                     const dcll_wsrc W, const float *__restrict__ bias,
                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
                                                      float *__restrict__ eps1_g, float *__restrict__ arp_g,
                                                      uint32_t *__restrict__ spk_out, float *__restrict__ pv_out,
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // ---- weights of my output-channel tile, stationary: A[co = 32 mt + jj][k] ----------------------------------------
     float wf[NK];
     if (CIN == 1) {         // k lanes = tap parity: step 0 = taps (0,1), step 1 = taps (2, zero-weight pad)
-        wf[0] = W[(32 * mt + jj) * 3 + h];
-        wf[NK - 1] = h == 0 ? W[(32 * mt + jj) * 3 + 2] : 0.0f;
+        wf[0] = W.at((32 * mt + jj) * 3 + h, 32 * mt + jj);
+        wf[NK - 1] = h == 0 ? W.at((32 * mt + jj) * 3 + 2, 32 * mt + jj) : 0.0f;
     } else {                // k lanes = input-channel pair: step s = cp * 3 + kx -> W[co][2 cp + h][kx]
 #pragma unroll
-        for (int s = 0; s < NK; ++s) wf[s] = W[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3];
+        for (int s = 0; s < NK; ++s) wf[s] = W.at(((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3, 32 * mt + jj);
     }
     // ---- my two pixel tiles (independent chains) ----------------------------------------------------------------------
     const int perm = jj < 16 ? 2 * jj : 2 * (jj - 16) + 1;          // lane -> pixel of the tile (even | odd)
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                     asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
                         : "+v"(vw) : "s"(w0), "s"(w1), "n"(r), "n"(32 + r));
                     vv[k] = v;
-                    if (OUT & 1) q[k] = sigmoidf_dev(v);
+                    if (OUT & 1) q[k] = (OUT & 4) ? v : sigmoidf_dev(v);
                 });
                 if (OUT & 1) {
                     float o[4];
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                     for (int k = 0; k < 4; ++k) o[k] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(q[k]), 0x401F));   // lane ^ 16
                     if (valid) {
                         // both lanes of a pooling pair hold the pair's maximum and store it to the same address: no lane
-                        // predicate, no exec-mask branch per value (sigmoid outputs are never NaN: plain v_max_f32)
+                        // predicate, no exec-mask branch per value (neither sigmoid outputs nor v are ever NaN: plain v_max_f32)
                         static_for<0, 4>([&](auto kc) {
                             constexpr int k = decltype(kc)::value, r = r0 + k, cr = (r & 3) + 8 * (r >> 2);
                             float qm;
@@ -275,9 +278,9 @@ bool dcll_seq_w3_geometry(const dcll_conv_desc *d)
            d->pool_h == 1 && d->pool_w == 2 && pow2 && ((long)d->h * d->w) % 32 == 0 && (256 % d->w == 0 || d->w == 256);
 }
 
-int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const int32_t *cells, const float *W, const float *b,
+int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const int32_t *cells, dcll_wsrc W, const float *b,
                        const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
-                       float *v_out, int32_t T, int32_t B, hipStream_t st)
+                       float *v_out, bool presigmoid, int32_t T, int32_t B, hipStream_t st)
 {
     const long HW = (long)d->h * d->w;
     if (HW >= (1L << 24)) return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3): plane larger than 2^24 pixels");
@@ -290,7 +293,7 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     const long ntile = (long)B * (HW / 32);
     const long nwg = (ntile + W3_NT - 1) / W3_NT;
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x tiles exceeds the grid limit");
-    const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0);
+    const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0) | ((pv_out && presigmoid) ? 4 : 0);
 #define DCLL_LAUNCH_W3W(C, R, O, WD)                                                                                    \
     hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, b, tau4,    \
                        eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp)
@@ -301,7 +304,9 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     case 0: DCLL_LAUNCH_W3(C, R, 0); break;                                                                              \
     case 1: DCLL_LAUNCH_W3(C, R, 1); break;                                                                              \
     case 2: DCLL_LAUNCH_W3(C, R, 2); break;                                                                              \
-    default: DCLL_LAUNCH_W3(C, R, 3); break;                                                                             \
+    case 3: DCLL_LAUNCH_W3(C, R, 3); break;                                                                              \
+    case 5: DCLL_LAUNCH_W3(C, R, 5); break;                                                                              \
+    default: DCLL_LAUNCH_W3(C, R, 7); break;                                                                             \
     }
     if (d->c_in == 1) {
         if (d->refractory) { DCLL_LAUNCH_W3O(1, true) } else { DCLL_LAUNCH_W3O(1, false) }

@@ -31,6 +31,7 @@ from .._lib import DenseDesc
 logger = logging.getLogger(__name__)
 
 device = 'cuda'      # same module-level switch as the reference (:34); 'cuda' is the MI355X under ROCm
+_UNSET = object()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -134,6 +135,34 @@ class ContinuousConv2D(nn.Module):
         self.wrp = 0.
         self.alpharp = .65
         self.state = None
+        self._q8 = None
+
+    # -- int8 weights (BASELINE config 5; the build's definition, quant.py) -----------------------------------------
+    def set_int8_weights(self, q, scale):
+        """Keep the conv weight's int8 form (q int8 like `weight`, scale fp32 (c_out,)) beside the fp32 Parameter, which
+        must hold exactly the dequantised values q * scale (quant.apply_int8_weights writes both).  From now on the
+        kernels read the int8 tensor through the C ABI (dcll_layer_opts) — bit-identical results, a quarter of the
+        weight bytes.  Dropped as soon as `weight` is modified (a learning step, load_state_dict)."""
+        if q is None:
+            self._q8 = None
+            return
+        if tuple(q.shape) != tuple(self.weight.shape) or q.dtype != torch.int8 or scale.shape != (self.out_channels,):
+            raise ValueError('int8 weights must be int8 %s with a (%d,) fp32 scale' % (tuple(self.weight.shape),
+                                                                                     self.out_channels))
+        dev = self.weight.device
+        self._q8 = (q.to(dev).contiguous(), scale.to(dev, torch.float32).contiguous(), self.weight._version,
+                    self.weight.data_ptr())
+
+    def int8_weights(self):
+        """(q, scale) while they still describe `weight`, else None."""
+        q8 = self._q8
+        if q8 is None or os.environ.get('DCLL_INT8_ABI', '1') == '0':
+            return None
+        if q8[2] != self.weight._version or q8[3] != self.weight.data_ptr() or q8[0].device != self.weight.device:
+            logger.warning('conv weight changed after quantisation: int8 form dropped, kernels read the fp32 weight')
+            self._q8 = None
+            return None
+        return q8[0], q8[1]
 
     # -- parameters ---------------------------------------------------------------------------------------------
     def _set_tau(self, alpha, alphas):
@@ -255,7 +284,8 @@ class ContinuousConv2D(nn.Module):
                 desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt,
                 st.eps0, st.eps1, arp,
                 None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
-                None if output_ is None else output_.weight, None if output_ is None else output_.bias, out=out)
+                None if output_ is None else output_.weight, None if output_ is None else output_.bias, out=out,
+                q8=self.int8_weights())
 
     def forward(self, input):
         """-> (output spikes, pv, pvmem), un-pooled (reference :407-426)."""
@@ -459,14 +489,16 @@ class Conv2dDCLLlayer(nn.Module):
         return cache[1], cache[2]
 
     def forward_sequence(self, inp, T, B, kind, want_spikes=True, buffers=None, fuse_readout=False, batch_slice=None,
-                         want_pv=True, lowhigh_iter0=None):
+                         want_pv=True, lowhigh_iter0=None, presigmoid=False):
         """All T steps in one launch.  inp: cells (T,B) int32 ('cells') or packed spikes (T,B,32,H*W/32) int32 ('packed').
         Neuron state is read from / written back to self.i2h.state (rows batch_slice .. batch_slice+B of it when
         `batch_slice` is given: a chunk of a larger batch).
         -> (packed spikes, pv (T,B,C,H,W) or None, logits (T,B,24|48) or None).  With fuse_readout ('packed' only)
         the readout(s) are computed in the kernel's epilogue and pv is not materialised.
         `lowhigh_iter0` (the slice's iteration count before the sequence): also count pv's first / last histogram bin
-        on the reference's histogram steps (:658-661); the (n,2) int64 counters are left in buffers['lowhigh']."""
+        on the reference's histogram steps (:658-661); the (n,2) int64 counters are left in buffers['lowhigh'].
+        `presigmoid`: the returned pv buffer holds v = pvmem + arp (max-pooled where the layer pools) instead of
+        sigmoid(v); the caller's readout applies the sigmoid (ops.readout_act) — the statistics are unchanged."""
         i2h = self.i2h
         buffers = {} if buffers is None else buffers
         buffers.pop('lowhigh', None)
@@ -482,27 +514,30 @@ class Conv2dDCLLlayer(nn.Module):
         desc = i2h.make_desc(self.im_dims, self.pooling, self.target_size, self.output_layer)
         tau4 = i2h.tau_per_channel()
         arp = st.arp if len(st) > 2 else None
+        q8 = i2h.int8_weights()
+        presigmoid = bool(presigmoid and want_pv and not fuse_readout)
         with torch.no_grad():
             if kind == 'cells':
                 spk, pv, _ = ops.conv_lif_sequence_cells(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,
                                                          T, B, want_spikes=want_spikes, want_pv=want_pv, out=buffers,
-                                                         lowhigh_iter0=lowhigh_iter0)
+                                                         lowhigh_iter0=lowhigh_iter0, q8=q8, presigmoid=presigmoid)
                 return spk, pv, None
             if kind == 'iq':        # inp = (iq (B,2,L), thr_i, thr_q, t0): encoder fused into the layer kernel
                 iq, thr_i, thr_q, t0 = inp
                 spk, pv, _ = ops.conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, i2h.weight, i2h.bias, tau4, st.eps0,
                                                       st.eps1, arp, T, B, want_spikes=want_spikes, want_pv=want_pv,
-                                                      out=buffers, lowhigh_iter0=lowhigh_iter0)
+                                                      out=buffers, lowhigh_iter0=lowhigh_iter0, q8=q8,
+                                                      presigmoid=presigmoid)
                 return spk, pv, None
             if fuse_readout:
                 Wp, rb = self.fused_readout_weights()
                 spk, _, _, logits = ops.conv_lif_sequence(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp,
                                                           T, B, want_spikes=want_spikes, want_pv=False, out=buffers,
-                                                          ro_Wp=Wp, ro_b=rb)
+                                                          ro_Wp=Wp, ro_b=rb, q8=q8)
                 return spk, None, logits
             spk, pv, _ = ops.conv_lif_sequence(desc, inp, i2h.weight, i2h.bias, tau4, st.eps0, st.eps1, arp, T, B,
                                                want_spikes=want_spikes, want_pv=want_pv, out=buffers,
-                                               lowhigh_iter0=lowhigh_iter0)
+                                               lowhigh_iter0=lowhigh_iter0, q8=q8, presigmoid=presigmoid)
         return spk, pv, None
 
 
@@ -737,8 +772,8 @@ class DCLLBase(nn.Module):
         backward and Adam as C-ABI calls — else None (then train_dcll builds the autograd graph around the same HIP
         forward / backward).  Served: Conv2dDCLLlayer; crit = SmoothL1Loss (beta 1) or MSELoss with mean reduction;
         optimizer(s) = torch.optim.Adam without amsgrad / maximize / capturable / fused; DCLL_NATIVE_LEARNING != 0."""
-        cached = getattr(self, '_native_kind', 0)
-        if cached != 0:
+        cached = getattr(self, '_native_kind', _UNSET)      # (0 is a loss kind: SmoothL1Loss)
+        if cached is not _UNSET:
             return cached
         kind = None
         crit, opt = getattr(self, 'crit', None), getattr(self, 'optimizer', None)
@@ -885,7 +920,7 @@ class DCLLClassification(DCLLBase):
         if ignore_burnin or self.iter >= self.burnin:
             logits = o if self.dclllayer.output_layer else p
             # kept on the device (no sync per step, unlike the reference's .cpu() at :726-728); converted on demand
-            self._clout.append(logits.argmax(1).detach())
+            self._clout.append(ops.argmax(logits.detach()))          # k_argmax: first maximum wins, like torch.argmax
         return o, p, pv, pvmem
 
     def set_sequence_result(self, clout_dev, n_steps, lowhigh=None, numel=0, vote=None):

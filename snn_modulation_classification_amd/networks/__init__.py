@@ -59,12 +59,17 @@ class ConvNetwork(torch.nn.Module):
                                               optimizer=opt, kwargs_optimizer=layer_opt, collect_stats=True,
                                               burnin=burnin))
         self._seq_buffers = {}
+        self._seq_scratch = {}
         # captured learning timesteps (hipGraph), per input shape; see _learn_graphed
         self.graph_learn = os.environ.get('DCLL_GRAPH_LEARN', '1') != '0'
         self._learn_graphs, self._learn_eager_steps, self._learn_last_key = {}, {}, None
         self._test_graphs, self._test_eager_steps = {}, {}
         # largest pv buffer (one layer, all T steps) the sequence path allocates; bigger batches run in chunks
         self.pv_budget_bytes = float(os.environ.get('DCLL_PV_BUDGET_GB', '24')) * 2 ** 30
+        # sequence path: the layer kernels write v and the readout GEMM applies the sigmoid (dcll_layer_opts
+        # pv_presigmoid + dcll_readout_act) — the transcendentals leave the kernels that share their vector pipe with
+        # the fp32 MFMAs; DCLL_PRESIGMOID=0 keeps pv = sigmoid(v) in the buffer
+        self.presigmoid = os.environ.get('DCLL_PRESIGMOID', '1') != '0'
 
     # -- reference protocol (per step) ----------------------------------------------------------------------------
     def learn(self, x, labels):
@@ -363,7 +368,7 @@ class ConvNetwork(torch.nn.Module):
         layers = [s.dclllayer for s in self.dcll_slices]
         npix = [int(np.prod(L.output_shape)) for L in layers]               # (pooled) pixels of a layer's output map
         chans = [L.out_channels for L in layers]
-        spk_max = max(c * (n // 32) for c, n in zip(chans[:-1], npix[:-1])) if len(layers) > 1 else 1
+        spk_max = max(max(c * (n // 32), 1) for c, n in zip(chans, npix))     # (every layer gets a view, also the last)
         pv_max = max(c * n for c, n in zip(chans, npix))
         H, W = layers[0].im_dims
         cache = self._seq_buffers.get(key)
@@ -397,7 +402,7 @@ class ConvNetwork(torch.nn.Module):
 
     @torch.no_grad()
     def test_sequence(self, cells=None, collect=True, profile=None, fuse_readout=False, iq=None, encoder=None,
-                      T=None, t0=None, output_only=False, overlap_readout=None):
+                      T=None, t0=None, output_only=False, overlap_readout=None, keep_spikes=False):
         """Equivalent of `for t in range(T): net.test(x[t])` for input given as cell indices (T,B) int32 on device
         (one input spike per sample per step, what iq2spiketrain produces), or as the raw IQ batch `iq` (B,2,L) with an
         `IQEncoder` — then the quantisation runs inside the first layer's kernel (T steps from sample t0; t0 drawn
@@ -417,6 +422,9 @@ class ConvNetwork(torch.nn.Module):
         the HBM-bound work behind each of them — pv statistics, readout GEMM (in its LDS-free <= 64-VGPR form), argmax /
         vote — on the caller's stream, so that it executes in the gaps of the NEXT layer's matrix-bound kernel instead
         of after it; one pv buffer per layer instead of one.  Results are identical up to the readout's summation order.
+
+        `keep_spikes`: also return every layer's packed output spike train, 'spikes' (per layer (T,B,C,HW/32) int32,
+        bit pix%32 of word pix/32; copies — the working buffers are reused) — for parity checks against the reference.
 
         Returns a dict with device tensors: 'logits' (per layer, (T,B,target); last entry = output_ layer),
         'clout' (per layer (T,B) int32) and 'vote' (per layer (B) int32)."""
@@ -453,7 +461,7 @@ class ConvNetwork(torch.nn.Module):
                     (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None
                     else cells[:, b0:b1].contiguous(),
                     'iq' if iq is not None else 'cells', T, b1 - b0, dev, profile, fuse_readout, batch_slice=b0,
-                    output_only=output_only, overlap=overlap_readout))
+                    output_only=output_only, overlap=overlap_readout, keep_spikes=keep_spikes))
             cat = lambda key, dim: [None if parts[0][key][i] is None else torch.cat([p[key][i] for p in parts], dim)
                                     for i in range(self.num_layers)]
             res = dict(logits=cat('logits', 1), clout=cat('clout', 1), vote=cat('vote', 0),
@@ -461,10 +469,12 @@ class ConvNetwork(torch.nn.Module):
                                 for i in range(self.num_layers)])
             if 'o' in parts[0]:
                 res['o'] = torch.cat([p['o'] for p in parts], 1)
+            if keep_spikes:
+                res['spikes'] = cat('spikes', 1)
         else:
             res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None else cells,
                                        'iq' if iq is not None else 'cells', T, B, dev, profile, fuse_readout,
-                                       output_only=output_only, overlap=overlap_readout)
+                                       output_only=output_only, overlap=overlap_readout, keep_spikes=keep_spikes)
         if collect:
             for i, s in enumerate(self.dcll_slices):
                 if res['clout'][i] is not None:
@@ -474,7 +484,7 @@ class ConvNetwork(torch.nn.Module):
         return res
 
     def _sequence_chunk(self, first_input, first_kind, T, B, dev, profile, fuse_readout, batch_slice=None,
-                        output_only=False, overlap=False):
+                        output_only=False, overlap=False, keep_spikes=False):
         """All layers over all T steps for B samples (the whole batch, or rows batch_slice.. of every layer's state)."""
         for s in self.dcll_slices:
             i2h = s.dclllayer.i2h
@@ -504,6 +514,8 @@ class ConvNetwork(torch.nn.Module):
 
         cur = first_input
         res = dict(logits=[], clout=[], vote=[], lowhigh=[])
+        if keep_spikes:
+            res['spikes'] = []
         for i, s in enumerate(self.dcll_slices):
             L = s.dclllayer
             last = (i == self.num_layers - 1)
@@ -515,13 +527,18 @@ class ConvNetwork(torch.nn.Module):
             # the slice's iteration count as T calls of forward() would
             stats_iter0 = s.iter if (s.collect_stats and not hidden_skip) else None
             kind = first_kind if i == 0 else 'packed'
+            # pv written before the sigmoid when this layer's readout is the act-capable GEMM (not fused, not co-resident)
+            Wt, bias = L.stacked_readout()
+            pv_view = lbuf['pv'].reshape(T * B, -1)
+            seq_ro = (not overlap and not fused and not hidden_skip and ops.readout_act_supported(pv_view, Wt))
+            presig = self.presigmoid and seq_ro
             if overlap:
                 if i in self._ro_done:
                     hot.wait_event(self._ro_done[i])    # the previous readout of this layer's pv buffer has finished
                 with torch.cuda.stream(hot):
                     spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B, kind,
-                                        want_spikes=not last, buffers=lbuf, fuse_readout=False, batch_slice=batch_slice,
-                                        want_pv=not hidden_skip, lowhigh_iter0=None)
+                                        want_spikes=(not last) or keep_spikes, buffers=lbuf, fuse_readout=False,
+                                        batch_slice=batch_slice, want_pv=not hidden_skip, lowhigh_iter0=None)
                     done = torch.cuda.Event()
                     done.record(hot)
                 main.wait_event(done)
@@ -529,9 +546,13 @@ class ConvNetwork(torch.nn.Module):
                     lbuf['lowhigh'] = ops.pv_lowhigh(pv.reshape(T, -1), T, stats_iter0)
             else:
                 spk, pv, ro = timed('lif_c1' if i == 0 else 'lif_c32', L.forward_sequence, cur, T, B, kind,
-                                    want_spikes=not last, buffers=lbuf, fuse_readout=fused and not hidden_skip,
-                                    batch_slice=batch_slice, want_pv=not hidden_skip, lowhigh_iter0=stats_iter0)
+                                    want_spikes=(not last) or keep_spikes, buffers=lbuf,
+                                    fuse_readout=fused and not hidden_skip,
+                                    batch_slice=batch_slice, want_pv=not hidden_skip, lowhigh_iter0=stats_iter0,
+                                    presigmoid=presig)
             res['lowhigh'].append(lbuf.get('lowhigh'))
+            if keep_spikes:
+                res['spikes'].append(spk.clone())
             if hidden_skip:
                 res['logits'].append(None)
                 res['clout'].append(None)
@@ -548,9 +569,12 @@ class ConvNetwork(torch.nn.Module):
             else:
                 # readout GEMM over all (t, b) rows; on the output layer i2o and output_ share ONE pass over pv
                 pv2d = pv.reshape(T * B, -1)
-                Wt, bias = L.stacked_readout()
-                ro = timed('readout', ops.readout, pv2d, Wt, bias, out=buf['ro'][i].reshape(T * B, -1),
-                           mode=ops.READOUT_CORESIDENT if overlap else ops.READOUT_AUTO)
+                if seq_ro:      # kernel form chosen by K alone: a row's logits do not depend on the chunking
+                    ro = timed('readout', ops.readout_act, pv2d, Wt, bias, out=buf['ro'][i].reshape(T * B, -1),
+                               presigmoid=presig, scratch=self._seq_scratch)
+                else:
+                    ro = timed('readout', ops.readout, pv2d, Wt, bias, out=buf['ro'][i].reshape(T * B, -1),
+                               mode=ops.READOUT_CORESIDENT if overlap else ops.READOUT_AUTO)
                 if overlap:
                     self._ro_done[i] = torch.cuda.Event()
                     self._ro_done[i].record(main)

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, DenseDesc, check, ptr, stream_ptr
+from ._lib import ACT_NONE, ACT_SIGMOID, ConvDesc, DenseDesc, LayerOpts, check, ptr, stream_ptr
 
 
 def _pair(v):
@@ -50,6 +50,22 @@ def _expect(t, name, dtype, shape=None, numel=None):
         raise ValueError("%s must have %d elements, got %d" % (name, numel, t.numel()))
 
 
+def layer_opts(desc, q8=None, presigmoid=False):
+    """dcll_layer_opts of a call as a ctypes reference (None = defaults).  q8 = (q int8 (c_out,c_in,kh,kw), scale fp32
+    (c_out)): the kernels read the conv weight as int8 and convert it once, (float)q * scale[co] (include/dcll_hip.h);
+    presigmoid: the sequence call writes v instead of sigmoid(v) into pv_out.  The caller keeps the tensors alive."""
+    if q8 is None and not presigmoid:
+        return None
+    o = LayerOpts()
+    if q8 is not None:
+        q, scale = q8
+        _expect(q, "w_q8", torch.int8, (desc.c_out, desc.c_in, desc.kh, desc.kw))
+        _expect(scale, "w_scale", torch.float32, (desc.c_out,))
+        o.w_q8, o.w_scale = ptr(q).value, ptr(scale).value
+    o.pv_presigmoid = int(bool(presigmoid))
+    return ctypes.byref(o)
+
+
 def _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=None, tau4=None):
     ch, cw, _, _ = conv_out_shape(desc)
     _expect(W, "W", torch.float32, (desc.c_out, desc.c_in, desc.kh, desc.kw))
@@ -68,12 +84,13 @@ def _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=None, tau4=None):
 
 
 def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None,
-                  out_W=None, out_b=None, want_v=True, out=None):
+                  out_W=None, out_b=None, want_v=True, out=None, q8=None):
     """One Conv2dDCLLlayer.forward step (dcll/pytorch_libdcll.py:599-608); state tensors are updated in place.
 
     Returns (s_pooled, p, o, pv_pooled, v) — p / o are None when the corresponding weights are None.
     `out`: optional dict of preallocated outputs ('s', 'pv', 'v', 'p', 'o', 'scratch'; filled in when absent) — the
     learning loop reuses one set per layer instead of allocating five tensors per step.
+    `q8`: (int8 weights, per-output-channel scale) — the kernels then read the conv weight as int8 (W may be None).
     """
     out = {} if out is None else out
     B = x.shape[0]
@@ -82,6 +99,7 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     x = _f32(x, "x").contiguous()
     _expect(x, "x", torch.float32, (B, desc.c_in, desc.h, desc.w))
     _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=(alpha, tau_m, alphas, tau_s))
+    opts = layer_opts(desc, q8)
     K_ro = desc.c_out * ph * pw
     if i2o_W is not None:
         _expect(i2o_W, "i2o_W", torch.float32, (desc.target, K_ro))
@@ -114,7 +132,7 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
         rc = _lib.get().dcll_conv_lif_step(
             ctypes.byref(d2), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
             ptr(eps0), ptr(eps1), ptr(arp), None, None, None, None,
-            ptr(s), None, None, ptr(pv), ptr(v), ptr(scratch), B, stream_ptr())
+            ptr(s), None, None, ptr(pv), ptr(v), ptr(scratch), opts, B, stream_ptr())
         check(rc, "dcll_conv_lif_step")
         readout(pv.reshape(B, -1), i2o_W, i2o_b, out=p, scratch=out)
         if desc.output_layer:
@@ -123,7 +141,7 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     rc = _lib.get().dcll_conv_lif_step(
         ctypes.byref(desc), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
         ptr(eps0), ptr(eps1), ptr(arp), ptr(i2o_W), ptr(i2o_b), ptr(out_W), ptr(out_b),
-        ptr(s), ptr(p), ptr(o), ptr(pv), ptr(v), ptr(scratch), B, stream_ptr())
+        ptr(s), ptr(p), ptr(o), ptr(pv), ptr(v), ptr(scratch), opts, B, stream_ptr())
     check(rc, "dcll_conv_lif_step")
     return s, p, o, pv, v
 
@@ -220,23 +238,24 @@ def pv_lowhigh_steps(iter0, T):
     return int(_lib.get().dcll_pv_lowhigh_steps(int(iter0), int(T)))
 
 
-def pv_lowhigh(pv, T, iter0):
+def pv_lowhigh(pv, T, iter0, presigmoid=False):
     """pv (T, ...) fp32 -> int64 (n, 2): per histogram step the counts of pv in the first / last of the reference's 19
-    bins over [0, 1] (dcll_pv_lowhigh)."""
+    bins over [0, 1] (dcll_pv_lowhigh).  presigmoid: the buffer holds v, sigmoid(v) is what is counted."""
     _expect(pv, "pv", torch.float32)
     pv = pv.contiguous()
     counts = torch.zeros((pv_lowhigh_steps(iter0, T), 2), device=pv.device, dtype=torch.int64)
-    check(_lib.get().dcll_pv_lowhigh(ptr(pv), pv.numel() // max(T, 1), T, int(iter0), ptr(counts), stream_ptr()),
-          "dcll_pv_lowhigh")
+    check(_lib.get().dcll_pv_lowhigh_act(ptr(pv), pv.numel() // max(T, 1), T, int(iter0), ptr(counts),
+                                         ACT_SIGMOID if presigmoid else ACT_NONE, stream_ptr()), "dcll_pv_lowhigh")
     return counts
 
 
 def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_pv=True,
-                      want_v=False, out=None, ro_Wp=None, ro_b=None, lowhigh_iter0=None):
+                      want_v=False, out=None, ro_Wp=None, ro_b=None, lowhigh_iter0=None, q8=None, presigmoid=False):
     """All T steps of one 32->32 layer in one launch (k_lif_seq_c32). spk_in: (T,B,32,8) int32 packed.
     With ro_Wp / ro_b the local readout(s) are fused: returns (spk, pv, v, logits (T,B,n_ro)).
-    With lowhigh_iter0 the pv statistics of the histogram steps are returned in out['lowhigh'] ((n,2) int64)."""
-    dev = W.device
+    With lowhigh_iter0 the pv statistics of the histogram steps are returned in out['lowhigh'] ((n,2) int64).
+    q8 / presigmoid: dcll_layer_opts (int8 weights; pv holds v, the readout applies the sigmoid: readout_act)."""
+    dev = b.device
     out = {} if out is None else out
     words = desc.h * desc.w // 32
     ch, cw, ph, pw = conv_out_shape(desc)          # pooling layers (the (1,3) / pool (1,2) geometry) emit POOLED maps
@@ -263,7 +282,8 @@ def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spik
     scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
     rc = _lib.get().dcll_conv_lif_sequence(ctypes.byref(desc), ptr(spk_in), ptr(W), ptr(b), ptr(tau4), ptr(eps0),
                                            ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v), ptr(ro_Wp), ptr(ro_b),
-                                           ptr(logits), n_ro, ptr(scratch), ptr(counts), iter0, T, B, stream_ptr())
+                                           ptr(logits), n_ro, ptr(scratch), ptr(counts), iter0,
+                                           layer_opts(desc, q8, presigmoid), T, B, stream_ptr())
     check(rc, "dcll_conv_lif_sequence")
     if counts is not None:
         out["lowhigh"] = counts
@@ -273,9 +293,9 @@ def conv_lif_sequence(desc, spk_in, W, b, tau4, eps0, eps1, arp, T, B, want_spik
 
 
 def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_pv=True,
-                            want_v=False, out=None, lowhigh_iter0=None):
+                            want_v=False, out=None, lowhigh_iter0=None, q8=None, presigmoid=False):
     """All T steps of the first layer (c_in = 1) from cell indices (T,B) int32 (k_lif_seq_c1)."""
-    dev = W.device
+    dev = b.device
     out = {} if out is None else out
     ch, cw, ph, pw = conv_out_shape(desc)          # pooling layers emit POOLED maps
     owords = ph * pw // 32
@@ -293,7 +313,8 @@ def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want
     scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
     rc = _lib.get().dcll_conv_lif_sequence_cells(ctypes.byref(desc), ptr(cells), ptr(W), ptr(b), ptr(tau4),
                                                  ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v),
-                                                 ptr(scratch), ptr(counts), iter0, T, B, stream_ptr())
+                                                 ptr(scratch), ptr(counts), iter0, layer_opts(desc, q8, presigmoid),
+                                                 T, B, stream_ptr())
     check(rc, "dcll_conv_lif_sequence_cells")
     if counts is not None:
         out["lowhigh"] = counts
@@ -301,9 +322,9 @@ def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want
 
 
 def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True,
-                         want_pv=True, want_v=False, out=None, lowhigh_iter0=None):
+                         want_pv=True, want_v=False, out=None, lowhigh_iter0=None, q8=None, presigmoid=False):
     """First layer from the raw IQ window (B,2,L): iq2spiketrain's quantisation fused into k_lif_seq_c1."""
-    dev = W.device
+    dev = b.device
     out = {} if out is None else out
     iq = iq.reshape(B, 2, -1).contiguous()
     L = iq.shape[-1]
@@ -322,7 +343,8 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
     scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
     rc = _lib.get().dcll_conv_lif_sequence_iq(ctypes.byref(desc), ptr(iq), ptr(thr_i), ptr(thr_q), L, t0, ptr(W), ptr(b),
                                               ptr(tau4), ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v),
-                                              ptr(scratch), ptr(counts), iter0, T, B, stream_ptr())
+                                              ptr(scratch), ptr(counts), iter0, layer_opts(desc, q8, presigmoid), T, B,
+                                              stream_ptr())
     check(rc, "dcll_conv_lif_sequence_iq")
     if counts is not None:
         out["lowhigh"] = counts
@@ -366,6 +388,42 @@ def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO, scratch=None):
     return out
 
 
+def readout_act_supported(pv2d, Wt):
+    """True if dcll_readout_act serves this shape (the LDS-staged 16x16x4 kernel: K % 32 == 0 — K % 256 == 0 when it is
+    split over K —, N <= 64, 16-byte aligned operands)."""
+    K, N = pv2d.shape[1], Wt.shape[0]
+    return (K % 32 == 0 and (K < 65536 or K % 256 == 0) and N <= 64 and pv2d.data_ptr() % 16 == 0 and
+            Wt.data_ptr() % 16 == 0 and pv2d.is_contiguous() and Wt.is_contiguous())
+
+
+def readout_act(pv2d, Wt, bias, out=None, presigmoid=False, scratch=None):
+    """The readout of the whole-sequence path (dcll_readout_act): out[r,n] = sum_k act(pv2d[r,k]) Wt[n,k] + bias[n] with
+    act = sigmoid when `presigmoid` (the layer kernel wrote v).  The kernel form depends on K only — a row's logits do
+    not depend on the row count, i.e. on how a batch is chunked.  `scratch`: dict keeping the split-K area ('act_splitk')."""
+    rows, K = pv2d.shape
+    N = Wt.shape[0]
+    if Wt.shape[1] != K:
+        raise ValueError("readout: K mismatch %d vs %d" % (Wt.shape[1], K))
+    _expect(pv2d, "pv", torch.float32)
+    _expect(Wt, "Wt", torch.float32)
+    _expect(bias, "bias", torch.float32, (N,))
+    if out is None:
+        out = torch.empty((rows, N), device=pv2d.device, dtype=torch.float32)
+    _expect(out, "out", torch.float32, (rows, N))
+    lib = _lib.get()
+    need = lib.dcll_readout_act_scratch(rows, K, N)
+    area = None
+    if need > 0:
+        area = None if scratch is None else scratch.get('act_splitk')
+        if area is None or area.numel() < need:
+            area = torch.empty((need,), device=pv2d.device, dtype=torch.float32)
+            if scratch is not None:
+                scratch['act_splitk'] = area
+    check(lib.dcll_readout_act(ptr(pv2d), ptr(Wt), ptr(bias), ptr(out), ptr(area), need, rows, K, N,
+                               ACT_SIGMOID if presigmoid else ACT_NONE, stream_ptr()), "dcll_readout_act")
+    return out
+
+
 def argmax_vote(logits, t_begin=0, want_vote=True):
     """logits (T,B,N) -> clout (T,B) int32, vote (B) int32."""
     T, B, N = logits.shape
@@ -375,6 +433,17 @@ def argmax_vote(logits, t_begin=0, want_vote=True):
     check(_lib.get().dcll_argmax_vote(ptr(logits), ptr(clout), ptr(vote), T, B, N, t_begin, stream_ptr()),
           "dcll_argmax_vote")
     return clout, vote
+
+
+def argmax(logits):
+    """logits (rows, N) fp32 -> (rows,) int32, first maximum wins like torch.argmax (k_argmax; DCLLClassification.forward
+    :724-728 per step)."""
+    rows, N = logits.shape
+    _expect(logits, "logits", torch.float32)
+    logits = logits.contiguous()
+    out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
+    check(_lib.get().dcll_argmax_vote(ptr(logits), ptr(out), None, 1, rows, N, 0, stream_ptr()), "dcll_argmax_vote")
+    return out
 
 
 def iq_encode(iq, thr_i, thr_q, t0, T, w, h):

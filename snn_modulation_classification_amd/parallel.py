@@ -7,6 +7,11 @@ a contiguous shard of the batch with replicated weights and NO data-path collect
 RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests and in rehearsals where several ranks share one GPU
 (DCLL_DIST_BACKEND=gloo: device tensors are staged through the host, RCCL refuses two ranks on one device).
 
+DCLL_FORCE_DIST=1 makes a ONE-rank job (WORLD_SIZE=1) form its process group and route every exchange through the
+backend anyway: on a 1-GPU box that executes the whole RCCL code path — communicator creation with `device_id`, the int64
+tally all-reduce, the fp32 gradient bucket, the fp64 MAX of the timings, barrier, destroy — on device tensors, with
+results that must equal the plain single-process run bit for bit (tests/test_gpu_multirank.py).
+
 `spawn_local_ranks` is the launcher of the entry points (`bench.py --gpus N`, `test_radio_ml.py --gpus N`,
 `train.py --gpus N`) when they are started plainly instead of under torchrun: the parent never touches the GPU.
 """
@@ -38,10 +43,15 @@ def local_device(local_rank):
     return local_rank % n if n > 0 else 0
 
 
+def forced():
+    """DCLL_FORCE_DIST=1: a one-rank job still forms its group and reduces through the backend (module docstring)."""
+    return os.environ.get("DCLL_FORCE_DIST", "0") == "1"
+
+
 def init_process_group(backend=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  nccl == RCCL under ROCm."""
     rank, local_rank, world = env_ranks()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         if backend is None:
             # DCLL_DIST_BACKEND=gloo lets the multi-rank path be rehearsed where RCCL cannot run (CPU container, or
             # several ranks sharing one GPU on a 1-GPU box)
@@ -70,7 +80,7 @@ def init_process_group(backend=None):
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
 
 
 def all_reduce_(t, op=None):
@@ -132,7 +142,8 @@ def allreduce_mean_tensors(tensors, local_n=None):
     tensors = [t for t in tensors if t is not None]
     if not is_distributed() or not tensors:
         return
-    w = float(local_n) if local_n is not None else 1.0
+    # (one rank: its shard IS the global batch, weight 1 — the bucket still travels through the backend)
+    w = float(local_n) if (local_n is not None and dist.get_world_size() > 1) else 1.0
     flat = torch.cat([t.reshape(-1) for t in tensors] + [torch.ones(1, device=tensors[0].device, dtype=tensors[0].dtype)])
     flat *= w
     all_reduce_(flat)
@@ -171,7 +182,9 @@ def spawn_local_ranks(n, argv=None, timeout=None):
     env = dict(os.environ)
     env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    n_dev = torch.cuda.device_count()           # does not initialise the GPU
+    # (counting devices: torch asks amdsmi / the HIP runtime's device query — no context, no stream, no allocation is
+    #  created in this process; the ranks are fresh processes either way, never forks of an initialised parent)
+    n_dev = torch.cuda.device_count()
     if n_dev < n and "DCLL_DIST_BACKEND" not in env:
         env["DCLL_DIST_BACKEND"] = "gloo"
         print("[launcher] %d ranks on %d GPU(s): rehearsal, ranks share devices, backend gloo" % (n, n_dev),

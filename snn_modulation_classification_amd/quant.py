@@ -4,9 +4,11 @@ The reference has no quantisation code (its README only says "(quantized)"), so 
 against: PARITY UNPINNED.  Definition used here:
 
 * weights: per-output-channel symmetric int8, scale[co] = max|W[co]| / 127, q = round-half-even(W / scale) in
-  [-127, 127]; the kernels run on the DEQUANTISED fp32 weights q * scale (exactly representable products of an
-  integer and one fp32 scale are what an int8 MAC followed by one fp32 multiply per channel yields up to the
-  accumulation order, which the pinned fmaf chain fixes);
+  [-127, 127]; the kernels READ THE INT8 TENSOR through the C ABI (`dcll_layer_opts.w_q8 / w_scale`, ABI v3) and
+  convert every weight exactly once, w = (float)q * scale[co] — one rounded fp32 multiply, the same value
+  `dequantize` produces — before the pinned fmaf chain runs on it: bit-identical to the run on the dequantised fp32
+  tensor (tested), a quarter of the weight bytes.  `i2h.weight` keeps the dequantised values (state-dict, per-step
+  autograd path);
 * spikes: between layers as 1-bit packed words (`ops.pack_spikes` / the sequence kernels' native format) — lossless.
 
 The parity statement that can be made and is tested: the HIP path on the dequantised weights equals the C oracle on the
@@ -29,13 +31,15 @@ def dequantize(q, scale):
 
 
 def apply_int8_weights(net):
-    """Quantise every slice's conv weight in place (i2h.weight <- dequantised int8); returns [(q, scale)] per slice so
-    that a caller can store the 8-bit form (1/4 of the bytes)."""
+    """Quantise every slice's conv weight: i2h.weight <- the dequantised values, and the int8 tensor + scales are kept on
+    the layer (`i2h.set_int8_weights`) — from here on every kernel call of the layer hands THOSE across the C ABI.
+    Returns [(q, scale)] per slice."""
     out = []
     with torch.no_grad():
         for s in net.dcll_slices:
-            w = s.dclllayer.i2h.weight
-            q, scale = quantize_int8_per_channel(w)
-            w.copy_(dequantize(q, scale))
+            i2h = s.dclllayer.i2h
+            q, scale = quantize_int8_per_channel(i2h.weight)
+            i2h.weight.copy_(dequantize(q, scale))
+            i2h.set_int8_weights(q, scale)
             out.append((q, scale))
     return out

@@ -93,8 +93,9 @@ def main():
     out["ow"] = lnet.dcll_slices[-1].dclllayer.output_.weight.detach().cpu().numpy()
     out["ob"] = lnet.dcll_slices[-1].dclllayer.output_.bias.detach().cpu().numpy()
     torch.cuda.synchronize()
+    out["backend"] = np.array(torch.distributed.get_backend() if parallel.is_distributed() else "none")
     np.savez(os.path.join(out_dir, "rank_%d_of_%d.npz" % (rank, world)), **out)
-    if world > 1:
+    if parallel.is_distributed():
         parallel.barrier()
         torch.distributed.destroy_process_group()
 

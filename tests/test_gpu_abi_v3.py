@@ -1,0 +1,382 @@
+"""ABI v3 (`dcll_layer_opts`, include/dcll_hip.h): int8 conv weights handed across the C ABI, and pv written before the
+sigmoid with the sigmoid applied by the readout GEMM.
+
+BASELINE config 5 ("int8 weights + 1-bit packed spikes") has no reference code (parity unpinned); what can
+be pinned, and is here: a call that reads the int8 tensor + per-channel scales is bit-identical — membrane v, spikes,
+final state — to the same call on the dequantised fp32 tensor, for EVERY kernel family behind the layer calls, and both
+equal the C oracle on the dequantised weights.  pv_presigmoid changes where a (not bit-pinned) sigmoid runs, nothing
+else: v in the buffer is the bit-exact v, the logits stay inside the 1e-4 contract, the pv statistics are unchanged."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_kernels import LOGIT_TOL, PV_TOL, _rand_layer, _sd_from, bits_equal, cu, dev  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _quant(W):
+    """per-output-channel symmetric int8, as quant.py defines it -> (q int8, scale fp32, dequantised fp32)"""
+    from snn_modulation_classification_amd import quant
+    q, scale = quant.quantize_int8_per_channel(torch.from_numpy(W))
+    return q.numpy(), scale.numpy(), quant.dequantize(q, scale).numpy()
+
+
+def _state(orc, rng, zero):
+    if not zero:
+        orc.state[0][...] = rng.uniform(0, 5, size=orc.state[0].shape)
+        orc.state[1][...] = rng.uniform(0, 50, size=orc.state[1].shape)
+        if len(orc.state) > 2 and orc.state[2] is not None:
+            orc.state[2][...] = -rng.uniform(0, 2, size=orc.state[2].shape)
+
+
+# (name, c_in, c_out, plane, kernel, padding, pooling, T, B): one case per kernel family behind the sequence calls
+SEQ_CASES = [
+    ("c32d", 32, 32, (16, 16), 7, 3, 1, 11, 3),          # k_lif_seq_c32d (T >= 8)
+    ("c32", 32, 32, (16, 16), 7, 3, 1, 5, 2),            # k_lif_seq_c32 (short sequence)
+    ("c32t", 32, 32, (16, 64), 7, 3, 1, 6, 2),           # k_lif_seq_c32t (tiled planes)
+    ("c1", 1, 32, (16, 16), 7, 3, 1, 9, 3),              # k_lif_seq_c1
+    ("c1_narrow", 1, 8, (16, 16), 7, 3, 1, 6, 2),        # k_lif_seq_c1, generic (guarded) epilogue
+    ("c1t", 1, 32, (32, 32), 7, 3, 1, 5, 2),             # k_lif_seq_c1t
+    ("w3_wide", 64, 64, (16, 64), (1, 3), (0, 1), (1, 2), 6, 2),     # k_lif_seq_w3<64, WIDE>
+    ("w3_narrow", 64, 64, (16, 4), (1, 3), (0, 1), (1, 2), 5, 3),    # k_lif_seq_w3<64, !WIDE>
+    ("w3_first", 1, 64, (16, 128), (1, 3), (0, 1), (1, 2), 7, 2),    # k_lif_seq_w3<1>
+]
+
+
+@pytest.mark.parametrize("wrp", [1.0, 0.0])
+@pytest.mark.parametrize("case", SEQ_CASES, ids=[c[0] for c in SEQ_CASES])
+def test_int8_abi_sequence_kernels_equal_dequantised_fp32_and_oracle(dev, case, wrp):
+    """Every sequence kernel with int8 weights + scales through dcll_layer_opts == the same call on the dequantised fp32
+    tensor == the C oracle on the dequantised weights: v, packed spikes and the final state, bit for bit."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    name, cin, cout, hw, ks, pad, pool, T, B = case
+    rng = np.random.RandomState(5 + len(name))
+    H, Wd = hw
+    kh, kw = (ks, ks) if isinstance(ks, int) else ks
+    n = cin * kh * kw
+    stdv = 1.0 / np.sqrt(n) / 250
+    W = (rng.uniform(-stdv * 1e-2, stdv * 1e-2, size=(cout, cin, kh, kw)) * 3.0).astype(np.float32)
+    b = rng.uniform(-stdv, stdv, size=(cout,)).astype(np.float32)
+    _, _, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout)
+    q, scale, Wd_ = _quant(W)
+    assert np.abs(Wd_ - W).max() <= scale.max() * 0.5 * 1.0001 and not np.array_equal(Wd_, W)
+    ph, pw = (H, Wd) if pool == 1 else (H, Wd // 2)
+    sd = _sd_from(Wd_, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    sd["i2o.weight"] = rng.uniform(-.005, .005, size=(24, cout * ph * pw)).astype(np.float32)
+    orc = C.OracleConvLayer(sd, hw, pad, pool, wrp)
+    orc.init_state(B)
+    _state(orc, rng, zero=False)
+    init = [None if s_ is None else s_.copy() for s_ in orc.state]
+    d = ops.make_conv_desc(cin, cout, hw, ks, pad, pool, 24, False, True, wrp)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    if cin == 1:
+        cells = rng.randint(0, H * Wd, size=(T, B)).astype(np.int32)
+        x = np.zeros((T, B, 1, H * Wd), np.float32)
+        x[np.arange(T)[:, None], np.arange(B)[None, :], 0, cells] = 1
+    else:
+        x = (rng.uniform(size=(T, B, cin, H * Wd)) < 0.1).astype(np.float32)
+        x[0] = rng.uniform(size=(B, cin, H * Wd)) < 0.5
+    want_spk = pool == 1 or (H * Wd) % 64 == 0
+
+    def run(Wt, q8):
+        st = [None if s_ is None else cu(s_.copy(), dev) for s_ in init]
+        arp = st[2] if wrp > 0 else None
+        if cin == 1:
+            spk, pv, v = ops.conv_lif_sequence_cells(d, cu(cells, dev), Wt, cu(b, dev), tau4, st[0], st[1], arp, T, B,
+                                                     want_spikes=want_spk, want_v=True, q8=q8)
+        else:
+            spk, pv, v = ops.conv_lif_sequence(d, ops.pack_spikes(cu(x, dev)), Wt, cu(b, dev), tau4, st[0], st[1], arp,
+                                               T, B, want_spikes=want_spk, want_v=True, q8=q8)
+        torch.cuda.synchronize()
+        return (None if spk is None else spk.cpu().numpy(), pv.cpu().numpy(), v.cpu().numpy(),
+                [None if s_ is None else s_.cpu().numpy() for s_ in st])
+
+    f_spk, f_pv, f_v, f_st = run(cu(Wd_, dev), None)                             # fp32 call on the dequantised tensor
+    q_spk, q_pv, q_v, q_st = run(None, (cu(q, dev), cu(scale, dev)))             # int8 tensor across the ABI, W = NULL
+    assert bits_equal(q_v, f_v), np.argwhere(q_v != f_v)[:5]
+    assert bits_equal(q_pv, f_pv)
+    if want_spk:
+        assert np.array_equal(q_spk, f_spk)
+    for a, c in zip(q_st, f_st):
+        if a is not None:
+            assert bits_equal(a, c)
+    nspk = 0
+    for t in range(T):
+        _, _, opv, ov, os_ = orc.forward(x[t].reshape(B, cin, H, Wd))
+        assert bits_equal(q_v[t], ov), (t, np.abs(q_v[t] - ov).max())
+        np.testing.assert_allclose(q_pv[t], opv, atol=PV_TOL, rtol=0)
+        nspk += os_.sum()
+    for a, c in zip(q_st, orc.state):
+        if a is not None and c is not None:
+            assert bits_equal(a, c)
+    assert 0.002 < nspk / (T * B * cout * ph * pw) < 0.95, "degenerate test"
+    # the fp32 ORIGINAL weights give a different membrane: the comparison above is not vacuous
+    o_v = run(cu(W, dev), None)[2]
+    assert not bits_equal(o_v, q_v)
+
+
+# (name, c_in, c_out, plane, kernel, padding, pooling, B): one case per kernel family behind dcll_conv_lif_step
+STEP_CASES = [
+    ("step_c32", 32, 32, (16, 16), 7, 3, 1, 300),        # k_lif_step_c32 (B > 256: one workgroup per sample)
+    ("step_c32_split", 32, 32, (16, 16), 7, 3, 1, 5),    # k_trace4 + k_lif_step_c32t<8>
+    ("step_c32t", 32, 32, (32, 48), 7, 3, 1, 2),         # k_lif_step_c32t<16>
+    ("step_c1", 1, 32, (16, 16), 7, 3, 1, 4),            # k_lif_step_c1
+    ("step_c1t", 1, 16, (32, 32), 7, 3, 1, 2),           # k_lif_step_c1 (tiled)
+    ("step_tiled_1x3", 64, 64, (16, 32), (1, 3), (0, 1), (1, 2), 2),     # k_conv_lif_tiled<1,3> + k_pool
+    ("step_tiled_5x5", 3, 12, (28, 28), 5, 2, 2, 2),     # k_conv_lif_tiled<5,5> (mnist geometry)
+    ("step_generic", 3, 5, (9, 11), (2, 4), (1, 2), 1, 2),               # k_conv_lif (any geometry)
+]
+
+
+@pytest.mark.parametrize("wrp", [1.0, 0.0])
+@pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_int8_abi_step_kernels_equal_dequantised_fp32_and_oracle(dev, case, wrp):
+    """dcll_conv_lif_step with int8 weights through dcll_layer_opts, three free-running steps from a non-zero state ==
+    the fp32 call on the dequantised tensor == the C oracle: s, v and the state bit for bit."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    name, cin, cout, hw, ks, pad, pool, B = case
+    rng = np.random.RandomState(17 + len(name))
+    H, Wd = hw
+    kh, kw = (ks, ks) if isinstance(ks, int) else ks
+    n = cin * kh * kw
+    stdv = 1.0 / np.sqrt(n) / 250
+    W = (rng.uniform(-stdv * 1e-2, stdv * 1e-2, size=(cout, cin, kh, kw)) * 3.0).astype(np.float32)
+    b = rng.uniform(-stdv, stdv, size=(cout,)).astype(np.float32)
+    _, _, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout)
+    q, scale, Wd_ = _quant(W)
+    d = ops.make_conv_desc(cin, cout, hw, ks, pad, pool, 24, False, True, wrp)
+    ch, cw, ph, pw = ops.conv_out_shape(d)
+    sd = _sd_from(Wd_, b, alpha, tau_m, alphas, tau_s, hw, rng=rng)
+    sd["i2o.weight"] = rng.uniform(-.005, .005, size=(24, cout * ph * pw)).astype(np.float32)
+    orc = C.OracleConvLayer(sd, hw, pad, pool, wrp)
+    orc.init_state(B)
+    _state(orc, rng, zero=False)
+    init = [None if s_ is None else s_.copy() for s_ in orc.state]
+    taus = [cu(sd[k], dev) for k in ("i2h.alpha", "i2h.tau_m__dt", "i2h.alphas", "i2h.tau_s__dt")]
+    xs = [(rng.uniform(size=(B, cin, H, Wd)) < 0.15).astype(np.float32) for _ in range(3)]
+    i2o_W, i2o_b = cu(sd["i2o.weight"], dev), cu(sd["i2o.bias"], dev)
+
+    def run(Wt, q8):
+        st = [None if s_ is None else cu(s_.copy(), dev) for s_ in init]
+        outs = []
+        for x in xs:
+            s, p, o, pv, v = ops.conv_lif_step(d, cu(x, dev), Wt, cu(b, dev), *taus, st[0], st[1],
+                                               st[2] if wrp > 0 else None, i2o_W, i2o_b, q8=q8)
+            outs.append([t.cpu().numpy() for t in (s, p, pv, v)])
+        return outs, [None if s_ is None else s_.cpu().numpy() for s_ in st]
+
+    f_out, f_st = run(cu(Wd_, dev), None)
+    q_out, q_st = run(None, (cu(q, dev), cu(scale, dev)))
+    for k, x in enumerate(xs):
+        for a, c in zip(q_out[k], f_out[k]):
+            assert bits_equal(a, c), (k, np.abs(a - c).max())
+        oo, op, opv, ov, os_ = orc.forward(x)
+        assert bits_equal(q_out[k][3], ov), (k, np.abs(q_out[k][3] - ov).max())
+        assert np.array_equal(q_out[k][0], os_)
+        np.testing.assert_allclose(q_out[k][1], op, atol=LOGIT_TOL, rtol=0)
+    for a, c, o_ in zip(q_st, f_st, orc.state):
+        if a is not None:
+            assert bits_equal(a, c) and bits_equal(a, o_)
+
+
+def test_layer_opts_validation(dev):
+    """dcll_layer_opts is checked before any launch: int8 weights without scales, a reserved field that is not 0,
+    pv_presigmoid on the per-step drop-in (which returns pv by contract), and neither weight form."""
+    import ctypes
+    from snn_modulation_classification_amd import _lib, ops
+    lib = _lib.get()
+    d = ops.make_conv_desc(32, 32, (16, 16), 7, 3, 1, 24, False, True, 1.0)
+    B, T = 2, 8
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+    spk_in, W, b, tau4 = z(T, B, 32, 8, dt=torch.int32), z(32, 32, 7, 7), z(32), z(4, 32)
+    e0, e1, arp, pv = z(B, 32, 16, 16), z(B, 32, 16, 16), z(B, 32, 16, 16), z(T, B, 32, 16, 16)
+    q = z(32, 32, 7, 7, dt=torch.int8)
+
+    def seq(opts, Wt=W):
+        return lib.dcll_conv_lif_sequence(ctypes.byref(d), _lib.ptr(spk_in), _lib.ptr(Wt), _lib.ptr(b), _lib.ptr(tau4),
+                                          _lib.ptr(e0), _lib.ptr(e1), _lib.ptr(arp), None, _lib.ptr(pv), None, None, None,
+                                          None, 0, None, None, 0, opts, T, B, None)
+    o = _lib.LayerOpts()
+    assert seq(ctypes.byref(o)) == _lib.DCLL_OK
+    o.w_q8 = q.data_ptr()
+    assert seq(ctypes.byref(o)) == _lib.DCLL_ERR_INVALID and b"w_scale" in lib.dcll_last_error()
+    o = _lib.LayerOpts()
+    o.reserved = 1
+    assert seq(ctypes.byref(o)) == _lib.DCLL_ERR_INVALID and b"reserved" in lib.dcll_last_error()
+    assert seq(None, Wt=None) == _lib.DCLL_ERR_INVALID
+    o = _lib.LayerOpts()
+    o.pv_presigmoid = 1
+    x, s = z(B, 32, 16, 16), z(B, 32, 16, 16)
+    one = z(1)
+    rc = lib.dcll_conv_lif_step(ctypes.byref(d), _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(one), _lib.ptr(one),
+                                _lib.ptr(one), _lib.ptr(one), _lib.ptr(e0), _lib.ptr(e1), _lib.ptr(arp), None, None, None,
+                                None, _lib.ptr(s), None, None, _lib.ptr(pv[0]), None, None, ctypes.byref(o), B, None)
+    assert rc == _lib.DCLL_ERR_INVALID and b"pv_presigmoid" in lib.dcll_last_error()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [c for c in SEQ_CASES if c[0] in ("c32d", "c32", "c32t", "c1", "c1_narrow", "c1t",
+                                                                      "w3_wide", "w3_narrow", "w3_first")],
+                         ids=lambda c: c[0])
+def test_presigmoid_buffer_holds_v_and_statistics_are_unchanged(dev, case):
+    """pv_presigmoid: pv_out receives the bit-exact v (max-pooled where the layer pools) and the pv statistics counted on
+    it (sigmoid applied inside the counting pass) equal those of the pv = sigmoid(v) run; spikes, state and v_out do not
+    change.  T covers two histogram steps (iterations 20 and 40)."""
+    from snn_modulation_classification_amd import ops
+    name, cin, cout, hw, ks, pad, pool, _, B = case
+    T = 41
+    rng = np.random.RandomState(29 + len(name))
+    H, Wd = hw
+    kh, kw = (ks, ks) if isinstance(ks, int) else ks
+    stdv = 1.0 / np.sqrt(cin * kh * kw) / 250
+    W = (rng.uniform(-stdv * 1e-2, stdv * 1e-2, size=(cout, cin, kh, kw)) * 3.0).astype(np.float32)
+    # biases large enough that pv leaves the middle bins on some neurons: the first / last bins are populated
+    b = (rng.uniform(-1, 1, size=(cout,)) * 4.0).astype(np.float32)
+    _, _, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout)
+    d = ops.make_conv_desc(cin, cout, hw, ks, pad, pool, 24, False, True, 1.0)
+    ch, cw, ph, pw = ops.conv_out_shape(d)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    if cin == 1:
+        inp = cu(rng.randint(0, H * Wd, size=(T, B)).astype(np.int32), dev)
+    else:
+        inp = ops.pack_spikes(cu((rng.uniform(size=(T, B, cin, H * Wd)) < 0.1).astype(np.float32), dev))
+    want_spk = pool == 1 or (H * Wd) % 64 == 0
+    fn = ops.conv_lif_sequence_cells if cin == 1 else ops.conv_lif_sequence
+
+    def run(presig, want_v):
+        st = [torch.zeros((B, cin, H, Wd), device=dev) for _ in range(2)] + [torch.zeros((B, cout, ch, cw), device=dev)]
+        out = {}
+        spk, pv, v = fn(d, inp, cu(W, dev), cu(b, dev), tau4, st[0], st[1], st[2], T, B, want_spikes=want_spk,
+                        want_v=want_v, out=out, lowhigh_iter0=0, presigmoid=presig)
+        torch.cuda.synchronize()
+        return spk, pv, v, st, out["lowhigh"].cpu().numpy()
+
+    spk0, pv0, v0, st0, lh0 = run(False, True)
+    for want_v in (False, True):         # (fast epilogues write only pv_out; with v_out the guarded ones run)
+        spk1, pv1, v1, st1, lh1 = run(True, want_v)
+        if want_spk:
+            assert torch.equal(spk0, spk1)
+        for a, c in zip(st0, st1):
+            assert torch.equal(a, c)
+        if pool == 1:
+            assert torch.equal(pv1, v0)                                     # the buffer IS v, bit for bit
+        else:
+            pooled = torch.maximum(v0[..., 0::2], v0[..., 1::2])             # (1,2) max-pool of the un-pooled v
+            assert torch.equal(pv1, pooled)
+        if want_v:
+            assert torch.equal(v1, v0)
+        np.testing.assert_allclose(torch.sigmoid(pv1).cpu().numpy(), pv0.cpu().numpy(), atol=PV_TOL, rtol=0)
+        assert lh0.shape == (2, 2) and np.array_equal(lh0, lh1), (lh0, lh1)
+    assert lh0.sum() > 0, "degenerate test: no pv value in the first or last bin"
+    # the counting pass on a presigmoid buffer as a call of its own
+    assert np.array_equal(ops.pv_lowhigh(pv1.reshape(T, -1), T, 0, presigmoid=True).cpu().numpy(), lh0)
+
+
+@pytest.mark.parametrize("rows,K,N", [(300, 8192, 24), (2500, 8192, 48), (129, 64, 33), (5, 32, 64), (2100, 65536, 24),
+                                      (40, 131072, 48), (1000, 1024, 24)])
+def test_readout_act(dev, rows, K, N):
+    """dcll_readout_act: with DCLL_ACT_SIGMOID == float64 sigmoid(v) . W^T + b inside the logit tolerance; with
+    DCLL_ACT_NONE the plain readout; and in both forms a row's logits do not depend on how many rows the call has (the
+    sequence path chunks batches) — incl. K >= 65536, which is split over K by K alone."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(9)
+    v = rng.normal(0, 2.5, size=(rows, K)).astype(np.float32)
+    W = rng.uniform(-.0055, .0055, size=(N, K)).astype(np.float32) * np.float32(np.sqrt(8192.0 / K))
+    b = rng.uniform(-.0055, .0055, size=(N,)).astype(np.float32)
+    sig = 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
+    dv, dW, db = cu(v, dev), cu(W, dev), cu(b, dev)
+    assert ops.readout_act_supported(dv, dW)
+    guard = torch.full((rows + 8, N), 7.0, device=dev)
+    out = ops.readout_act(dv, dW, db, out=guard[:rows], presigmoid=True)
+    assert float(guard[rows:].min()) == 7.0 and float(guard[rows:].max()) == 7.0
+    np.testing.assert_allclose(out.cpu().numpy(), sig @ W.astype(np.float64).T + b, atol=3e-5, rtol=0)
+    plain = ops.readout_act(dv, dW, db, presigmoid=False)
+    np.testing.assert_allclose(plain.cpu().numpy(), v.astype(np.float64) @ W.astype(np.float64).T + b, atol=2e-4, rtol=0)
+    # sigmoid applied by the kernel == the kernel on a buffer that already holds the device sigmoid of the same values
+    # (summation order identical) up to the ulp the two sigmoid instruction sequences may differ by
+    pre = ops.readout_act(torch.sigmoid(dv), dW, db, presigmoid=False)
+    np.testing.assert_allclose(out.cpu().numpy(), pre.cpu().numpy(), atol=2e-6, rtol=0)
+    if rows > 140:
+        part = ops.readout_act(dv[:133].contiguous(), dW, db, presigmoid=True)
+        assert torch.equal(part, out[:133])
+        part = ops.readout_act(dv[:133].contiguous(), dW, db, presigmoid=False)
+        assert torch.equal(part, plain[:133])
+    # shapes the 16x16x4 kernel does not serve are refused, not mis-read
+    from snn_modulation_classification_amd import _lib
+    bad = torch.zeros((4, 100), device=dev)
+    assert not ops.readout_act_supported(bad, torch.zeros((3, 100), device=dev))
+    with pytest.raises(_lib.DCLLUnsupported):
+        ops.readout_act(bad, torch.zeros((3, 100), device=dev), torch.zeros(3, device=dev))
+
+
+def _net(yaml_name, im, B, int8):
+    import os
+    from argparse import Namespace
+    from conftest import ROOT
+    from snn_modulation_classification_amd import quant
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", yaml_name))
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    torch.manual_seed(2)
+    np.random.seed(2)
+    net = ConvNetwork(args, im, B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
+                      learning_rates=None, burnin=2)
+    net.reset(True)
+    if int8:
+        quant.apply_int8_weights(net)
+    return net
+
+
+@pytest.mark.parametrize("yaml_name,im,B,T,int8", [("radio_ml_conv.yaml", (1, 16, 16), 21, 45, False),
+                                                   ("radio_ml_conv.yaml", (1, 32, 32), 3, 21, True),
+                                                   ("radio_ml_conv_ref.yaml", (1, 16, 128), 5, 23, True)])
+def test_network_int8_abi_and_presigmoid_do_not_change_the_run(dev, monkeypatch, yaml_name, im, B, T, int8):
+    """ConvNetwork.test_sequence with the int8 tensors handed across the ABI and v in the pv buffer (the defaults) == the
+    same run with DCLL_INT8_ABI=0 (kernels read the dequantised fp32 Parameter) and DCLL_PRESIGMOID=0 (pv = sigmoid(v) in
+    the buffer): neuron state of every layer bit for bit, logits within the sigmoid's ulp, identical pv statistics, same
+    per-step argmax up to logit ties."""
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    H, W = im[1], im[2]
+    torch.manual_seed(5)
+    iq = (0.4 * torch.randn(B, 2, 128)).to(dev)
+    enc = IQEncoder(W, H, device=dev)
+    a = _net(yaml_name, im, B, int8)
+    assert a.presigmoid and all((s.dclllayer.i2h.int8_weights() is not None) == int8 for s in a.dcll_slices)
+    a.reset()
+    ra = a.test_sequence(iq=iq, encoder=enc, T=T, t0=2)
+    monkeypatch.setenv("DCLL_INT8_ABI", "0")
+    monkeypatch.setenv("DCLL_PRESIGMOID", "0")
+    b = _net(yaml_name, im, B, int8)
+    assert not b.presigmoid and all(s.dclllayer.i2h.int8_weights() is None for s in b.dcll_slices)
+    b.reset()
+    rb = b.test_sequence(iq=iq, encoder=enc, T=T, t0=2)
+    torch.cuda.synchronize()
+    for i, (sa, sb) in enumerate(zip(a.dcll_slices, b.dcll_slices)):
+        for x, y in zip(sa.dclllayer.i2h.state, sb.dclllayer.i2h.state):
+            assert torch.equal(x, y), i
+        np.testing.assert_allclose(ra["logits"][i].cpu().numpy(), rb["logits"][i].cpu().numpy(), atol=2e-5, rtol=0)
+        assert torch.equal(ra["lowhigh"][i], rb["lowhigh"][i]) and ra["lowhigh"][i].shape[0] == T // 20
+        lg = (ra["o"] if i == len(a.dcll_slices) - 1 else ra["logits"][i]).cpu().numpy()
+        top2 = np.sort(lg, axis=-1)[..., -2:]
+        tie = (top2[..., 1] - top2[..., 0]) <= 1e-4
+        ca, cb = ra["clout"][i].cpu().numpy(), rb["clout"][i].cpu().numpy()
+        assert np.array_equal(ca[~tie], cb[~tie]), i
+    np.testing.assert_allclose(ra["o"].cpu().numpy(), rb["o"].cpu().numpy(), atol=2e-5, rtol=0)
+
+
+def test_int8_form_is_dropped_when_the_weight_changes(dev):
+    """The int8 tensor describes i2h.weight only until somebody writes the Parameter (a learning step, load_state_dict):
+    then the layer goes back to the fp32 weight instead of silently running on stale int8 values."""
+    net = _net("radio_ml_conv.yaml", (1, 16, 16), 2, True)
+    i2h = net.dcll_slices[1].dclllayer.i2h
+    assert i2h.int8_weights() is not None
+    with torch.no_grad():
+        i2h.weight.mul_(1.5)
+    assert i2h.int8_weights() is None
+    sd = net.dcll_slices[2].dclllayer.state_dict()
+    net.dcll_slices[2].dclllayer.load_state_dict(sd)
+    assert net.dcll_slices[2].dclllayer.i2h.int8_weights() is None
+    assert net.dcll_slices[0].dclllayer.i2h.int8_weights() is not None

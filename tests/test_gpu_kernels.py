@@ -791,7 +791,7 @@ def test_tiled_sequence_state_update_is_race_free(dev):
     import ctypes
     rc = _lib.get().dcll_conv_lif_sequence_cells(ctypes.byref(d), _lib.ptr(cu(cells, dev)), _lib.ptr(cu(W, dev)),
                                                  _lib.ptr(cu(b, dev)), _lib.ptr(tau4), _lib.ptr(eps0), _lib.ptr(eps1),
-                                                 _lib.ptr(arp), None, None, None, None, None, 0, T1, B1, None)
+                                                 _lib.ptr(arp), None, None, None, None, None, 0, None, T1, B1, None)
     assert rc == _lib.DCLL_ERR_INVALID and b"state_scratch" in _lib.get().dcll_last_error()
 
 

@@ -136,3 +136,46 @@ def test_entry_points_shard_over_ranks(tmp_path):
             assert np.array_equal(a, b), k
         else:
             np.testing.assert_allclose(b, a, rtol=0, atol=2e-3 * np.abs(a).max(), err_msg=k)
+
+
+@pytest.mark.timeout(1200)
+def test_rccl_code_path_on_a_one_rank_group_equals_the_plain_run(tmp_path):
+    """The RCCL branch of parallel.py on the 1-GPU box: ONE fresh child with WORLD_SIZE=1, DCLL_FORCE_DIST=1 and the
+    default backend (nccl == RCCL) forms a communicator with `device_id` and sends every exchange of the evaluation and
+    of a local-learning run through it on device tensors — int64 tallies, the fp32 gradient bucket per timestep, barrier,
+    destroy_process_group.  Everything it computes equals the plain single-process run BIT FOR BIT.  Then `bench.py
+    --gpus 1` under the same switch: additionally the fp64 ReduceOp.MAX of the step time; same votes as the plain run."""
+    B, T = 256, 64
+    plain, forced_dir = tmp_path / "plain", tmp_path / "rccl"
+    plain.mkdir()
+    forced_dir.mkdir()
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DCLL_DIST_BACKEND",
+                                                              "DCLL_FORCE_DIST")}
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rccl = dict(base, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                DCLL_FORCE_DIST="1")
+    for env, out in ((base, plain), (rccl, forced_dir)):
+        r = subprocess.run([sys.executable, WORKER, str(out), str(B), str(T)], env=env, timeout=900, capture_output=True,
+                           text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(plain / "rank_0_of_1.npz"), np.load(forced_dir / "rank_0_of_1.npz")
+    assert str(a["backend"]) == "none" and str(b["backend"]) == "nccl"
+    assert sorted(a.files) == sorted(b.files)
+    for key in a.files:
+        if key == "backend":
+            continue
+        x, y = a[key], b[key]
+        assert x.shape == y.shape and x.dtype == y.dtype and x.tobytes() == y.tobytes(), key
+    assert int(b["tallies"][0, -1]) == B
+    lines = {}
+    for name, env in (("plain", base), ("rccl", dict(rccl, MASTER_PORT=str(_free_port())))):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                            "--batch", "256", "--cpu-windows", "0", "--per-step", "0", "--config5", "0"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(out) == 1, r.stdout
+        lines[name] = json.loads(out[0])
+    assert "backend nccl" in lines["rccl"]["config"]["parallelism"] and "backend none" in lines["plain"]["config"]["parallelism"]
+    assert lines["rccl"]["n_gpus"] == 1 and lines["rccl"]["value"] > 0
+    assert lines["rccl"]["vote_accuracy_vs_random_labels"] == lines["plain"]["vote_accuracy_vs_random_labels"]

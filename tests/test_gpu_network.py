@@ -1,5 +1,6 @@
 """GPU tests of the drop-in surface: the reference's builder / slice protocol driven exactly like test_radio_ml.py
 drives it (per-step net.test) and through the fused whole-sequence path, against the reference's golden outputs."""
+import json
 import os
 from argparse import Namespace
 
@@ -639,42 +640,56 @@ def test_full_size_properties_batch8192_t128():
             assert np.array_equal(got.view(np.uint32), orc.layers[i].state[j].view(np.uint32)), (i, name)
 
 
-@pytest.mark.timeout(1200)
-def test_top1_agreement_with_reference_cpu_path_2048_windows():
-    """Top-1 (get_predictions_by_vote, reference dcll/pytorch_libdcll.py:44-61) of the fused MI355X path vs the
-    reference's CPU path (oracle/torch_ref.py: bit-identical to the imported reference on the golden vectors) on
-    4 x 512 synthetic windows, T=128: the votes of every layer must agree on >= 99.9 % of the windows."""
-    from oracle import torch_ref
+@pytest.mark.timeout(2400)
+def test_top1_agreement_and_spike_flips_vs_reference_cpu_path_10240_windows(capsys):
+    """The fused MI355X path against the reference's CPU path (oracle/torch_ref.py: the reference's eager op sequence,
+    bit-identical to the imported reference on the golden vectors) on 20 x 512 synthetic windows, T=128, free-running:
+      * top-1 (get_predictions_by_vote, reference dcll/pytorch_libdcll.py:44-61): the votes of every layer agree on
+        >= 99.9 % of the 10 240 windows, and so does the per-step argmax of the output layer (SURVEY 8(c): >= 10 k);
+      * spike trains of all three layers, bit by bit (4.0e9 spikes): the number of flips is REPORTED — the reference's conv
+        runs in oneDNN, whose summation order is not the pinned one, so exact equality at this scale is not a property
+        any fp32 implementation can promise — and the FIRST flip of every affected window must sit inside
+        the rounding band |v_ref| <= 8*eps*sum|w*eps1| (+ one rounding), i.e. be a legitimate fp32 tie-break, not a bug."""
+    from oracle import flip_count, torch_ref
     from snn_modulation_classification_amd.data.utils import IQEncoder
     from snn_modulation_classification_amd.networks import load_network_spec
-    NB, B, T, R_ = 4, 512, 128, 16
+    NB, B, T, R_ = 20, 512, 128, 16
     convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
     net = _radio_net(B, R_)
     enc = IQEncoder(R_, R_, device='cuda')
     sds = [{k: v.detach().cpu() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
     ref = torch_ref.RefConvNetwork(sds, convs, wrp=1.0)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     agree = np.zeros(3)
     step_agree = 0.0
+    flips = None
     for i in range(NB):
         g = torch.Generator().manual_seed(300 + i)
         iq = (0.4 * torch.randn(B, 2, 128, generator=g)).cuda()
         net.zero_states()
         net.reset()
-        res = net.test_sequence(iq=iq, encoder=enc, T=T, t0=0, collect=False)
+        res = net.test_sequence(iq=iq, encoder=enc, T=T, t0=0, collect=False, keep_spikes=True)
         cells = enc(iq, T, t0=0).cpu().long()
         x = torch.zeros(T, B, R_ * R_).scatter_(2, cells.unsqueeze(-1), 1.0).reshape(T, B, 1, R_, R_)
-        with torch.no_grad():
-            ref.reset(True)
-            for t in range(T):
-                ref.test(x[t])
+        dev_spikes = [flip_count.unpack_words(s_.cpu().numpy(), (R_, R_)) for s_ in res["spikes"]]
+        ref.reset(True)
+        flips = flip_count.merge(flips, flip_count.spike_flips(ref, x, dev_spikes))
         votes = ref.votes()
         for l in range(3):
             agree[l] += int((votes[l] == res["vote"][l].cpu().numpy()).sum())
         step_agree += float((np.array(ref.clout[2]) == res["clout"][2].cpu().numpy()).mean())
     agree /= NB * B
-    assert NB * B >= 2048
+    report = dict(flips, vote_agreement_per_layer=[float(a) for a in agree],
+                  output_layer_per_step_argmax_agreement=step_agree / NB)
+    with capsys.disabled():
+        print("\n[spike flips vs reference CPU path] %s" % json.dumps(report))
+    assert NB * B >= 10240 and flips["windows"] == NB * B
     assert (agree >= 0.999).all(), agree
     assert step_agree / NB >= 0.999, step_agree / NB
+    assert flips["first_flips_outside_rounding_band"] == 0, flips
+    assert flips["first_flips_inside_rounding_band"] == flips["windows_with_a_flip"]
+    # (how MANY windows flip is a property of the two summation orders and of how often |v| comes within ~1e-7 of zero —
+    #  SURVEY 7 H1 measured 3e-6 of all values below 1e-7 — not a defect count: it is reported above, not bounded here)
 
 
 class _Writer:
