@@ -1,0 +1,64 @@
+// Launch time of k_lif_seq_w3<64> alone (diagnostic, not product)   ./ablate_w3 [B] [W]
+// (Round 3: a build with s_memtime stamps per wave and phase — trace / chain A / epilogue A / chain B / epilogue B /
+//  barrier — showed where a step went; the numbers are in DESIGN.md 4.1c.  Build with -DW3_EPG=n / -fno-slp-vectorize to
+//  compare code-generation variants.)
+#include "../snn_modulation_classification_amd/csrc/dcll_seq_w3.hip"
+#include <vector>
+#include <stdlib.h>
+
+char *dcll_err_buf(void) { static char b[512]; return b; }
+
+static float run(int B, int Wd, int T, const uint32_t *spk_in, const float *W, const float *bias, const float *tau4, float *e0,
+                 float *e1, float *arp, uint32_t *spk_out, float *pv, int reps)
+{
+    const int HW = 16 * Wd, NTS = HW / 32;
+    int logW = 0;
+    while ((1 << logW) < Wd) ++logW;
+    const long nwg = ((long)B * NTS + 7) / 8;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(a);
+        if (Wd >= 32)
+            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, true>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
+                               dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f);
+        else
+            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, false>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
+                               dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char **argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 1024, Wd = argc > 2 ? atoi(argv[2]) : 64, T = 128;
+    const long HW = 16L * Wd, nin = (long)B * 64 * HW, nsp = (long)T * B * 64 * (HW / 32);
+    std::vector<uint32_t> hs(nsp);
+    srand(1);
+    for (auto &x : hs) { uint32_t v = 0; for (int i = 0; i < 32; ++i) v |= (uint32_t)((rand() % 100) < 8) << i; x = v; }
+    std::vector<float> hw(64 * 64 * 3), hb(64), ht(4 * 64);
+    for (auto &x : hw) x = (rand() / (float)RAND_MAX - 0.5f) * 1e-5f;
+    for (auto &x : hb) x = (rand() / (float)RAND_MAX - 0.5f) * 1e-3f;
+    for (int c = 0; c < 64; ++c) { ht[c] = 0.95f; ht[64 + c] = 20.f; ht[128 + c] = 0.85f; ht[192 + c] = 6.7f; }
+    uint32_t *spk_in, *spk_out; float *W, *bias, *tau4, *e0, *e1, *arp, *pv;
+    hipMalloc(&spk_in, nsp * 4); hipMalloc(&spk_out, (long)T * B * 64 * (HW / 64) * 4 + 64);
+    hipMalloc(&W, hw.size() * 4); hipMalloc(&bias, 256); hipMalloc(&tau4, 1024);
+    hipMalloc(&e0, nin * 4); hipMalloc(&e1, nin * 4); hipMalloc(&arp, nin * 4);
+    hipMalloc(&pv, (long)T * B * 64 * (HW / 2) * 4);
+    hipMemcpy(spk_in, hs.data(), nsp * 4, hipMemcpyHostToDevice);
+    hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(bias, hb.data(), 256, hipMemcpyHostToDevice);
+    hipMemcpy(tau4, ht.data(), 1024, hipMemcpyHostToDevice);
+    hipMemset(e0, 0, nin * 4); hipMemset(e1, 0, nin * 4); hipMemset(arp, 0, nin * 4);
+    const double ideal = 2.0 * 64 * 192 * HW * (double)T * B / 157.3e12 * 1e3;
+    const float ms = run(B, Wd, T, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, 4);
+    printf("k_lif_seq_w3<64> B=%d W=%d T=%d: %.2f ms = %.1f %% of the fp32-MFMA peak (ideal at 157.3 TF: %.2f ms)\n", B, Wd, T, ms,
+           100.0 * ideal / ms, ideal);
+    return 0;
+}

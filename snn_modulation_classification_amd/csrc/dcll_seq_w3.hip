@@ -14,17 +14,27 @@
 //     (cp, kx, h: ci = 2cp + h) of its two pixel tiles 2g, 2g+1, one after the other: no hand-off between waves (unlike
 //     k_lif_seq_c32d, whose K = 1568 had to be split over the waves);
 //   - lane <-> pixel map of a tile: lanes 0..15 hold the EVEN pixels, lanes 16..31 the ODD ones, so a pooling pair sits
-//     in lanes j and j + 16: pooled pv = max with one ds_swizzle (xor 16), and the ballot of the spike compare carries
-//     the even pixels in bits 0..15 and the odd ones in bits 16..31: pooled spike half-word = (w & 0xffff) | (w >> 16);
-//     the half-words of a wave's two tiles are one 32-bit word of the next layer's input;
+//     in lanes j and j + 16 = the same lane of two neighbouring 16-lane ROWS.  Two accumulator registers (channels c, c+1)
+//     are pooled by ONE v_permlane16_swap_b32 (gfx950: swaps the odd rows of one register with the even rows of the
+//     other) + ONE v_max_f32: afterwards rows 0 / 2 hold the pooled map of channel c (lane halves h = 0 / 1), rows 1 / 3
+//     that of channel c+1 — 64 DISTINCT pooled values in one register, one store instruction, no LDS round trip (the
+//     first form used a ds_swizzle per value and stored every pooled value from both lanes of its pair).  The pooled
+//     spike is (pooled v > 0) — max(s_a, s_b) exactly — so one v_cmp on that register yields the four 16-bit pooled
+//     half-words of the two channels; the half-words of a wave's two tiles are one 32-bit word of the next layer's input;
 //   - per step: trace update (all threads) | barrier | 2 x 96 MFMAs + epilogue per wave | barrier.
 // Outputs are the POOLED maps: spk_out (T,B,64,H*W/64) packed, pv_out (T,B,64,H,W/2); v_out (T,B,64,H,W) un-pooled.
 // Same pinned arithmetic as every other path (include/dcll_hip.h): bit-identical to the per-step kernels / the C oracle.
 #include "dcll_internal.h"
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
-constexpr int W3_CHS = 388;         // floats per channel image: 256 pixels + 256 / W shared pad columns + 1 <= 385 (W = 2);
-                                    // = 4 mod 32: the 8 channels x 8 words of a wave's trace access spread over the banks
+#ifndef W3_EPG
+#define W3_EPG 2                    // register pairs per epilogue group
+#endif
+constexpr int W3_CHS = 385;         // floats per channel image: 256 pixels + 256 / W shared pad columns + 1 <= 385 (W = 2);
+                                    // ODD: the 64 lanes of a trace access are the 64 channels of one tile, and an odd channel
+                                    // stride maps them onto the 64 LDS banks one to one (388 = 4 mod 32 with lanes =
+                                    // 8 channels x 8 tiles was a 4-way conflict on every trace read and write)
 
 // WIDE: W >= 32 — a thread's 32 trace pixels lie in one row, their LDS offsets are immediates (for narrower planes every
 // element adds a wave-uniform row term: two more instructions per access)
@@ -47,7 +57,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // right after a wave's own chains of step t — one barrier per step instead of two, and the waves of a SIMD drift apart
     // (one in its trace / epilogue phase while the other issues MFMAs).
     constexpr bool DB = WIDE && CIN == 64;
-    constexpr int CHS = DB ? 292 : W3_CHS;              // both = 4 mod 32 (bank spread of the trace accesses)
+    constexpr int CHS = DB ? 289 : W3_CHS;              // both odd (bank spread of the trace accesses); 289 >= 256 + 8 + 1
     constexpr int IMG = CIN * CHS + 8;
     __shared__ __attribute__((aligned(16))) float img[(DB ? 2 : 1) * IMG];
     __shared__ float sbias[64];
@@ -62,9 +72,10 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     if (tid < 64) sbias[tid] = bias[tid];
 
     // ---- trace ownership -------------------------------------------------------------------------------------------
-    // CIN = 64: thread (ci = tid >> 3, wq = tid & 7) owns the 32 pixels of tile wq of channel ci (= one input word);
+    // CIN = 64: thread (ci = lane, wq = wave) owns the 32 pixels of tile wq of channel ci (= one input word): a wave is
+    //           one tile of all 64 channels — validity, sample and tile index are wave-uniform, LDS accesses conflict-free;
     // CIN = 1:  threads 0..255 own one pixel each of the single channel
-    const int ci_t = CIN == 1 ? 0 : tid >> 3, wq = CIN == 1 ? tid >> 5 : tid & 7;
+    const int ci_t = CIN == 1 ? 0 : lane, wq = CIN == 1 ? tid >> 5 : w;
     const long Gt = G0 + wq;
     const bool tvalid = Gt < ntot && (CIN == 64 || tid < W3_PX);
     const long bt = tvalid ? Gt / NTS : 0;
@@ -133,8 +144,18 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
             for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[src + lb + i + (WIDE ? 0 : (i >> lw))];
 #pragma unroll
             for (int i = i0; i < i0 + 8 && i < NE; ++i) {
-                const float x = CIN == 1 ? (cl == pix0 ? 1.0f : 0.0f) : (float)((wd >> i) & 1u);
-                trace_update(x, ta, tm, tas, ts, e0[i], e1[i - i0]);
+                if (CIN == 1) {
+                    trace_update(cl == pix0 ? 1.0f : 0.0f, ta, tm, tas, ts, e0[i], e1[i - i0]);
+                } else {
+                    // x * tau_s for x in {0, 1} = the sign-extended input bit AND tau_s (v_bfe_i32 + v_and_b32: exact), then
+                    // the two trace lines of dcll/pytorch_libdcll.py:493-494, every op rounded separately
+                    const float a = __int_as_float(__builtin_amdgcn_sbfe((int)wd, i, 1) & __float_as_int(ts));
+                    const float bb = tas * e0[i];
+                    e0[i] = a + bb;
+                    const float cc = ta * e1[i - i0];
+                    const float dd = e0[i] * tm;
+                    e1[i - i0] = cc + dd;
+                }
                 if (tvalid) img[dst + lb + i + (WIDE ? 0 : (i >> lw))] = e1[i - i0];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -184,68 +205,69 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // epilogue: refractory trace, threshold, sigmoid, (1,2) max-pool, pooled spike half-word.
-            // stores as wave-uniform base (per value) + 32-bit lane offset: no 64-bit address VALU
+            // epilogue: refractory trace, threshold, (1,2) max-pool, sigmoid, pooled spike half-words — two accumulator
+            // registers (channels cr, cr + 1) at a time.  Stores as wave-uniform base (per pair) + 32-bit lane offset.
             const long row = ((long)t * B + bb) * 64 + 32 * mt;
             const char *pvb = (const char *)(pv_out + row * HW2), *vb = (const char *)(v_out + row * HW);
-            // lane BYTE offsets (+ cr * HW2 * 4 / + cr * HW * 4, wave-uniform, per value): the store takes SGPR base + VGPR
-            // offset as they are — no shift / add per store
-            unsigned lp = 4u * (4 * h * HW2 + 16 * mm + (jj & 15)), lv = 4u * (4 * h * HW + 32 * mm + perm);
+            // lane BYTE offsets.  Un-pooled v: value r of lane (h, jj) is channel cr(r) + 4 h, pixel perm(jj).  Pooled map
+            // after the row swap: lane row rw = lane >> 4 holds channel cr + (rw & 1) + 4 (rw >> 1), pooled pixel lane & 15.
+            const int rw = lane >> 4;
+            unsigned lp = 4u * ((4 * (rw >> 1) + (rw & 1)) * HW2 + 16 * mm + (lane & 15)), lv = 4u * (4 * h * HW + 32 * mm + perm);
             int hw2 = 4 * HW2, hw1 = 4 * HW;
             // opaque per step: otherwise the per-value store addresses derived from them are hoisted out of the time loop
             asm volatile("" : "+v"(lp), "+v"(lv), "+s"(hw2), "+s"(hw1));
-            // four values at a time: their ds_swizzles go out together and are waited for once
-            static_for<0, 4>([&](auto gc) {
-                constexpr int r0 = 4 * decltype(gc)::value;
-                float q[4], vv[4];
-                static_for<0, 4>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value, r = r0 + k;
-                    float v = acc[r];
-                    bool sp;
-                    if (REFRACTORY) v = refractory(acc[r], arp[r], alpharp, wrp, sp);
-                    else sp = v > 0.0f;
-                    const unsigned long long mk = __ballot(sp);
-                    // per half h: even pixels in bits 0..15, odd in 16..31 -> 16 pooled bits
-                    const uint32_t a0 = (uint32_t)mk, a1 = (uint32_t)(mk >> 32);
-                    const uint32_t w0 = (a0 & 0xffffu) | (a0 >> 16), w1 = (a1 & 0xffffu) | (a1 >> 16);
+            static_for<0, 16 / (2 * W3_EPG)>([&](auto gc) {             // W3_EPG pairs at a time: keeps the temporaries few
+                constexpr int r0 = 2 * W3_EPG * decltype(gc)::value;
+                float pm[W3_EPG];
+                int &vwr = vw;          // (named here: the asm operand of the inner generic lambda alone does not capture it)
+                static_for<0, W3_EPG>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value, r = r0 + 2 * k, cr = (r & 3) + 8 * (r >> 2);
+                    float vx = acc[r], vy = acc[r + 1];
+                    bool sx, sy;
+                    if (REFRACTORY) {
+                        vx = refractory(acc[r], arp[r], alpharp, wrp, sx);
+                        vy = refractory(acc[r + 1], arp[r + 1], alpharp, wrp, sy);
+                    }
+                    if ((OUT & 2) && valid) {
+                        *(float *)(vb + (long)cr * hw1 + lv) = vx;
+                        *(float *)(vb + (long)(cr + 1) * hw1 + lv) = vy;
+                    }
+                    // rows (16 lanes): vx = [even px | odd px | even px | odd px] of channels cr (h = 0), cr + 4 (h = 1);
+                    // after the swap sw[0] = [vx.row0, vy.row0, vx.row2, vy.row2], sw[1] = [vx.row1, vy.row1, vx.row3, vy.row3]:
+                    // their maximum is the pooled v of channel cr in rows 0 / 2 and of channel cr + 1 in rows 1 / 3
+                    // (v is never NaN: plain v_max_f32, no canonicalisation)
+                    const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(vx), __float_as_uint(vy), false, false);
+                    asm("v_max_f32 %0, %1, %2" : "=v"(pm[k]) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
+                    // pooled spike = max(s_a, s_b) = (pooled v > 0), exactly: bits 0..15 channel cr, 16..31 channel cr + 1
+                    // (h = 0), 32..63 the same for h = 1 -> parked in lanes k' and 32 + k' of vw (k' = pair index)
+                    const unsigned long long mk = __ballot(pm[k] > 0.0f);
+                    int &vwi = vwr;
                     // (wait states as the compiler places them around its own v_writelane, see k_lif_seq_c1)
                     asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
-                        : "+v"(vw) : "s"(w0), "s"(w1), "n"(r), "n"(32 + r));
-                    vv[k] = v;
-                    if (OUT & 1) q[k] = (OUT & 4) ? v : sigmoidf_dev(v);
+                        : "+v"(vwi) : "s"((uint32_t)mk), "s"((uint32_t)(mk >> 32)), "n"(r / 2), "n"(32 + r / 2));
                 });
-                if (OUT & 1) {
-                    float o[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(q[k]), 0x401F));   // lane ^ 16
-                    if (valid) {
-                        // both lanes of a pooling pair hold the pair's maximum and store it to the same address: no lane
-                        // predicate, no exec-mask branch per value (neither sigmoid outputs nor v are ever NaN: plain v_max_f32)
-                        static_for<0, 4>([&](auto kc) {
-                            constexpr int k = decltype(kc)::value, r = r0 + k, cr = (r & 3) + 8 * (r >> 2);
-                            float qm;
-                            asm("v_max_f32 %0, %1, %2" : "=v"(qm) : "v"(q[k]), "v"(o[k]));
-                            *(float *)(pvb + (long)cr * hw2 + lp) = qm;
-                        });
-                    }
-                }
-                if ((OUT & 2) && valid) {
-                    static_for<0, 4>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value, r = r0 + k, cr = (r & 3) + 8 * (r >> 2);
-                        *(float *)(vb + (long)cr * hw1 + lv) = vv[k];
+                if ((OUT & 1) && valid) {
+                    static_for<0, W3_EPG>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value, r = r0 + 2 * k, cr = (r & 3) + 8 * (r >> 2);
+                        // sigmoid is monotone: sigmoid(max-pool(v)) == max-pool(sigmoid(v)) (up to its last ulp; pv is not
+                        // bit-pinned) — half as many transcendentals; (OUT & 4): the readout applies it (pv_presigmoid)
+                        *(float *)(pvb + (long)cr * hw2 + lp) = (OUT & 4) ? pm[k] : sigmoidf_dev(pm[k]);
                     });
                 }
-                __builtin_amdgcn_sched_barrier(0);      // one group at a time: keeps the temporaries few
+                __builtin_amdgcn_sched_barrier(0);
             });
         };
         do_tile(baseA, arpA, validA, bA, mA, vwA);
         do_tile(baseB, arpB, validB, bB, mB, vwB);
-        // lanes 0..15 / 32..47 hold the pooled half-words of channel (lane & 3) + 8 ((lane & 15) >> 2) + 4 h of my two
-        // tiles: together one 32-bit word of the next layer's input
-        if (spk_out && jj < 16 && validA) {
+        // lanes q / 32 + q (q < 8) hold, for the channel pair cr(2q), cr(2q) + 1 (+ 4 h), the pooled half-words of my two
+        // tiles as (channel cr | channel cr + 1 << 16): regrouped into the two 32-bit words (tile A | tile B << 16) of the
+        // next layer's input
+        if (spk_out && jj < 8 && validA) {
             const long row = ((long)t * B + bA) * 64 + 32 * mt;
-            (spk_out + row * NW2)[(unsigned)((jj & 3) + 8 * (jj >> 2) + 4 * h) * (unsigned)NW2 + (unsigned)(mA >> 1)] =
-                (uint32_t)vwA | ((uint32_t)vwB << 16);
+            uint32_t *wp = spk_out + row * NW2 + (unsigned)(mA >> 1);
+            const unsigned cq = (unsigned)(((2 * jj) & 3) + 8 * ((2 * jj) >> 2) + 4 * h);
+            wp[cq * (unsigned)NW2] = ((uint32_t)vwA & 0xffffu) | ((uint32_t)vwB << 16);
+            wp[(cq + 1) * (unsigned)NW2] = ((uint32_t)vwA >> 16) | ((uint32_t)vwB & 0xffff0000u);
         }
         if (DB && t + 1 < T) trace_step(word, cell, cur, cur ^ IMG);         // step t+1's traces into the other image
         lds_barrier();

@@ -62,20 +62,29 @@ def init_process_group(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_device(local_rank))
             kw["device_id"] = torch.device("cuda", local_device(local_rank))
-        if backend == "gloo":
-            # gloo announces its connections with a printf on stdout; stdout is reserved for the job's report (rank 0's
-            # one JSON line), so fd 1 points at stderr while the group forms
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-                dist.barrier()
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
-        else:
+        # Both backends announce themselves with a printf on STDOUT while the group / the communicator forms (gloo its
+        # connections, RCCL a five-line version banner — seen on the 1-GPU box with the one-rank RCCL group); stdout is
+        # reserved for the job's report (rank 0's one JSON line), so fd 1 points at stderr until the first collective
+        # has run (RCCL creates its communicator lazily when no device_id is given).
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+            if backend == "nccl":
+                warm = torch.zeros(1, device=kw["device_id"])
+                dist.all_reduce(warm)
+                torch.cuda.synchronize(kw["device_id"])
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            try:                                # the banner sits in libc's stdout buffer when fd 1 is a pipe: push it
+                import ctypes                   # out while fd 1 still points at stderr
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, local_rank, world
 
 
