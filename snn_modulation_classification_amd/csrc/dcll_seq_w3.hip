@@ -31,10 +31,16 @@ constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 #ifndef W3_EPG
 #define W3_EPG 2                    // register pairs per epilogue group
 #endif
-constexpr int W3_CHS = 385;         // floats per channel image: 256 pixels + 256 / W shared pad columns + 1 <= 385 (W = 2);
-                                    // ODD: the 64 lanes of a trace access are the 64 channels of one tile, and an odd channel
-                                    // stride maps them onto the 64 LDS banks one to one (388 = 4 mod 32 with lanes =
-                                    // 8 channels x 8 tiles was a 4-way conflict on every trace read and write)
+// eps1 image in LDS, PIXEL-major: element (channel ci, padded pixel position q) at q * PST + ci, PST = 66 (c_in = 64) —
+//   - q = p + (p >> log2 W) + 1 for pixel p of the workgroup's 256: one shared zero position between rows = the conv's
+//     horizontal padding; W3_NPOS positions: 256 + 256 / W + 2 <= 386 (W = 2), 266 when W >= 32;
+//   - the 64 lanes of a trace access are the 64 channels of one pixel: consecutive floats, conflict-free;
+//   - a B fragment (lane = pixel, k lanes = channel pair 2cp + h, tap kx) is at lane base + kx * PST + 2 cp: all 96 k-steps of
+//     a chain lie within 2 * 66 + 62 = 194 floats of ONE per-lane base — inside the 255-dword reach of ds_read2_b32's 8-bit
+//     offsets, so the chain has no address arithmetic at all (channel-major images needed a new base per channel pair:
+//     ~70 v_add_u32 per wave and step on the vector pipe the MFMAs run on); PST = 66 = 2 mod 64 puts the 32 pixels x 2
+//     channels of a fragment read on 64 different banks.
+constexpr int W3_NPOS = 386;
 
 // WIDE: W >= 32 — a thread's 32 trace pixels lie in one row, their LDS offsets are immediates (for narrower planes every
 // element adds a wave-uniform row term: two more instructions per access)
@@ -57,8 +63,8 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // right after a wave's own chains of step t — one barrier per step instead of two, and the waves of a SIMD drift apart
     // (one in its trace / epilogue phase while the other issues MFMAs).
     constexpr bool DB = WIDE && CIN == 64;
-    constexpr int CHS = DB ? 289 : W3_CHS;              // both odd (bank spread of the trace accesses); 289 >= 256 + 8 + 1
-    constexpr int IMG = CIN * CHS + 8;
+    constexpr int PST = CIN == 1 ? 1 : 66;              // floats per padded pixel position
+    constexpr int IMG = (DB ? 266 : W3_NPOS) * PST + 8;
     __shared__ __attribute__((aligned(16))) float img[(DB ? 2 : 1) * IMG];
     __shared__ float sbias[64];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, jj = lane & 31;
@@ -82,17 +88,17 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     const int mtile = tvalid ? (int)(Gt % NTS) : 0;
     const float ta = tau4[0 * CIN + ci_t], tm = tau4[1 * CIN + ci_t], tas = tau4[2 * CIN + ci_t], ts = tau4[3 * CIN + ci_t];
     float e0[NE];
-    // LDS offset of my first pixel: block pixel p -> ci * CHS + p + (p >> logW) + 1
+    // LDS offset of my first pixel: block pixel p -> (p + (p >> logW) + 1) * PST + ci
     // (for my 32 consecutive pixels 32 wq + i the row term splits into a per-thread part and a wave-uniform one:
     //  (32 wq + i) >> logW == ((32 wq) >> logW) + (i >> logW), W a power of two)
     const int p0 = CIN == 1 ? tid & (W3_PX - 1) : 32 * wq;
-    const int loff0 = ci_t * CHS + p0 + 1 + (p0 >> logW);
+    const int loff0 = (p0 + 1 + (p0 >> logW)) * PST + ci_t;
     const long sbase = (bt * CIN + ci_t) * HW + 32L * mtile + (CIN == 1 ? (tid & 31) : 0);     // my first state element
     __syncthreads();                                     // image zeroed
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         e0[i] = tvalid ? eps0_g[sbase + i] : 0.0f;
-        if (tvalid) img[loff0 + i + (WIDE ? 0 : (i >> logW))] = eps1_g[sbase + i];
+        if (tvalid) img[loff0 + (i + (WIDE ? 0 : (i >> logW))) * PST] = eps1_g[sbase + i];
     }
 
     // ---- weights of my output-channel tile, stationary: A[co = 32 mt + jj][k] ----------------------------------------
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     const int mA = validA ? (int)(GA % NTS) : 0, mB = validB ? (int)((GA + 1) % NTS) : 0;
     const int pA = 64 * g + perm, pB = pA + 32;
     // B-fragment lane base: CIN = 64: channel h of the pair; CIN = 1: tap h of the pair (tap kx reads x + kx - 1)
-    const int baseA = (CIN == 1 ? h : h * CHS) + pA + (pA >> logW), baseB = (CIN == 1 ? h : h * CHS) + pB + (pB >> logW);
+    const int baseA = h + (pA + (pA >> logW)) * PST, baseB = h + (pB + (pB >> logW)) * PST;
     float arpA[16], arpB[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
         for (int i0 = 0; i0 < NE; i0 += 8) {
             float e1[8];
 #pragma unroll
-            for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[src + lb + i + (WIDE ? 0 : (i >> lw))];
+            for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[src + lb + (i + (WIDE ? 0 : (i >> lw))) * PST];
 #pragma unroll
             for (int i = i0; i < i0 + 8 && i < NE; ++i) {
                 if (CIN == 1) {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                     const float dd = e0[i] * tm;
                     e1[i - i0] = cc + dd;
                 }
-                if (tvalid) img[dst + lb + i + (WIDE ? 0 : (i >> lw))] = e1[i - i0];
+                if (tvalid) img[dst + lb + (i + (WIDE ? 0 : (i >> lw))) * PST] = e1[i - i0];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -191,12 +197,12 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                 // the 6 B fragments of channel pairs cp + 2, cp + 3 are fetched before the MFMAs of pairs cp, cp + 1
                 float bq[2][6];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) bq[0][q] = img[cur + base + (q / 3) * 2 * CHS + q % 3];
+                for (int q = 0; q < 6; ++q) bq[0][q] = img[cur + base + (q / 3) * 2 + (q % 3) * PST];
 #pragma unroll
                 for (int c2 = 0; c2 < 16; ++c2) {
                     if (c2 + 1 < 16) {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) bq[(c2 + 1) & 1][q] = img[cur + base + (2 * (c2 + 1) + q / 3) * 2 * CHS + q % 3];
+                        for (int q = 0; q < 6; ++q) bq[(c2 + 1) & 1][q] = img[cur + base + (2 * (c2 + 1) + q / 3) * 2 + (q % 3) * PST];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     for (int i = 0; i < NE; ++i) {
         if (tvalid) {
             eps0_g[sbase + i] = e0[i];
-            eps1_g[sbase + i] = img[fin + loff0 + i + (WIDE ? 0 : (i >> logW))];
+            eps1_g[sbase + i] = img[fin + loff0 + (i + (WIDE ? 0 : (i >> logW))) * PST];
         }
     }
     if (REFRACTORY) {
