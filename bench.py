@@ -183,7 +183,7 @@ def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
                                 "fused sequence kernels" if fused else "per-step path (7 layer calls per timestep)"),
                    "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [H, W],
                    "path": "sequence" if fused else "per-step", "int8_weights_through_abi": int8_abi,
-                   "pv_presigmoid": bool(net.presigmoid),
+                   "pv_presigmoid": net.presigmoid != '0',
                    "parallelism": "batch shards, %d rank(s), tally all-reduce only" % world},
         "roofline": roof, "kernel_ms_per_step": kernel_ms, "hbm_bound_kernels": hbm,
         "conv_tflops_per_gpu": flop * steps / dt / 1e12}

@@ -3,11 +3,14 @@
 //   ./ablate_c32d co         with the co-resident readout (k_readout_direct, <= 64 VGPRs, no LDS) running on a second,
 //                            lower-priority stream over the previous pv buffer — what test_sequence(overlap_readout=True)
 //                            does: how much does a stage of the layer kernel stretch?
+//   ./ablate_c32d presig     pv_presigmoid (round 3): the epilogue stores v instead of sigmoid(v) — launch time and the
+//                            stamps of the non-MFMA phase with and without the four sigmoids per wave and stage
 #include "../snn_modulation_classification_amd/csrc/dcll_hip.hip"
 #include <vector>
 int main(int argc, char **argv)
 {
-    const bool co = argc > 1;
+    const bool presig = argc > 1 && argv[1][0] == 'p';
+    const bool co = argc > 1 && !presig;
     const int B = 1024, T = 128;
     size_t nin = (size_t)T * B * 32 * 8;
     uint32_t *spk_in, *spk_out; float *W, *bias, *tau4, *e0, *e1, *arp, *pv; unsigned long long *dbg;
@@ -20,6 +23,8 @@ int main(int argc, char **argv)
     hipMalloc(&e0, ns * 4); hipMalloc(&e1, ns * 4); hipMalloc(&arp, ns * 4);
     hipMemset(e0, 0, ns * 4); hipMemset(e1, 0, ns * 4); hipMemset(arp, 0, ns * 4);
     hipMalloc(&pv, (size_t)T * ns * 4); hipMalloc(&dbg, 4096); hipMemset(dbg, 0, 4096);
+    float *dbg_v = nullptr;                     // a full-size v output whose head doubles as the stamp area (presig mode)
+    if (presig) hipMalloc(&dbg_v, (size_t)T * ns * 4);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     // co-resident readout: 24 rows over a second pv buffer (T*B rows of 8192), launched back to back on its own stream so
     // that it runs for the whole duration of the layer kernel
@@ -37,6 +42,36 @@ int main(int argc, char **argv)
     auto launch_side = [&](int n) {
         for (int i = 0; i < n; ++i) dcll_launch_readout_direct(pv2, Wro, nullptr, ro, (long)T * B, 8192, 24, side);
     };
+    if (presig) {
+        for (int mode = 0; mode < 2; ++mode) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                hipEventRecord(a);
+                if (mode == 0)
+                    hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);
+                else
+                    hipLaunchKernelGGL((k_lif_seq_c32d<true, 2, 0>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, pv, T, B, 0.65f, 1.0f);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                if (ms < best) best = ms;
+            }
+            printf("k_lif_seq_c32d B=%d T=%d, buffer = %s: %.3f ms (best of 4)\n", B, T, mode ? "v (pv_presigmoid)" : "sigmoid(v)", best);
+            // stamps: the debug area is the head of the v output (OUT = 3 / 2: both variants also write v there first)
+            if (mode == 0)
+                hipLaunchKernelGGL((k_lif_seq_c32d<true, 3, 1>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)dbg_v, T, B, 0.65f, 1.0f);
+            else
+                hipLaunchKernelGGL((k_lif_seq_c32d<true, 2, 1>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, (float *)nullptr, (float *)dbg_v, T, B, 0.65f, 1.0f);
+            hipDeviceSynchronize();
+            unsigned long long h3[64];
+            hipMemcpy(h3, dbg_v, 512, hipMemcpyDeviceToHost);
+            const double nst3 = 4.0 * T + 8;
+            printf("  cycles per stage | non-MFMA phase | barrier 2 | chains + slot write | barrier 1%s\n", mode ? "" : "   (this variant also stores v: OUT = 3)");
+            for (int w = 0; w < 8; ++w)
+                printf("  w%d: %8.0f | %7.0f | %7.0f | %7.0f | %7.0f\n", w, h3[w * 8] / nst3, h3[w * 8 + 1] / nst3, h3[w * 8 + 2] / nst3,
+                       h3[w * 8 + 3] / nst3, h3[w * 8 + 4] / nst3);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 3 && !co; ++rep) {
         hipEventRecord(a);
         hipLaunchKernelGGL((k_lif_seq_c32d<true, 1, 0>), dim3(B), dim3(512), 0, 0, spk_in, dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, 0.65f, 1.0f);

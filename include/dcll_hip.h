@@ -185,6 +185,19 @@ int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W
                         float *out_s, float *out_p, float *out_pv, float *out_v, int32_t B, void *stream);
 
 /*
+ * All T timesteps of a DenseDCLLlayer in one call — `for t: layer.forward(x[t])` (:250-255) — the dense twin of
+ * dcll_conv_lif_sequence.  x (T,B,in) fp32; neuron state in/out as in dcll_dense_lif_step (read at t = 0, written after
+ * t = T-1); out_s, out_pv, out_v (T,B,out), out_p (T,B,target), each may be NULL (out_p needs out_pv).
+ * in_features <= 1024 and out_features <= 128: ONE launch with the state on chip for all T (32 samples per workgroup, eps0
+ * in registers, eps1 in LDS, W streamed from L2); larger layers advance step by step inside the call with the state in
+ * HBM.  The local readout runs once over all T x B rows.  Same pinned chain as the per-step call: bit-identical v / s / state.
+ */
+int dcll_dense_lif_sequence(const dcll_dense_desc *d, const float *x, const float *W, const float *b,
+                            const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
+                            float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
+                            float *out_s, float *out_p, float *out_pv, float *out_v, int32_t T, int32_t B, void *stream);
+
+/*
  * Whole-sequence fast path behind ConvNetwork.test (networks/__init__.py:182-185) for one layer: all T timesteps
  * of dcll/pytorch_libdcll.py:485-509 / :407-426 in ONE launch with the neuron state held on-chip.
  * Supported geometry (else DCLL_ERR_UNSUPPORTED): c_in==32, c_out==32, 7x7, pad 3, pool 1, time constants constant

@@ -75,6 +75,7 @@ SIGNATURES = {
     "dcll_adam_step_dyn": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P, _P]),
     "dcll_cells_to_planes": (_I32, [_P, _P, _I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
+    "dcll_dense_lif_sequence": (_I32, [_DDP] + [_P] * 16 + [_I32, _I32, _P]),
     "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _P, _P, _I32, _OP, _I32, _I32, _P]),
     "dcll_permute_readout": (_I32, [_P, _P, _I32, _P]),
     "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_P, _P, _I32, _OP, _I32, _I32, _P]),

@@ -26,7 +26,7 @@
 //                      systolic hand-off, every wave runs two whole chains, weights stream through LDS.
 //   k_trace / k_conv_lif_tiled / k_conv_lif / k_pool   generic per-step path (any geometry, state in HBM) — the exact
 //                      drop-in for `.forward`; same pinned order.
-//   k_dense_lif        DenseDCLLlayer step.
+//   (dense twins: k_dense_lif_mfma / k_dense_lif_seq in dcll_dense.hip.)
 //   k_bwd_dv[_nopool], k_bwd_wgrad_c32 (MFMA, 16x16 plane or 16x16 tiles with halo), k_bwd_wgrad (any geometry, row
 //                      bands), k_bwd_reduce[4], k_bwd_outgrad[_part/_reduce]   backward of one layer step (local learning).
 //   k_readout_v4 / k_readout_ks / k_readout_rows / k_readout (+ k_readout_sum)   fp32-MFMA GEMMs for i2o / output_:
@@ -244,33 +244,6 @@ __global__ void k_pool(dcll_conv_desc d, int ch, int cw, int ph, int pw, const f
         }
     s_out[i] = ms;
     pv_out[i] = mp;
-}
-
-// DenseDCLLlayer step: one thread per (b, o); chain over input features in natural order (pairs (2cp,2cp+1)).
-__global__ void k_dense_lif(dcll_dense_desc d, const float *__restrict__ eps1, const float *__restrict__ W,
-                            const float *__restrict__ bias, float *__restrict__ arp, float *__restrict__ s_out,
-                            float *__restrict__ pv_out, float *__restrict__ v_out, long n)
-{
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int o = (int)(i % d.out_features);
-    long b = i / d.out_features;
-    const float *e = eps1 + b * d.in_features;
-    const float *w = W + (long)o * d.in_features;
-    float acc = bias ? bias[o] : 0.0f;
-    for (int k = 0; k < d.in_features; ++k) acc = __builtin_fmaf(e[k], w[k], acc);
-    float v = acc;
-    bool s;
-    if (d.refractory) {
-        float a = arp[i];
-        v = refractory(acc, a, d.alpharp, d.wrp, s);
-        arp[i] = a;
-    } else {
-        s = v > 0.0f;
-    }
-    if (v_out) v_out[i] = v;
-    if (s_out) s_out[i] = s ? 1.0f : 0.0f;
-    if (pv_out) pv_out[i] = sigmoidf_dev(v);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2607,14 +2580,50 @@ extern "C" int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, con
     if (B < 0) return fail(DCLL_ERR_INVALID, "dcll_dense_lif_step: negative batch");
     if (B == 0) return DCLL_OK;
     hipStream_t st = (hipStream_t)stream;
-    const long nin = (long)B * d->in_features, nout = (long)B * d->out_features;
+    const long nin = (long)B * d->in_features;
     hipLaunchKernelGGL(k_trace, dim3(nblk(nin, 256) > 4096 ? 4096 : nblk(nin, 256)), dim3(256), 0, st, x, alpha, tau_m,
                        alphas, tau_s, eps0, eps1, nin, (long)d->in_features, d->tau_is_tensor);
     HIP_CHECK_LAUNCH("k_trace");
-    hipLaunchKernelGGL(k_dense_lif, dim3(nblk(nout, 256)), dim3(256), 0, st, *d, eps1, W, b, arp, out_s, out_pv, out_v,
-                       nout);
-    HIP_CHECK_LAUNCH("k_dense_lif");
+    int rc = dcll_launch_dense_mfma(d, eps1, W, b, arp, out_s, out_pv, out_v, B, st);       // pinned chain as an MFMA GEMM
+    if (rc) return rc;
     if (i2o_W && out_p) return launch_readout(out_pv, i2o_W, i2o_b, out_p, B, d->out_features, d->target, st);
+    return DCLL_OK;
+}
+
+// All T steps of a dense layer in one call: `for t: DenseDCLLlayer.forward(x[t])` (dcll/pytorch_libdcll.py:250-255).
+// Small layers (dcll_dense_seq_fits: in_features <= 1024, out_features <= 128) run k_dense_lif_seq — one launch, neuron
+// state on chip for the whole sequence; larger ones advance step by step (k_trace + k_dense_lif_mfma, state in HBM: the
+// traces of ONE sample at in_features = 8192 are 64 KB).  Either way the local readout runs once over all T x B rows.
+extern "C" int dcll_dense_lif_sequence(const dcll_dense_desc *d, const float *x, const float *W, const float *b,
+                                       const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
+                                       float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
+                                       float *out_s, float *out_p, float *out_pv, float *out_v, int32_t T, int32_t B,
+                                       void *stream)
+{
+    const char *who = "dcll_dense_lif_sequence";
+    if (!d || d->in_features < 1 || d->out_features < 1) return fail(DCLL_ERR_INVALID, "bad descriptor", who);
+    if (T == 0 || B == 0) return DCLL_OK;
+    if (!x || !W || !alpha || !tau_m || !alphas || !tau_s || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "null pointer", who);
+    if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "refractory layer needs arp", who);
+    if (T < 0 || B < 0) return fail(DCLL_ERR_INVALID, "negative size", who);
+    if (i2o_W && out_p && !out_pv) return fail(DCLL_ERR_INVALID, "the local readout needs out_pv", who);
+    hipStream_t st = (hipStream_t)stream;
+    const long nin = (long)B * d->in_features, nout = (long)B * d->out_features;
+    int rc;
+    if (dcll_dense_seq_fits(d)) {
+        rc = dcll_launch_dense_seq(d, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, out_s, out_pv, out_v, T, B, st);
+        if (rc) return rc;
+    } else {
+        for (int t = 0; t < T; ++t) {
+            hipLaunchKernelGGL(k_trace, dim3(nblk(nin, 256) > 4096 ? 4096 : nblk(nin, 256)), dim3(256), 0, st, x + t * nin, alpha,
+                               tau_m, alphas, tau_s, eps0, eps1, nin, (long)d->in_features, d->tau_is_tensor);
+            HIP_CHECK_LAUNCH("k_trace");
+            rc = dcll_launch_dense_mfma(d, eps1, W, b, arp, out_s ? out_s + t * nout : nullptr,
+                                        out_pv ? out_pv + t * nout : nullptr, out_v ? out_v + t * nout : nullptr, B, st);
+            if (rc) return rc;
+        }
+    }
+    if (i2o_W && out_p) return launch_readout(out_pv, i2o_W, i2o_b, out_p, (long)T * B, d->out_features, d->target, st);
     return DCLL_OK;
 }
 

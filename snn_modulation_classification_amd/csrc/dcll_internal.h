@@ -85,6 +85,16 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
                        const float *tau4, float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
                        float *v_out, bool presigmoid, int32_t T, int32_t B, hipStream_t st);
 
+// dense twins (dcll_dense.hip): one step as an fp32-MFMA GEMM on the updated traces; all T steps with the state on chip
+__attribute__((visibility("hidden")))
+int dcll_launch_dense_mfma(const dcll_dense_desc *d, const float *eps1, const float *W, const float *b, float *arp,
+                           float *out_s, float *out_pv, float *out_v, int32_t B, hipStream_t st);
+__attribute__((visibility("hidden"))) bool dcll_dense_seq_fits(const dcll_dense_desc *d);
+__attribute__((visibility("hidden")))
+int dcll_launch_dense_seq(const dcll_dense_desc *d, const float *x, const float *W, const float *b, const float *alpha,
+                          const float *tau_m, const float *alphas, const float *tau_s, float *eps0, float *eps1, float *arp,
+                          float *out_s, float *out_pv, float *out_v, int32_t T, int32_t B, hipStream_t st);
+
 // k_readout_direct (dcll_readout.hip): LDS-free 16x16x4 readout GEMM in <= 64 VGPRs (fits beside a sequence kernel)
 __attribute__((visibility("hidden")))
 int dcll_launch_readout_direct(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,

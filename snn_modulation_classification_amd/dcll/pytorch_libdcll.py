@@ -664,6 +664,25 @@ class DenseDCLLlayer(nn.Module):
         s, p, pv, v = self.i2h._step(input.reshape(-1, self.in_channels), self.i2o)
         return s, p, pv, v
 
+    def forward_sequence(self, x_seq, want_v=False):
+        """`for t: self.forward(x_seq[t])` in one C-ABI call (dcll_dense_lif_sequence): x_seq (T,B,...) -> (output spikes
+        (T,B,out), pvoutput (T,B,target), pv (T,B,out), pvmem (T,B,out) or None).  Small layers keep their neuron state on
+        chip for all T; the results are bit-identical to T calls of forward()."""
+        i2h = self.i2h
+        T, B = x_seq.shape[0], x_seq.shape[1]
+        x_seq = x_seq.reshape(T, B, self.in_channels)
+        if not i2h.spiking:
+            raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
+        if i2h.state is None or i2h.state.eps0.shape[0] != B:
+            i2h.init_state(B)
+        desc = DenseDesc(i2h.in_channels, i2h.out_channels, self.i2o.weight.shape[0], int(i2h.alpha.numel() > 1),
+                         int(i2h.wrp > 0), float(i2h.alpharp), float(i2h.wrp))
+        st = i2h.state
+        with torch.no_grad():
+            return ops.dense_lif_sequence(desc, x_seq, i2h.weight, i2h.bias, i2h.alpha, i2h.tau_m__dt, i2h.alphas,
+                                          i2h.tau_s__dt, st.eps0, st.eps1, st.arp if len(st) > 2 else None,
+                                          self.i2o.weight, self.i2o.bias, want_v=want_v)
+
     def init_hiddens(self, batch_size, init_value=0):
         self.i2h.init_state(batch_size, init_value=init_value)
         return self

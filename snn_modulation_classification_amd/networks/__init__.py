@@ -66,10 +66,13 @@ class ConvNetwork(torch.nn.Module):
         self._test_graphs, self._test_eager_steps = {}, {}
         # largest pv buffer (one layer, all T steps) the sequence path allocates; bigger batches run in chunks
         self.pv_budget_bytes = float(os.environ.get('DCLL_PV_BUDGET_GB', '24')) * 2 ** 30
-        # sequence path: the layer kernels write v and the readout GEMM applies the sigmoid (dcll_layer_opts
-        # pv_presigmoid + dcll_readout_act) — the transcendentals leave the kernels that share their vector pipe with
-        # the fp32 MFMAs; DCLL_PRESIGMOID=0 keeps pv = sigmoid(v) in the buffer
-        self.presigmoid = os.environ.get('DCLL_PRESIGMOID', '1') != '0'
+        # sequence path: the layer kernels can write v and let the readout GEMM apply the sigmoid (dcll_layer_opts
+        # pv_presigmoid + dcll_readout_act) — the transcendentals then leave the kernels that share their vector pipe with
+        # the fp32 MFMAs.  DCLL_PRESIGMOID: 'auto' (default) = where it was measured to pay — the pooling (1,3) layers of
+        # radio_ml_conv_ref.yaml (first layer 39 -> 33 ms at batch 4096); on the 7x7 layers of radio_ml_conv.yaml it is a
+        # net LOSS (k_lif_seq_c1 5.47 -> 5.05 ms, k_lif_seq_c32d 24.25 -> 24.21 ms per 1024 windows, but the three
+        # readouts 9.7 -> 10.8 ms: DESIGN.md 8) and stays off; '1' / '0' force it on / off everywhere.
+        self.presigmoid = os.environ.get('DCLL_PRESIGMOID', 'auto')
 
     # -- reference protocol (per step) ----------------------------------------------------------------------------
     def learn(self, x, labels):
@@ -531,7 +534,7 @@ class ConvNetwork(torch.nn.Module):
             Wt, bias = L.stacked_readout()
             pv_view = lbuf['pv'].reshape(T * B, -1)
             seq_ro = (not overlap and not fused and not hidden_skip and ops.readout_act_supported(pv_view, Wt))
-            presig = self.presigmoid and seq_ro
+            presig = seq_ro and (self.presigmoid == '1' or (self.presigmoid == 'auto' and L.pooling != (1, 1)))
             if overlap:
                 if i in self._ro_done:
                     hot.wait_event(self._ro_done[i])    # the previous readout of this layer's pv buffer has finished

@@ -203,6 +203,33 @@ def dense_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, 
     return s, p, pv, v
 
 
+def dense_lif_sequence(desc, x_seq, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None,
+                       want_s=True, want_v=False):
+    """All T steps of a DenseDCLLlayer in one call (dcll_dense_lif_sequence): x_seq (T,B,in) fp32 -> (s (T,B,out) or None,
+    p (T,B,target) or None, pv (T,B,out), v (T,B,out) or None); the state tensors are updated in place."""
+    T, B = x_seq.shape[0], x_seq.shape[1]
+    dev = x_seq.device
+    x_seq = _f32(x_seq, "x").contiguous()
+    _expect(x_seq, "x", torch.float32, (T, B, desc.in_features))
+    _expect(W, "W", torch.float32, (desc.out_features, desc.in_features))
+    _expect(eps0, "eps0", torch.float32, (B, desc.in_features))
+    _expect(eps1, "eps1", torch.float32, (B, desc.in_features))
+    _expect(arp, "arp", torch.float32, (B, desc.out_features))
+    n = desc.in_features if desc.tau_is_tensor else 1
+    for k, t in enumerate((alpha, tau_m, alphas, tau_s)):
+        _expect(t, "time constant %d" % k, torch.float32, numel=n)
+    if i2o_W is not None:
+        _expect(i2o_W, "i2o_W", torch.float32, (desc.target, desc.out_features))
+    new = lambda want, last: torch.empty((T, B, last), device=dev, dtype=torch.float32) if want else None
+    s, pv, v = new(want_s, desc.out_features), new(True, desc.out_features), new(want_v, desc.out_features)
+    p = new(i2o_W is not None, desc.target)
+    rc = _lib.get().dcll_dense_lif_sequence(
+        ctypes.byref(desc), ptr(x_seq), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s), ptr(eps0),
+        ptr(eps1), ptr(arp), ptr(i2o_W), ptr(i2o_b), ptr(s), ptr(p), ptr(pv), ptr(v), T, B, stream_ptr())
+    check(rc, "dcll_dense_lif_sequence")
+    return s, p, pv, v
+
+
 def permute_readout(Wt):
     """(N, 8192) readout matrix -> the fused epilogue's layout (dcll_permute_readout)."""
     Wt = Wt.contiguous()

@@ -343,14 +343,15 @@ def test_network_int8_abi_and_presigmoid_do_not_change_the_run(dev, monkeypatch,
     torch.manual_seed(5)
     iq = (0.4 * torch.randn(B, 2, 128)).to(dev)
     enc = IQEncoder(W, H, device=dev)
+    monkeypatch.setenv("DCLL_PRESIGMOID", "1")             # (the default, 'auto', turns it on for the pooling layers only)
     a = _net(yaml_name, im, B, int8)
-    assert a.presigmoid and all((s.dclllayer.i2h.int8_weights() is not None) == int8 for s in a.dcll_slices)
+    assert a.presigmoid == '1' and all((s.dclllayer.i2h.int8_weights() is not None) == int8 for s in a.dcll_slices)
     a.reset()
     ra = a.test_sequence(iq=iq, encoder=enc, T=T, t0=2)
     monkeypatch.setenv("DCLL_INT8_ABI", "0")
     monkeypatch.setenv("DCLL_PRESIGMOID", "0")
     b = _net(yaml_name, im, B, int8)
-    assert not b.presigmoid and all(s.dclllayer.i2h.int8_weights() is None for s in b.dcll_slices)
+    assert b.presigmoid == '0' and all(s.dclllayer.i2h.int8_weights() is None for s in b.dcll_slices)
     b.reset()
     rb = b.test_sequence(iq=iq, encoder=enc, T=T, t0=2)
     torch.cuda.synchronize()
@@ -380,3 +381,85 @@ def test_int8_form_is_dropped_when_the_weight_changes(dev):
     net.dcll_slices[2].dclllayer.load_state_dict(sd)
     assert net.dcll_slices[2].dclllayer.i2h.int8_weights() is None
     assert net.dcll_slices[0].dclllayer.i2h.int8_weights() is not None
+
+
+# (in_features, out_features, B, T, tensor tau, wrp)
+DENSE_CASES = [(40, 24, 5, 4, False, 1.0), (40, 24, 5, 4, True, 0.0), (257, 130, 133, 3, True, 1.0), (1024, 128, 70, 6, True, 1.0),
+               (1000, 96, 33, 5, False, 0.0), (7, 3, 1, 5, True, 1.0), (2050, 64, 40, 3, True, 1.0), (96, 200, 64, 4, False, 1.0)]
+
+
+@pytest.mark.parametrize("cin,cout,B,T,ttau,wrp", DENSE_CASES)
+def test_dense_twins_vs_oracle(dev, cin, cout, B, T, ttau, wrp):
+    """The dense twins (reference dcll/pytorch_libdcll.py:131-148, :171-195, :250-255): dcll_dense_lif_step — the fp32-MFMA
+    GEMM with an unsplit, in-order K loop — and dcll_dense_lif_sequence — all T steps in one call, state on chip when the
+    layer is small (in <= 1024, out <= 128), step by step inside the call otherwise — == the C oracle stepping: v, s, eps0 /
+    eps1 / arp bit for bit, from a non-zero state; (C_in,)-tensor and scalar time constants, refractory or not, odd K, ragged
+    tiles, out above the on-chip limit, in above it."""
+    from snn_modulation_classification_amd import ops
+    from snn_modulation_classification_amd._lib import DenseDesc
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(cin + cout)
+    stdv = 1.0 / np.sqrt(cin)
+    W = (rng.uniform(-stdv * 1e-2, stdv * 1e-2, size=(cout, cin)) * 3.0).astype(np.float32)
+    b = (rng.uniform(-stdv, stdv, size=(cout,)) * 0.02).astype(np.float32)
+    n = cin if ttau else 1
+    taum, taus = rng.uniform(5, 35, size=n) * 1e-3, rng.uniform(5, 10, size=n) * 1e-3
+    alpha, alphas = (1 - 1e-3 / taum).astype(np.float32), (1 - 1e-3 / taus).astype(np.float32)
+    tau_m = (np.float32(1) / (np.float32(1) - alpha)).astype(np.float32)
+    tau_s = (np.float32(1) / (np.float32(1) - alphas)).astype(np.float32)
+    sd = {"i2h.weight": W, "i2h.bias": b, "i2h.alpha": alpha, "i2h.tau_m__dt": tau_m, "i2h.alphas": alphas,
+          "i2h.tau_s__dt": tau_s, "i2o.weight": rng.uniform(-.05, .05, size=(10, cout)).astype(np.float32),
+          "i2o.bias": rng.uniform(-.05, .05, size=(10,)).astype(np.float32)}
+    orc = C.OracleDenseLayer(sd, wrp)
+    x = (rng.uniform(size=(T, B, cin)) < 0.2).astype(np.float32)
+    x[:, :, ::5] *= rng.uniform(0.5, 2.0, size=x[:, :, ::5].shape).astype(np.float32)      # any fp32 input is legal
+    orc.forward(np.zeros((B, cin), np.float32))            # allocates the state
+    init = [rng.uniform(0, 5, size=(B, cin)).astype(np.float32), rng.uniform(0, 50, size=(B, cin)).astype(np.float32),
+            -rng.uniform(0, 2, size=(B, cout)).astype(np.float32)]
+    for s_, i_ in zip(orc.state, init):
+        s_[...] = i_
+    t = {k: cu(v, dev) for k, v in sd.items()}
+    d = DenseDesc(cin, cout, 10, int(ttau), int(wrp > 0), .65, wrp)
+    args = (t["i2h.weight"], t["i2h.bias"], t["i2h.alpha"], t["i2h.tau_m__dt"], t["i2h.alphas"], t["i2h.tau_s__dt"])
+    st_a = [cu(i_.copy(), dev) for i_ in init]             # per-step twin
+    st_b = [cu(i_.copy(), dev) for i_ in init]             # sequence twin
+    s_seq, p_seq, pv_seq, v_seq = ops.dense_lif_sequence(d, cu(x, dev), *args, st_b[0], st_b[1],
+                                                         st_b[2] if wrp > 0 else None, t["i2o.weight"], t["i2o.bias"],
+                                                         want_v=True)
+    nspk = 0
+    for k in range(T):
+        s, p, pv, v = ops.dense_lif_step(d, cu(x[k], dev), *args, st_a[0], st_a[1], st_a[2] if wrp > 0 else None,
+                                         t["i2o.weight"], t["i2o.bias"])
+        os_, op, opv, ov = orc.forward(x[k])
+        assert bits_equal(v.cpu().numpy(), ov), (k, np.abs(v.cpu().numpy() - ov).max())
+        assert np.array_equal(s.cpu().numpy(), os_)
+        assert bits_equal(v_seq[k].cpu().numpy(), ov), (k, np.abs(v_seq[k].cpu().numpy() - ov).max())
+        assert np.array_equal(s_seq[k].cpu().numpy(), os_)
+        np.testing.assert_allclose(pv_seq[k].cpu().numpy(), opv, atol=PV_TOL, rtol=0)
+        np.testing.assert_allclose(p.cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
+        np.testing.assert_allclose(p_seq[k].cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
+        nspk += os_.sum()
+    for j in range(3 if wrp > 0 else 2):
+        assert bits_equal(st_a[j].cpu().numpy(), orc.state[j]), j
+        assert bits_equal(st_b[j].cpu().numpy(), orc.state[j]), j
+    assert 0.01 < nspk / (T * B * cout) < 0.99, "degenerate test"
+
+
+def test_dense_layer_forward_sequence_equals_forward(dev):
+    """DenseDCLLlayer.forward_sequence == T calls of .forward (the reference's protocol, :250-255), bit for bit."""
+    from snn_modulation_classification_amd.dcll.pytorch_libdcll import DenseDCLLlayer
+    T, B = 9, 37
+    x = (torch.rand(T, B, 300, device=dev) < 0.3).float()
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(4)
+        np.random.seed(4)
+        outs.append(DenseDCLLlayer(300, 50, target_size=10, wrp=1.0, random_tau=True).to(dev).init_hiddens(B))
+    a, b = outs
+    sa, pa, pva, va = a.forward_sequence(x, want_v=True)
+    for t in range(T):
+        s, p, pv, v = b.forward(x[t])
+        assert torch.equal(sa[t], s) and torch.equal(va[t], v) and torch.equal(pva[t], pv)
+        np.testing.assert_allclose(pa[t].cpu().numpy(), p.cpu().numpy(), atol=2e-5, rtol=0)
+    for u, w_ in zip(a.i2h.state, b.i2h.state):
+        assert torch.equal(u, w_)
