@@ -88,6 +88,22 @@ typedef struct dcll_dense_desc {
  *                    max-pool(sigmoid(v)) == sigmoid(max-pool(v)) up to the last ulp of the (not bit-pinned) sigmoid.
  *                    Not combined with the fused readout (n_ro > 0).
  */
+/*
+ * Second threshold table of the IQ quantiser (dcll_iq_encode, dcll_conv_lif_sequence_iq; NULL = one table for all samples).
+ * The reference quantises one time sample of the whole batch at a time with torch CPU ops (data/utils.py:60-79); torch's
+ * float `pow` runs full groups of 16 / 32 batch positions through its vector implementation and the remaining positions
+ * (batch size not a multiple of the group, chunk ends of its thread pool) through scalar libm, and the two differ in the
+ * last ulp at some cell boundaries — so which cell a boundary value lands in depends on the sample's POSITION in the batch.
+ * thr_*_tail are the thresholds of the scalar path, tail_mask[b] != 0 marks the samples the reference would have sent
+ * through it (the host derives all three from torch itself, data/utils.py IQEncoder): device cells == reference cells for
+ * every batch size.
+ */
+typedef struct dcll_iq_tail {
+    const float *thr_i_tail;    /* (w-1) */
+    const float *thr_q_tail;    /* (h-1) */
+    const uint8_t *tail_mask;   /* (B)   */
+} dcll_iq_tail;
+
 typedef struct dcll_layer_opts {
     const int8_t *w_q8;         /* int8 conv weights (c_out,c_in,kh,kw), or NULL: the call's fp32 W is used */
     const float *w_scale;       /* (c_out) fp32, required with w_q8                                          */
@@ -255,7 +271,7 @@ int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32_t *cells, 
  * h-1 floats).  T <= 4096.
  */
 int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
-                              int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
+                              const dcll_iq_tail *tail, int32_t L, int32_t t0, const float *W, const float *b, const float *tau4,
                               float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
                               float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
                               const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream);
@@ -334,7 +350,7 @@ int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t
  * the host encoder so that the result is bit-identical to it.
  *   iq (B,2,L) fp32 ; cells (T,B) int32 = q*w + i for samples t0..t0+T-1
  */
-int dcll_iq_encode(const float *iq, const float *thr_i, const float *thr_q, int32_t *cells,
+int dcll_iq_encode(const float *iq, const float *thr_i, const float *thr_q, const dcll_iq_tail *tail, int32_t *cells,
                    int32_t B, int32_t L, int32_t t0, int32_t T, int32_t w, int32_t h, void *stream);
 
 /* Unpack (T*B, C, HW/32) packed spikes to fp32 (T*B, C, HW) and back — glue for the tensor-level API. */

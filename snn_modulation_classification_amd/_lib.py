@@ -52,6 +52,11 @@ class LayerOpts(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class IQTail(ctypes.Structure):
+    """dcll_iq_tail: thresholds of torch's scalar pow path + the batch positions that take it"""
+    _fields_ = [("thr_i_tail", ctypes.c_void_p), ("thr_q_tail", ctypes.c_void_p), ("tail_mask", ctypes.c_void_p)]
+
+
 ACT_NONE, ACT_SIGMOID = 0, 1
 ADAM_MAX_TENSORS = 8
 LOSS_SMOOTH_L1, LOSS_MSE = 0, 1
@@ -79,7 +84,7 @@ SIGNATURES = {
     "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _P, _P, _I32, _OP, _I32, _I32, _P]),
     "dcll_permute_readout": (_I32, [_P, _P, _I32, _P]),
     "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_P, _P, _I32, _OP, _I32, _I32, _P]),
-    "dcll_conv_lif_sequence_iq": (_I32, [_DP, _P, _P, _P, _I32, _I32] + [_P] * 9 + [_P, _P, _I32, _OP, _I32, _I32, _P]),
+    "dcll_conv_lif_sequence_iq": (_I32, [_DP, _P, _P, _P, _P, _I32, _I32] + [_P] * 9 + [_P, _P, _I32, _OP, _I32, _I32, _P]),
     "dcll_pv_lowhigh": (_I32, [_P, _I64, _I32, _I32, _P, _P]),
     "dcll_pv_lowhigh_act": (_I32, [_P, _I64, _I32, _I32, _P, _I32, _P]),
     "dcll_readout_act_scratch": (_I64, [_I64, _I32, _I32]),
@@ -90,7 +95,7 @@ SIGNATURES = {
     "dcll_readout_splitk_scratch": (_I64, [_I64, _I32, _I32]),
     "dcll_readout_splitk": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "dcll_argmax_vote": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "dcll_iq_encode": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "dcll_iq_encode": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "dcll_unpack_spikes": (_I32, [_P, _P, _I64, _P]),
     "dcll_pack_spikes": (_I32, [_P, _P, _I64, _P]),
 }

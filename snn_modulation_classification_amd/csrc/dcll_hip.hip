@@ -996,7 +996,7 @@ __global__ __launch_bounds__(64) void k_vote(const int32_t *__restrict__ clout, 
 // glue: IQ -> cell index, pack / unpack
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_iq_encode(const float *__restrict__ iq, const float *__restrict__ thr_i,
-                            const float *__restrict__ thr_q, int32_t *__restrict__ cells, int B, int L, int t0, int T,
+                            const float *__restrict__ thr_q, const dcll_iq_tail tail, int32_t *__restrict__ cells, int B, int L, int t0, int T,
                             int w, int h)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1005,8 +1005,10 @@ __global__ void k_iq_encode(const float *__restrict__ iq, const float *__restric
     float vi = iq[((long)b * 2 + 0) * L + t0 + t];
     float vq = iq[((long)b * 2 + 1) * L + t0 + t];
     int ci = 0, cq = 0;
-    for (int j = 0; j < w - 1; ++j) ci += vi >= thr_i[j];
-    for (int j = 0; j < h - 1; ++j) cq += vq >= thr_q[j];
+    const float *ti, *tq;
+    iq_tables(thr_i, thr_q, tail, b, ti, tq);
+    for (int j = 0; j < w - 1; ++j) ci += vi >= ti[j];
+    for (int j = 0; j < h - 1; ++j) cq += vq >= tq[j];
     cells[i] = cq * w + ci;
 }
 
@@ -1056,7 +1058,7 @@ constexpr int C1_MAXT = 4096;       // longest window the fused IQ encoder of k_
 template <bool REFRACTORY, int FAST, bool IQ>
 __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t *__restrict__ cells,
                                                     const float *__restrict__ iq, const float *__restrict__ thr_i,
-                                                    const float *__restrict__ thr_q, int L, int t0,
+                                                    const float *__restrict__ thr_q, const dcll_iq_tail tail, int L, int t0,
                                                     const dcll_wsrc W, const float *__restrict__ bias,
                                                     const float *__restrict__ tau4, float *__restrict__ eps0_g,
                                                     float *__restrict__ eps1_g, float *__restrict__ arp_g,
@@ -1073,10 +1075,12 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
     const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];
     for (int i = pix; i < 22 * PS + 8; i += 256) plane[i] = 0.0f;
     if (IQ) {
+        const float *ti, *tq;
+        iq_tables(thr_i, thr_q, tail, b, ti, tq);
         for (int t = pix; t < T; t += 256) {
             const float vi = iq[((long)b * 2 + 0) * L + t0 + t], vq = iq[((long)b * 2 + 1) * L + t0 + t];
             int ci = 0, cq = 0;
-            for (int k = 0; k < 15; ++k) { ci += vi >= thr_i[k]; cq += vq >= thr_q[k]; }
+            for (int k = 0; k < 15; ++k) { ci += vi >= ti[k]; cq += vq >= tq[k]; }
             scell[t] = cq * 16 + ci;
         }
     }
@@ -3117,32 +3121,32 @@ extern "C" int dcll_conv_lif_sequence(const dcll_conv_desc *d, const uint32_t *s
 }
 
 static int launch_c1(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
-                     const float *thr_q, int L, int t0, dcll_wsrc W, const float *b, const float *tau4, float *eps0,
+                     const float *thr_q, dcll_iq_tail tail, int L, int t0, dcll_wsrc W, const float *b, const float *tau4, float *eps0,
                      float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out, float *state_scratch,
                      uint64_t *pv_lowhigh, int iter0, bool presig, int T, int B, hipStream_t st)
 {
     const char *who = "dcll_conv_lif_sequence_cells/_iq";
     const long per_step = (long)B * d->c_out * d->h * d->w;
     if (pv_lowhigh) {       // statistics pass over the sampled steps' pv planes after the layer kernel
-        int rc = launch_c1(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
+        int rc = launch_c1(d, cells, iq, thr_i, thr_q, tail, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
                            state_scratch, nullptr, 0, presig, T, B, st);
         if (rc) return rc;
         return launch_pv_lowhigh(pv_out, per_step, T, iter0, (unsigned long long *)pv_lowhigh, st, who, presig);
     }
     // both the presigmoid pv_out and v_out wanted (tests): v_out is written, pv_out is a copy of it
     if (presig && pv_out && v_out) {
-        int rc = launch_c1(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, nullptr, v_out,
+        int rc = launch_c1(d, cells, iq, thr_i, thr_q, tail, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, nullptr, v_out,
                            state_scratch, nullptr, 0, false, T, B, st);
         if (rc) return rc;
         return presig_copy(seq_outs{nullptr, v_out, pv_out}, per_step * T, st, who);
     }
     if (d->h != 16 || d->w != 16)       // large plane: k_lif_seq_c1t, one workgroup per (sample, 8 x 32 tile)
-        return dcll_launch_seq_c1t(d, cells, iq, thr_i, thr_q, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
+        return dcll_launch_seq_c1t(d, cells, iq, thr_i, thr_q, tail, L, t0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
                                    state_scratch, T, B, st, presig);
     const bool fastpath = d->c_out == 32 && spk_out && pv_out && !v_out;
     if (presig && !fastpath) { v_out = pv_out; pv_out = nullptr; }
 #define DCLL_LAUNCH_C1(R, F, Q)                                                                                         \
-    hipLaunchKernelGGL((k_lif_seq_c1<R, F, Q>), dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, L, t0, W,  \
+    hipLaunchKernelGGL((k_lif_seq_c1<R, F, Q>), dim3(B), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q, tail, L, t0, W,  \
                        b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->alpharp, d->wrp)
 #define DCLL_LAUNCH_C1Q(R, F)                                                                                           \
     do { if (iq) DCLL_LAUNCH_C1(R, F, true); else DCLL_LAUNCH_C1(R, F, false); } while (0)
@@ -3189,12 +3193,12 @@ extern "C" int dcll_conv_lif_sequence_cells(const dcll_conv_desc *d, const int32
         return launch_pv_lowhigh(pv_out, (long)B * d->c_out * d->h * (d->w / 2), T, iter0, (unsigned long long *)pv_lowhigh,
                                  (hipStream_t)stream, who, presig);
     }
-    return launch_c1(d, cells, nullptr, nullptr, nullptr, 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
+    return launch_c1(d, cells, nullptr, nullptr, nullptr, make_iq_tail(nullptr), 0, 0, W, b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out,
                      state_scratch, pv_lowhigh, iter0, presig, T, B, (hipStream_t)stream);
 }
 
 extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *iq, const float *thr_i, const float *thr_q,
-                                         int32_t L, int32_t t0, const float *Wf, const float *b, const float *tau4,
+                                         const dcll_iq_tail *tail, int32_t L, int32_t t0, const float *Wf, const float *b, const float *tau4,
                                          float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out,
                                          float *v_out, float *state_scratch, uint64_t *pv_lowhigh, int32_t iter0,
                                          const dcll_layer_opts *opts, int32_t T, int32_t B, void *stream)
@@ -3206,10 +3210,11 @@ extern "C" int dcll_conv_lif_sequence_iq(const dcll_conv_desc *d, const float *i
     rc = check_opts(Wf, opts, true, who);
     if (rc) return rc;
     if (!iq || !thr_i || !thr_q || !b || !tau4 || !eps0 || !eps1) return fail(DCLL_ERR_INVALID, "null pointer", who);
+    if (tail && tail->tail_mask && (!tail->thr_i_tail || !tail->thr_q_tail)) return fail(DCLL_ERR_INVALID, "tail mask without tail tables", who);
     if (d->refractory && !arp) return fail(DCLL_ERR_INVALID, "refractory layer needs arp", who);
     if (T < 0 || B < 0 || t0 < 0 || t0 + T > L) return fail(DCLL_ERR_INVALID, "window [t0, t0+T) outside the IQ row", who);
     if (T > C1_MAXT) return fail(DCLL_ERR_UNSUPPORTED, "at most 4096 timesteps per launch", who);
-    return launch_c1(d, nullptr, iq, thr_i, thr_q, L, t0, make_wsrc(Wf, opts), b, tau4, eps0, eps1, arp, spk_out, pv_out,
+    return launch_c1(d, nullptr, iq, thr_i, thr_q, make_iq_tail(tail), L, t0, make_wsrc(Wf, opts), b, tau4, eps0, eps1, arp, spk_out, pv_out,
                      v_out, state_scratch, pv_lowhigh, iter0, opts && opts->pv_presigmoid, T, B, (hipStream_t)stream);
 }
 
@@ -3231,14 +3236,17 @@ extern "C" int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vo
     return DCLL_OK;
 }
 
-extern "C" int dcll_iq_encode(const float *iq, const float *thr_i, const float *thr_q, int32_t *cells, int32_t B,
+extern "C" int dcll_iq_encode(const float *iq, const float *thr_i, const float *thr_q, const dcll_iq_tail *tail,
+                              int32_t *cells, int32_t B,
                               int32_t L, int32_t t0, int32_t T, int32_t w, int32_t h, void *stream)
 {
     if (!iq || !thr_i || !thr_q || !cells || B < 0 || T < 0 || t0 < 0 || t0 + T > L || w < 1 || h < 1)
         return fail(DCLL_ERR_INVALID, "dcll_iq_encode: bad argument");
+    if (tail && tail->tail_mask && (!tail->thr_i_tail || !tail->thr_q_tail))
+        return fail(DCLL_ERR_INVALID, "dcll_iq_encode: tail mask without tail tables");
     if (T == 0 || B == 0) return DCLL_OK;
     hipLaunchKernelGGL(k_iq_encode, dim3(nblk((long)T * B, 256)), dim3(256), 0, (hipStream_t)stream, iq, thr_i, thr_q,
-                       cells, B, L, t0, T, w, h);
+                       make_iq_tail(tail), cells, B, L, t0, T, w, h);
     HIP_CHECK_LAUNCH("k_iq_encode");
     return DCLL_OK;
 }

@@ -46,6 +46,16 @@ static inline int fail(int code, const char *msg, const char *who = nullptr)
 // at(idx, co) is the ONE place a weight is converted: (float)q * scale[co], a single rounded multiply — bit for bit what
 // the dequantised fp32 tensor holds, so every chain downstream is unchanged.  The branch is wave-uniform.
 // ------------------------------------------------------------------------------------------------------------
+// thresholds of sample b of the IQ quantiser: the scalar-path table for the samples the mask marks (dcll_iq_tail)
+__device__ __forceinline__ void iq_tables(const float *thr_i, const float *thr_q, const dcll_iq_tail &tail, long b,
+                                          const float *&ti, const float *&tq)
+{
+    const bool tl = tail.tail_mask && tail.tail_mask[b];
+    ti = tl ? tail.thr_i_tail : thr_i;
+    tq = tl ? tail.thr_q_tail : thr_q;
+}
+static inline dcll_iq_tail make_iq_tail(const dcll_iq_tail *t) { return t ? *t : dcll_iq_tail{nullptr, nullptr, nullptr}; }
+
 struct dcll_wsrc {
     const float *f;
     const int8_t *q;
@@ -74,7 +84,7 @@ int dcll_launch_seq_c32t(const dcll_conv_desc *d, const uint32_t *spk_in, dcll_w
 // k_lif_seq_c1t: the first layer (c_in 1) on such planes, input as cell indices or raw IQ
 __attribute__((visibility("hidden")))
 int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
-                        const float *thr_q, int L, int t0, dcll_wsrc W, const float *b, const float *tau4,
+                        const float *thr_q, dcll_iq_tail tail, int L, int t0, dcll_wsrc W, const float *b, const float *tau4,
                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
                         float *state_scratch, int T, int B, hipStream_t st, bool presig = false);
 

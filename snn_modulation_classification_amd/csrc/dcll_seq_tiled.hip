@@ -357,7 +357,7 @@ constexpr int C1T_REGION = 14 * TRW;        // 532
 template <bool REFRACTORY, int FAST = 0>
 __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *__restrict__ cells,
                                                       const float *__restrict__ iq, const float *__restrict__ thr_i,
-                                                      const float *__restrict__ thr_q, int L, int t0,
+                                                      const float *__restrict__ thr_q, const dcll_iq_tail tail, int L, int t0,
                                                       const dcll_wsrc W, const float *__restrict__ bias,
                                                       const float *__restrict__ tau4, const float *__restrict__ eps0_in,
                                                       const float *__restrict__ eps1_in, float *__restrict__ eps0_g,
@@ -382,11 +382,13 @@ __global__ __launch_bounds__(256) void k_lif_seq_c1t(int c_out, const int32_t *_
     for (int i = tid; i < C1T_REGION + 8; i += 256) plane[i] = 0.0f;
     if (iq) {
         // quantisation of iq2spiketrain (data/utils.py:60-82) in threshold form, as k_iq_encode: cell = row * W + col
+        const float *ti, *tq;
+        iq_tables(thr_i, thr_q, tail, b, ti, tq);
         for (int t = tid; t < T; t += 256) {
             const float vi = iq[(b * 2 + 0) * L + t0 + t], vq = iq[(b * 2 + 1) * L + t0 + t];
             int ci = 0, cq = 0;
-            for (int k = 0; k < Wd - 1; ++k) ci += vi >= thr_i[k];
-            for (int k = 0; k < H - 1; ++k) cq += vq >= thr_q[k];
+            for (int k = 0; k < Wd - 1; ++k) ci += vi >= ti[k];
+            for (int k = 0; k < H - 1; ++k) cq += vq >= tq[k];
             scell[t] = cq * Wd + ci;
         }
     }
@@ -511,7 +513,7 @@ static int snapshot_state(const float *eps0, const float *eps1, float *scratch, 
 }
 
 int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const float *iq, const float *thr_i,
-                        const float *thr_q, int L, int t0, dcll_wsrc W, const float *b, const float *tau4,
+                        const float *thr_q, dcll_iq_tail tail, int L, int t0, dcll_wsrc W, const float *b, const float *tau4,
                         float *eps0, float *eps1, float *arp, uint32_t *spk_out, float *pv_out, float *v_out,
                         float *state_scratch, int T, int B, hipStream_t st, bool presig)
 {
@@ -526,7 +528,7 @@ int dcll_launch_seq_c1t(const dcll_conv_desc *d, const int32_t *cells, const flo
     if (presig && !fastpath) { v_out = pv_out; pv_out = nullptr; }        // (the caller made sure only one of them is wanted)
 #define DCLL_LAUNCH_C1T(R, F)                                                                                           \
     hipLaunchKernelGGL((k_lif_seq_c1t<R, F>), dim3((unsigned)nwg), dim3(256), 0, st, d->c_out, cells, iq, thr_i, thr_q,  \
-                       L, t0, W, b, tau4, eps0_in, eps1_in, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,         \
+                       tail, L, t0, W, b, tau4, eps0_in, eps1_in, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, d->h, d->w,         \
                        d->alpharp, d->wrp)
     if (d->refractory) {
         if (fastpath && presig) DCLL_LAUNCH_C1T(true, 2);

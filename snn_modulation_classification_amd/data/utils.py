@@ -5,7 +5,9 @@
   iq2spiketrain      reference data/utils.py:43-87  (one spike per I/Q sample in the I/Q plane)
   iq2cells           same quantisation, returning the cell index q*W + i per (t, b) instead of a dense plane
   IQEncoder          the same map on the MI355X (dcll_iq_encode): thresholds found on the host by bisection over the
-                     host encoder, so device cells are bit-identical to the host's
+                     host encoder — one table per code path of torch's float pow (vector groups / scalar tail) plus the
+                     batch positions that take the scalar one — so device cells are bit-identical to the host's for
+                     every batch size
 """
 import numpy as np
 import torch
@@ -99,16 +101,23 @@ def _ordered_to_f32(k):
     return u.view(np.float32)
 
 
-def cell_thresholds(lo, hi, n_cells, do_gamma=True, window=2048):
+def cell_thresholds(lo, hi, n_cells, do_gamma=True, window=2048, path='vector'):
     """thr[j] = smallest float32 x with quantise(x) >= j+1, j = 0..n_cells-2, by bisection over the float32 line.
 
-    The host map is evaluated through torch's VECTOR path (the candidate replicated to 64 lanes: torch's float loops
-    run 2 x Vec::size() = 16 (AVX2) or 32 (AVX-512) elements per vector iteration and hand the tail to scalar libm),
-    which is what every sample of a batch whose size is a multiple of 32 goes through in the reference.  `pow` need not be
-    monotone to the last ulp, so every threshold is verified on `window` consecutive floats on either side and a
-    ValueError is raised if the map is not a clean step there (never observed)."""
+    path='vector': the host map is evaluated through torch's VECTOR path (the candidates padded to a multiple of 64
+    lanes: torch's float loops run 2 x Vec::size() = 16 (AVX2) or 32 (AVX-512) elements per vector iteration and hand
+    the tail to scalar libm), which is what the samples in full groups of a batch go through in the reference.
+    path='scalar': through the scalar tail (tensors of 15 elements — shorter than any vector iteration), which is what the
+    last B mod 16 / 32 samples of a batch (and the samples at the chunk ends of torch's thread pool) go through.  The two
+    differ in the last ulp at some cell boundaries (on an AVX-512 host: 4 of the 15 boundaries of a 16-cell axis).
+    `pow` need not be monotone to the last ulp, so every threshold is verified on `window` consecutive floats on either
+    side and a ValueError is raised if the map is not a clean step there (never observed)."""
     def f(vals):
         vals = np.asarray(vals, dtype=np.float32)
+        if path == 'scalar':
+            out = [_quantise(torch.from_numpy(vals[k:k + 15].copy()), lo, hi, n_cells, do_gamma).numpy()
+                   for k in range(0, len(vals), 15)]
+            return np.concatenate(out)
         pad = (-len(vals)) % 64
         full = np.concatenate([vals, np.repeat(vals[-1:], pad)]) if pad else vals
         return _quantise(torch.from_numpy(full), lo, hi, n_cells, do_gamma).numpy()[:len(vals)]
@@ -119,7 +128,7 @@ def cell_thresholds(lo, hi, n_cells, do_gamma=True, window=2048):
         a, b = lo_k, hi_k               # f(a) < j+1 <= f(b)
         while b - a > 1:
             mid = (a + b) // 2
-            if f(_ordered_to_f32([mid] * 64))[0] >= j + 1:
+            if f(_ordered_to_f32([mid] * (1 if path == 'scalar' else 64)))[0] >= j + 1:
                 b = mid
             else:
                 a = mid
@@ -132,17 +141,67 @@ def cell_thresholds(lo, hi, n_cells, do_gamma=True, window=2048):
 
 
 class IQEncoder:
-    """iq2spiketrain's quantisation on the GPU: raw IQ (B,2,L) fp32 in HBM -> cells (T,B) int32."""
+    """iq2spiketrain's quantisation on the GPU: raw IQ (B,2,L) fp32 in HBM -> cells (T,B) int32.
 
-    def __init__(self, out_w, out_h, I_bounds=(-1, 1), Q_bounds=(-1, 1), do_gamma=True, device='cuda'):
-        self.w, self.h = out_w, out_h
-        self.thr_i = torch.from_numpy(cell_thresholds(I_bounds[0], I_bounds[1], out_w, do_gamma)).to(device)
-        self.thr_q = torch.from_numpy(cell_thresholds(Q_bounds[0], Q_bounds[1], out_h, do_gamma)).to(device)
+    Exact for every batch size: the reference quantises a length-B vector per time sample with torch CPU ops, and which
+    implementation of `pow` an element meets — vector or scalar — depends on its position in that vector.  The encoder
+    holds the thresholds of both paths and asks torch itself which positions of a B-vector take the scalar one (a witness
+    value on which the two paths disagree, pushed through the host quantiser once per batch size): `tail(B)` is what the
+    kernels get as dcll_iq_tail.  `exact_tail=False` keeps the single vector-path table (exact for batches that are
+    multiples of 32)."""
 
-    def __call__(self, iq, max_duration, t0=None):
+    def __init__(self, out_w, out_h, I_bounds=(-1, 1), Q_bounds=(-1, 1), do_gamma=True, device='cuda', exact_tail=True):
+        self.w, self.h, self.device = out_w, out_h, device
+        self._bounds, self._gamma = (tuple(I_bounds), tuple(Q_bounds)), do_gamma
+        ti = cell_thresholds(I_bounds[0], I_bounds[1], out_w, do_gamma)
+        tq = cell_thresholds(Q_bounds[0], Q_bounds[1], out_h, do_gamma)
+        self.thr_i, self.thr_q = torch.from_numpy(ti).to(device), torch.from_numpy(tq).to(device)
+        self.thr_i_tail = self.thr_q_tail = None
+        self._witness, self._masks = None, {}
+        if exact_tail:
+            si = cell_thresholds(I_bounds[0], I_bounds[1], out_w, do_gamma, path='scalar')
+            sq = cell_thresholds(Q_bounds[0], Q_bounds[1], out_h, do_gamma, path='scalar')
+            for axis, (v_, s_) in enumerate(((ti, si), (tq, sq))):
+                d = np.nonzero(v_ != s_)[0]
+                if len(d) and self._witness is None:
+                    # at min(thr) the path with the lower threshold already says cell j + 1, the other still j
+                    j = int(d[0])
+                    x = min(v_[j], s_[j])
+                    self._witness = (axis, float(x), int(j + 1) if s_[j] < v_[j] else int(j), n_cells_of(axis, out_w, out_h))
+            if self._witness is not None:       # (else: the two paths agree on this host — one table serves all)
+                self.thr_i_tail, self.thr_q_tail = torch.from_numpy(si).to(device), torch.from_numpy(sq).to(device)
+
+    def tail_mask_host(self, B):
+        """uint8 (B): 1 where torch's quantiser sends position b of a length-B vector through its scalar pow path."""
+        m = self._masks.get(B)
+        if m is None:
+            axis, x, scalar_cell, n_cells = self._witness
+            lo, hi = self._bounds[axis]
+            got = _quantise(torch.full((B,), x, dtype=torch.float32), lo, hi, n_cells, self._gamma).numpy()
+            m = self._masks[B] = (got == scalar_cell).astype(np.uint8)
+        return m
+
+    def tail(self, B, start=0, stop=None, total=None):
+        """dcll_iq_tail operands (thr_i_tail, thr_q_tail, mask) for samples start..stop of a batch of `total` (default: the
+        B samples are the whole batch), or None when one table serves all."""
+        if self._witness is None:
+            return None
+        total = B if total is None else total
+        stop = start + B if stop is None else stop
+        mask = self.tail_mask_host(total)[start:stop]
+        if not mask.any():
+            return None
+        return self.thr_i_tail, self.thr_q_tail, torch.from_numpy(np.ascontiguousarray(mask)).to(self.device)
+
+    def __call__(self, iq, max_duration, t0=None, start=0, total=None):
         from .. import ops
         iq = iq.reshape(iq.shape[0], 2, -1).contiguous()
         L = iq.shape[-1]
         if t0 is None:
             t0 = np.random.randint(0, L - max_duration + 1)       # same draw as the host encoder
-        return ops.iq_encode(iq, self.thr_i, self.thr_q, t0, max_duration, self.w, self.h)
+        return ops.iq_encode(iq, self.thr_i, self.thr_q, t0, max_duration, self.w, self.h,
+                             tail=self.tail(iq.shape[0], start=start, total=total))
+
+
+def n_cells_of(axis, out_w, out_h):
+    return out_w if axis == 0 else out_h

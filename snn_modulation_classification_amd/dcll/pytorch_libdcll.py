@@ -522,12 +522,13 @@ class Conv2dDCLLlayer(nn.Module):
                                                          T, B, want_spikes=want_spikes, want_pv=want_pv, out=buffers,
                                                          lowhigh_iter0=lowhigh_iter0, q8=q8, presigmoid=presigmoid)
                 return spk, pv, None
-            if kind == 'iq':        # inp = (iq (B,2,L), thr_i, thr_q, t0): encoder fused into the layer kernel
-                iq, thr_i, thr_q, t0 = inp
+            if kind == 'iq':        # inp = (iq (B,2,L), thr_i, thr_q, t0[, tail]): encoder fused into the layer kernel
+                iq, thr_i, thr_q, t0 = inp[:4]
+                tail = inp[4] if len(inp) > 4 else None
                 spk, pv, _ = ops.conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, i2h.weight, i2h.bias, tau4, st.eps0,
                                                       st.eps1, arp, T, B, want_spikes=want_spikes, want_pv=want_pv,
                                                       out=buffers, lowhigh_iter0=lowhigh_iter0, q8=q8,
-                                                      presigmoid=presigmoid)
+                                                      presigmoid=presigmoid, tail=tail)
                 return spk, pv, None
             if fuse_readout:
                 Wp, rb = self.fused_readout_weights()

@@ -461,7 +461,8 @@ class ConvNetwork(torch.nn.Module):
             for b0 in range(0, B, chunk):
                 b1 = min(B, b0 + chunk)
                 parts.append(self._sequence_chunk(
-                    (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None
+                    (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0), encoder.tail(b1 - b0, b0, b1, B))
+                    if iq is not None
                     else cells[:, b0:b1].contiguous(),
                     'iq' if iq is not None else 'cells', T, b1 - b0, dev, profile, fuse_readout, batch_slice=b0,
                     output_only=output_only, overlap=overlap_readout, keep_spikes=keep_spikes))
@@ -475,7 +476,8 @@ class ConvNetwork(torch.nn.Module):
             if keep_spikes:
                 res['spikes'] = cat('spikes', 1)
         else:
-            res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0)) if iq is not None else cells,
+            res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0), encoder.tail(B))
+                                       if iq is not None else cells,
                                        'iq' if iq is not None else 'cells', T, B, dev, profile, fuse_readout,
                                        output_only=output_only, overlap=overlap_readout, keep_spikes=keep_spikes)
         if collect:

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SIGMOID, ConvDesc, DenseDesc, LayerOpts, check, ptr, stream_ptr
+from ._lib import ACT_NONE, ACT_SIGMOID, ConvDesc, DenseDesc, IQTail, LayerOpts, check, ptr, stream_ptr
 
 
 def _pair(v):
@@ -348,8 +348,23 @@ def conv_lif_sequence_cells(desc, cells, W, b, tau4, eps0, eps1, arp, T, B, want
     return spk, pv, v
 
 
+def iq_tail(tail, w, h, B):
+    """dcll_iq_tail of a call as a ctypes reference (None = one threshold table).  tail = (thr_i_tail (w-1), thr_q_tail
+    (h-1), mask (B) uint8 on the device): the samples the mask marks are quantised with the scalar-path thresholds
+    (include/dcll_hip.h; data/utils.py IQEncoder).  The caller keeps the tensors alive."""
+    if tail is None:
+        return None
+    ti, tq, mask = tail
+    _expect(ti, "thr_i_tail", torch.float32, (w - 1,))
+    _expect(tq, "thr_q_tail", torch.float32, (h - 1,))
+    _expect(mask, "tail_mask", torch.uint8, (B,))
+    t = IQTail()
+    t.thr_i_tail, t.thr_q_tail, t.tail_mask = ptr(ti).value, ptr(tq).value, ptr(mask).value
+    return ctypes.byref(t)
+
+
 def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp, T, B, want_spikes=True,
-                         want_pv=True, want_v=False, out=None, lowhigh_iter0=None, q8=None, presigmoid=False):
+                         want_pv=True, want_v=False, out=None, lowhigh_iter0=None, q8=None, presigmoid=False, tail=None):
     """First layer from the raw IQ window (B,2,L): iq2spiketrain's quantisation fused into k_lif_seq_c1."""
     dev = b.device
     out = {} if out is None else out
@@ -368,7 +383,8 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
         pv = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32)
     v = torch.empty((T, B, desc.c_out, desc.h, desc.w), device=dev, dtype=torch.float32) if want_v else None
     scratch, counts, iter0 = _seq_extras(desc, B, T, dev, out, lowhigh_iter0)
-    rc = _lib.get().dcll_conv_lif_sequence_iq(ctypes.byref(desc), ptr(iq), ptr(thr_i), ptr(thr_q), L, t0, ptr(W), ptr(b),
+    rc = _lib.get().dcll_conv_lif_sequence_iq(ctypes.byref(desc), ptr(iq), ptr(thr_i), ptr(thr_q),
+                                              iq_tail(tail, desc.w, desc.h, B), L, t0, ptr(W), ptr(b),
                                               ptr(tau4), ptr(eps0), ptr(eps1), ptr(arp), ptr(spk), ptr(pv), ptr(v),
                                               ptr(scratch), ptr(counts), iter0, layer_opts(desc, q8, presigmoid), T, B,
                                               stream_ptr())
@@ -473,16 +489,16 @@ def argmax(logits):
     return out
 
 
-def iq_encode(iq, thr_i, thr_q, t0, T, w, h):
-    """iq (B,2,L) fp32 -> cells (T,B) int32 = q*w + i."""
+def iq_encode(iq, thr_i, thr_q, t0, T, w, h, tail=None):
+    """iq (B,2,L) fp32 -> cells (T,B) int32 = q*w + i.  tail: see iq_tail."""
     B, two, L = iq.shape
     assert two == 2
     _expect(iq, "iq", torch.float32)
     _expect(thr_i, "thr_i", torch.float32, (w - 1,))
     _expect(thr_q, "thr_q", torch.float32, (h - 1,))
     cells = torch.empty((T, B), device=iq.device, dtype=torch.int32)
-    check(_lib.get().dcll_iq_encode(ptr(iq), ptr(thr_i), ptr(thr_q), ptr(cells), B, L, t0, T, w, h, stream_ptr()),
-          "dcll_iq_encode")
+    check(_lib.get().dcll_iq_encode(ptr(iq), ptr(thr_i), ptr(thr_q), iq_tail(tail, w, h, B), ptr(cells), B, L, t0, T, w, h,
+                                    stream_ptr()), "dcll_iq_encode")
     return cells
 
 

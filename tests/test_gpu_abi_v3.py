@@ -463,3 +463,51 @@ def test_dense_layer_forward_sequence_equals_forward(dev):
         np.testing.assert_allclose(pa[t].cpu().numpy(), p.cpu().numpy(), atol=2e-5, rtol=0)
     for u, w_ in zip(a.i2h.state, b.i2h.state):
         assert torch.equal(u, w_)
+
+
+@pytest.mark.parametrize("B,R_", [(37, 16), (4099, 16), (45, 32)])
+def test_device_iq_encoder_is_exact_for_ragged_batches(dev, B, R_):
+    """Device cells == host iq2cells (= the reference's per-time-sample torch quantiser, data/utils.py:60-79) for batch
+    sizes that are NOT multiples of 32, on inputs placed on every cell boundary and one ulp either side: torch's float pow
+    sends the last B mod 32 (16 on AVX2) positions of a batch vector through scalar libm, whose boundaries differ from the
+    vector path's in the last ulp; the kernels get both threshold tables and the positions (dcll_iq_tail).  Checked for the
+    stand-alone encoder kernel and for the quantiser fused into the first layer's sequence kernel (16x16: k_lif_seq_c1,
+    32x32: k_lif_seq_c1t), whole and chunked batches."""
+    from test_host_logic import _boundary_iq
+    from snn_modulation_classification_amd import ops
+    from snn_modulation_classification_amd.data.utils import IQEncoder, iq2cells
+    enc = IQEncoder(R_, R_, device=dev)
+    tabs = [enc.thr_i.cpu().numpy(), enc.thr_q.cpu().numpy()]
+    if enc.thr_i_tail is not None:
+        tabs += [enc.thr_i_tail.cpu().numpy(), enc.thr_q_tail.cpu().numpy()]
+    L, T = 40, 33
+    iq = _boundary_iq(B, L, tabs, seed=B + R_)
+    np.random.seed(3)
+    want, t0 = iq2cells(torch.from_numpy(iq), R_, R_, max_duration=T)
+    got = enc(cu(iq, dev), T, t0=t0)
+    assert torch.equal(got.cpu(), want), np.argwhere(got.cpu().numpy() != want.numpy())[:5]
+    if enc.thr_i_tail is not None:       # not vacuous: the single-table encoder misplaces boundary samples of the tail
+        plain = ops.iq_encode(cu(iq, dev), enc.thr_i, enc.thr_q, t0, T, R_, R_)
+        assert not torch.equal(plain.cpu(), want)
+    # fused into the first layer's kernel == the cells path on the host's cells, whole batch and chunks of 16
+    d = ops.make_conv_desc(1, 32, (R_, R_), 7, 3, 1, 24, False, True, 1.0)
+    rng = np.random.RandomState(1)
+    W, b, alpha, tau_m, alphas, tau_s = _rand_layer(rng, 1, 32, gain=3.0)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+
+    def state(n):
+        return [torch.zeros((n, 1, R_, R_), device=dev), torch.zeros((n, 1, R_, R_), device=dev),
+                torch.zeros((n, 32, R_, R_), device=dev)]
+    st = state(B)
+    ref_spk, _, _ = ops.conv_lif_sequence_cells(d, cu(want.numpy(), dev), cu(W, dev), cu(b, dev), tau4, *st, T, B,
+                                                want_pv=False)
+    st = state(B)
+    spk, _, _ = ops.conv_lif_sequence_iq(d, cu(iq, dev), enc.thr_i, enc.thr_q, t0, cu(W, dev), cu(b, dev), tau4, *st, T, B,
+                                         want_pv=False, tail=enc.tail(B))
+    assert torch.equal(spk, ref_spk)
+    for b0 in range(0, B, 16):
+        b1 = min(B, b0 + 16)
+        st = state(b1 - b0)
+        part, _, _ = ops.conv_lif_sequence_iq(d, cu(iq[b0:b1], dev), enc.thr_i, enc.thr_q, t0, cu(W, dev), cu(b, dev), tau4,
+                                              *st, T, b1 - b0, want_pv=False, tail=enc.tail(b1 - b0, b0, b1, B))
+        assert torch.equal(part, ref_spk[:, b0:b1]), b0
