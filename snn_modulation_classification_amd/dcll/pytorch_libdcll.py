@@ -859,6 +859,32 @@ class DCLLBase(nn.Module):
                 loss = None
         return (o if L.output_layer else s), p, pv, v, loss, learned
 
+    def _grads_into_slab(self):
+        """Make the .grad tensors of this slice's trainable parameters views of ONE flat buffer (+ one count element): the
+        backward kernels then write straight into what the per-slice all-reduce sends — no gather / scatter copies around
+        the collective (parallel.allreduce_slab_begin).  -> the slab."""
+        L = self.dclllayer
+        prm = [L.i2h.weight, L.i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
+        slab = getattr(self, '_grad_slab', None)
+        n = sum(q.numel() for q in prm)
+        ok = slab is not None and slab.numel() == n + 1 and slab.device == prm[0].device
+        off = 0
+        for q in prm:
+            ok = ok and q.grad is not None and q.grad.data_ptr() == (slab.data_ptr() + 4 * off if slab is not None else -1)
+            off += q.numel()
+        if ok:
+            return slab
+        slab = torch.zeros(n + 1, device=prm[0].device, dtype=torch.float32)
+        off = 0
+        for q in prm:
+            view = slab[off:off + q.numel()].view_as(q)
+            if q.grad is not None:
+                view.copy_(q.grad)
+            q.grad = view
+            off += q.numel()
+        self._grad_slab = slab
+        return slab
+
     def _grad_tensors(self):
         L = self.dclllayer
         prm = [L.i2h.weight, L.i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
@@ -893,7 +919,12 @@ class DCLLBase(nn.Module):
         With torch.distributed initialised the gradients are averaged over the ranks (RCCL) before the step.
         Without regularisers and with SmoothL1 / MSE losses and Adam (what train.py runs) the whole step is C-ABI calls
         (`_native_learning`); otherwise the same HIP forward / backward run inside an autograd node and torch supplies the
-        loss module and the optimizer."""
+        loss module and the optimizer.
+
+        NOTE (native path): output, pvoutput, pv, pvmem and the loss are VIEWS of this slice's preallocated step buffers —
+        valid until the slice's next step, which overwrites them (the reference returns fresh tensors each step).  A caller
+        that collects them over timesteps must .clone() them; ConvNetwork.learn / train.py only chain `output` into the
+        next slice within the same step."""
         if not isinstance(self.dclllayer, Conv2dDCLLlayer):
             raise NotImplementedError('local learning is implemented for Conv2dDCLLlayer slices')
         from .. import parallel

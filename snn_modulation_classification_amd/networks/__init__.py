@@ -60,6 +60,10 @@ class ConvNetwork(torch.nn.Module):
                                               burnin=burnin))
         self._seq_buffers = {}
         self._seq_scratch = {}
+        # samples of the GLOBAL batch of the current learning step when the batch is sharded over ranks (the entry points
+        # set it next to shard_range): lets the gradient all-reduce weigh the shards exactly; None = derive it in the
+        # collective (a count element travels with every slab)
+        self.global_batch = None
         # captured learning timesteps (hipGraph), per input shape; see _learn_graphed
         self.graph_learn = os.environ.get('DCLL_GRAPH_LEARN', '1') != '0'
         self._learn_graphs, self._learn_eager_steps, self._learn_last_key = {}, {}, None
@@ -88,16 +92,26 @@ class ConvNetwork(torch.nn.Module):
         key = (tuple(x.shape), tuple(labels.shape))
         if key != self._learn_last_key:                # another geometry: the slices' buffers are reallocated
             self._learn_last_key, self._learn_eager_steps[key] = key, 0
+        from .. import parallel
+        ranks = parallel.is_distributed()
+        if ranks:
+            for s in self.dcll_slices:
+                s._grads_into_slab()
         if self._graph_learn_ok(x, labels, key) and self._learn_graphed(x, labels, key):
             return
-        spikes, learned = x, []
+        # Under ranks every slice's gradients are ONE slab whose all-reduce starts as soon as its backward is enqueued and
+        # runs under the next slice's forward / backward (slice l+1 needs slice l's spikes, not its gradients); the
+        # single Adam launch waits for all of them.
+        spikes, learned, pending = x, [], []
         for s in self.dcll_slices:
             spikes, _, _, _, _, l = s._learn_forward_backward(spikes, labels, want_loss=False)   # nobody reads the value
             if l:
                 learned.append(s)
+                if ranks:
+                    pending.append(parallel.allreduce_slab_begin(s._grad_slab, x.shape[0], self.global_batch))
+        for h in pending:
+            parallel.allreduce_slab_end(h)
         if learned:
-            from .. import parallel
-            parallel.allreduce_mean_tensors([g for s in learned for g in s._grad_tensors()], local_n=x.shape[0])
             ops.adam_step([t for s in learned for t in s._adam_tensors()])
             if len(learned) == len(self.dcll_slices):
                 self._learn_eager_steps[key] = self._learn_eager_steps.get(key, 0) + 1
@@ -122,9 +136,6 @@ class ConvNetwork(torch.nn.Module):
                 self._graph_small(x)):
             return False
         if self._learn_eager_steps.get(key, 0) < 2:            # buffers, .grad and Adam state exist after eager steps
-            return False
-        from .. import parallel
-        if parallel.is_distributed():                          # the gradient bucket's collective stays outside graphs
             return False
         for s in self.dcll_slices:
             it = s.iter + 1
@@ -185,7 +196,19 @@ class ConvNetwork(torch.nn.Module):
         g['dyn_host_np'][slot, :] = ops.adam_dyn_values(tensors)
         g['dyn'].copy_(g['dyn_host'][slot], non_blocking=True)
         g['events'][slot].record()
-        g['graph'].replay()
+        if g['segments'] is None:
+            g['graph'].replay()
+        else:
+            # under ranks: one captured segment per slice, its gradient slab's all-reduce started (eagerly — collectives
+            # stay outside the graphs) right behind it so that it runs under the next segment, Adam as a last segment
+            from .. import parallel
+            pending = []
+            for seg, s in zip(g['segments'], self.dcll_slices):
+                seg.replay()
+                pending.append(parallel.allreduce_slab_begin(s._grad_slab, x.shape[0], self.global_batch))
+            for h in pending:
+                parallel.allreduce_slab_end(h)
+            g['graph'].replay()
         rec = g['clout'].clone()
         for i, s in enumerate(self.dcll_slices):
             s.iter += 1
@@ -204,21 +227,37 @@ class ConvNetwork(torch.nn.Module):
                  records=[isinstance(s, DCLLClassification) for s in self.dcll_slices])
         g['dyn_host_np'] = g['dyn_host'].numpy()
         iters = [s.iter for s in self.dcll_slices]
+        from .. import parallel
+        ranks = parallel.is_distributed()
         graph = torch.cuda.CUDAGraph()
+        segments = [torch.cuda.CUDAGraph() for _ in self.dcll_slices] if ranks else None
         torch.cuda.synchronize(dev)
         try:
             # (thread_local: API calls of other host threads — a data loader pinning memory — do not break the capture)
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                spikes = g['x']
+            if not ranks:
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    spikes = g['x']
+                    for i, s in enumerate(self.dcll_slices):
+                        spikes, _, _, _, _, l = s._learn_forward_backward(spikes, g['y'], want_loss=False,
+                                                                         clout_out=g['clout'][i])
+                        assert l
+                    ops.adam_step([t for s in self.dcll_slices for t in s._adam_tensors(advance=False)], dyn=g['dyn'])
+            else:
+                # one graph per slice (the slabs' collectives run between them, outside any capture) + one for Adam,
+                # all in one memory pool: a segment's outputs are the next one's inputs
+                spikes, pool = g['x'], None
                 for i, s in enumerate(self.dcll_slices):
-                    spikes, _, _, _, _, l = s._learn_forward_backward(spikes, g['y'], want_loss=False,
-                                                                     clout_out=g['clout'][i])
-                    assert l
-                ops.adam_step([t for s in self.dcll_slices for t in s._adam_tensors(advance=False)], dyn=g['dyn'])
+                    with torch.cuda.graph(segments[i], pool=pool, capture_error_mode='thread_local'):
+                        spikes, _, _, _, _, l = s._learn_forward_backward(spikes, g['y'], want_loss=False,
+                                                                         clout_out=g['clout'][i])
+                        assert l
+                    pool = segments[i].pool() if pool is None else pool
+                with torch.cuda.graph(graph, pool=pool, capture_error_mode='thread_local'):
+                    ops.adam_step([t for s in self.dcll_slices for t in s._adam_tensors(advance=False)], dyn=g['dyn'])
         finally:
             for s, it in zip(self.dcll_slices, iters):         # capturing records the launches, it runs nothing
                 s.iter = it
-        g['graph'] = graph
+        g['graph'], g['segments'] = graph, segments
         return g
 
     @torch.no_grad()

@@ -163,6 +163,44 @@ def allreduce_mean_tensors(tensors, local_n=None):
         off += t.numel()
 
 
+def allreduce_slab_begin(slab, local_n, global_n=None):
+    """Start the all-reduce of ONE slice's gradient slab — a flat fp32 buffer whose views are the slice's .grad tensors,
+    followed by one count element — and return a handle for allreduce_slab_end; the caller goes on enqueueing the next
+    slice's kernels, which run under the collective (RCCL works on its own stream and orders itself behind the kernels
+    already enqueued on the current one).  The slab holds the gradient of the LOCAL mean loss: it is weighted by the
+    shard's share of the global batch first — local_n / global_n when the caller knows the global batch (exact for
+    power-of-two rank counts, no division afterwards), else local_n with the count element carrying the weights' sum.
+    One rank: nothing to weigh, the slab still travels through the backend.  None when not distributed."""
+    if not is_distributed():
+        return None
+    world = dist.get_world_size()
+    counted = False
+    if world > 1:
+        if global_n:
+            slab.mul_(float(local_n) / float(global_n))
+        else:
+            slab[-1] = 1.0
+            slab.mul_(float(local_n))
+            counted = True
+    if slab.is_cuda and dist.get_backend() == "gloo":      # rehearsal backend: staged through the host, synchronous
+        host = slab.detach().cpu()
+        dist.all_reduce(host)
+        slab.copy_(host)
+        return (None, slab, counted)
+    return (dist.all_reduce(slab, async_op=True), slab, counted)
+
+
+def allreduce_slab_end(handle):
+    """Make the current stream wait for a slab's collective (no host sync under RCCL) and finish its weighting."""
+    if handle is None:
+        return
+    work, slab, counted = handle
+    if work is not None:
+        work.wait()
+    if counted:
+        slab.div_(slab[-1].clone())
+
+
 def allreduce_mean_grads(params, local_n=None):
     """Average .grad over the ranks (the local losses are means over the LOCAL batch, so the global-batch gradient is
     the shard-size-weighted mean of the shard gradients).  One flat all-reduce per call; no-op for a single process."""

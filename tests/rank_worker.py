@@ -80,6 +80,7 @@ def main():
     lnet = radio_net(lhi - llo, 16, dev, learn=True)
     lnet.reset()
     lnet.train()
+    lnet.global_batch = LEARN_B
     for t in range(LEARN_T):
         lnet.learn(x[t], y[t])
         if t == LEARN_BURNIN - 1:         # first learning step: gradients of identical weights

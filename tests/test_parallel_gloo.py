@@ -125,6 +125,43 @@ def test_two_rank_gradient_mean_with_ragged_shards(tmp_path):
         assert np.allclose(np.load(os.path.join(str(tmp_path), "r_%d.npy" % rank)), expect)
 
 
+def _slab_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_process_group(backend="gloo")
+    # two slices' slabs (gradient views + one count element), ragged shards of 3 and 5 samples; both started before
+    # either is finished — the order ConvNetwork.learn uses (slice l's collective under slice l+1's kernels)
+    n = 3 + 2 * rank
+    out = {}
+    for known in (False, True):
+        slabs = [torch.cat([torch.full((4,), float(rank + 1)), torch.zeros(1)]),
+                 torch.cat([torch.full((6,), 10.0 * (rank + 1)), torch.zeros(1)])]
+        views = [s_[:-1] for s_ in slabs]
+        handles = [parallel.allreduce_slab_begin(s_, n, 8 if known else None) for s_ in slabs]
+        for h in handles:
+            parallel.allreduce_slab_end(h)
+        out["known" if known else "counted"] = np.concatenate([v.numpy() for v in views])
+    np.savez(os.path.join(out_dir, "s_%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gradient_slabs_overlapped_and_weighted(tmp_path):
+    """allreduce_slab_begin / _end (per-slice gradient slabs, several in flight): the global-batch mean for ragged shards,
+    with the global batch given by the caller (weights local / global, no division afterwards) and without (a count
+    element travels in the slab); a single process is a no-op."""
+    port = _free_port()
+    mp.spawn(_slab_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    expect = np.concatenate([np.full(4, (1 * 3 + 2 * 5) / 8.0), np.full(6, (10 * 3 + 20 * 5) / 8.0)])
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "s_%d.npz" % rank))
+        assert np.allclose(got["known"], expect) and np.allclose(got["counted"], expect)
+    slab = torch.ones(5)
+    assert parallel.allreduce_slab_begin(slab, 4, 8) is None and slab.tolist() == [1.0] * 5
+    parallel.allreduce_slab_end(None)
+
+
 _LAUNCHED = '''
 import os, sys
 sys.path.insert(0, %r)

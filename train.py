@@ -199,6 +199,7 @@ def main(argv=None):
                 if samples.shape[0] != args.batch_size:       # ragged last batch: the state is sized for batch_size
                     gen_train = iter(train_data)
                     samples, labels = next(gen_train)
+            net.global_batch = samples.shape[0]               # (the gradient all-reduce weighs the shards by it)
             if world > 1:                                     # my contiguous shard of the batch
                 a, b = parallel.shard_range(samples.shape[0], rank, world)
                 samples, labels = samples[a:b], labels[a:b]
