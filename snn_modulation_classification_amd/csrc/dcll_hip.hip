@@ -1066,14 +1066,17 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
                                                     float *__restrict__ v_out, int T, int B, float alpharp, float wrp)
 {
     constexpr int PS = 24;                      // plane row stride: 16 + 2*3 padding + the pad tap's column
-    __shared__ float plane[22 * PS + 8];
+    constexpr int PLANE = 22 * PS + 8;
+    // two planes, by step parity: a step's MFMAs read plane[t & 1] while the next step's trace update already writes the
+    // other one — ONE barrier per step (round 3; a single plane needed a second barrier behind the MFMAs)
+    __shared__ float plane[2 * PLANE];
     __shared__ float sbias[32];
     __shared__ int scell[IQ ? C1_MAXT : 1];
     const int b = blockIdx.x, pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63;
     const int w = __builtin_amdgcn_readfirstlane(pix >> 6);
     const int h = lane >> 5, j = lane & 31;
     const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];
-    for (int i = pix; i < 22 * PS + 8; i += 256) plane[i] = 0.0f;
+    for (int i = pix; i < 2 * PLANE; i += 256) plane[i] = 0.0f;
     if (IQ) {
         const float *ti, *tq;
         iq_tables(thr_i, thr_q, tail, b, ti, tq);
@@ -1109,14 +1112,17 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
         const int tn = t + 1 < T ? t + 1 : t;
         const int cell_next = IQ ? scell[tn] : cells[(long)tn * B + b];
         trace_update(cell == pix ? 1.0f : 0.0f, alpha, tau_m, alphas, tau_s, e0, e1);
-        plane[(y + 3) * PS + x + 3] = e1;
-        lds_barrier();      // LDS-only: does not wait for this step's pv stores
+        float *pl = plane + (t & 1) * PLANE;
+        pl[(y + 3) * PS + x + 3] = e1;
+        // LDS-only barrier (does not wait for this step's pv stores): every wave's reads of plane[t & 1] from step t - 2 were
+        // issued before it passed the barrier of step t - 1, and that barrier waits for the wave's outstanding LDS operations
+        lds_barrier();
         const long obase = ((long)t * B + b) * c_out;
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
             const int m = 2 * w + tl;
-            const float *bn = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h;               // second tap: + 1
-            const float *bx = plane + (2 * m + (j >> 4)) * PS + (j & 15) + h * (PS - 6);    // ... or the next row's first
+            const float *bn = pl + (2 * m + (j >> 4)) * PS + (j & 15) + h;               // second tap: + 1
+            const float *bx = pl + (2 * m + (j >> 4)) * PS + (j & 15) + h * (PS - 6);    // ... or the next row's first
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
@@ -1157,7 +1163,6 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
             }
         }
         cell = cell_next;
-        lds_barrier();      // LDS-only: does not wait for this step's pv stores
     }
     eps0_g[(long)b * 256 + pix] = e0;
     eps1_g[(long)b * 256 + pix] = e1;

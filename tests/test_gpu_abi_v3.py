@@ -511,3 +511,86 @@ def test_device_iq_encoder_is_exact_for_ragged_batches(dev, B, R_):
         part, _, _ = ops.conv_lif_sequence_iq(d, cu(iq[b0:b1], dev), enc.thr_i, enc.thr_q, t0, cu(W, dev), cu(b, dev), tau4,
                                               *st, T, b1 - b0, want_pv=False, tail=enc.tail(b1 - b0, b0, b1, B))
         assert torch.equal(part, ref_spk[:, b0:b1]), b0
+
+
+def test_one_layer_network_runs_the_sequence_path(dev):
+    """A ConvNetwork with a single layer (sequence_supported() accepts it): its spike view must not be sized from "all
+    layers but the last" (round-2 advisor finding: an empty max) — test_sequence runs and equals the per-step path."""
+    import os
+    from argparse import Namespace
+    from conftest import ROOT
+    from snn_modulation_classification_amd import ops
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))[:1]
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    B, T = 5, 9
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        net = ConvNetwork(args, (1, 16, 16), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
+                          learning_rates=None, burnin=2)
+        net.reset(True)
+        nets.append(net)
+    a, b = nets
+    assert a.sequence_supported() and a.num_layers == 1
+    cells = torch.randint(0, 256, (T, B), device=dev, dtype=torch.int32)
+    a.reset()
+    res = a.test_sequence(cells, keep_spikes=True)
+    assert res["spikes"][0].shape == (T, B, 32, 8) and res["o"].shape == (T, B, 24)
+    planes = ops.cells_to_planes(cells, 256)
+    b.reset()
+    for t in range(T):
+        b.test(planes[t].reshape(B, 1, 16, 16))
+    for x, y in zip(a.dcll_slices[0].dclllayer.i2h.state, b.dcll_slices[0].dclllayer.i2h.state):
+        assert torch.equal(x, y)
+    assert a.dcll_slices[0].iter == b.dcll_slices[0].iter == T
+
+
+@pytest.mark.timeout(900)
+def test_config5_properties_at_batch_1024_t128(dev):
+    """BASELINE config 5 at a size the oracle cannot walk (radio_ml_conv_ref.yaml, int8 weights through the ABI, Q=16 x
+    I=128 plane, T=128, batch 1024: 34 GB of pooled maps): size-independent properties — the run is deterministic, a run in
+    chunks of 384 windows (pv budget) equals the unchunked run sample for sample (state, votes, per-step argmax; logits
+    bit for bit: the sequence readout's summation order does not depend on the row count), and two samples are walked by
+    the C oracle for the first steps (logits within 1e-4)."""
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    from snn_modulation_classification_amd.networks import load_network_spec
+    from oracle import c_oracle as C
+    import os
+    from conftest import ROOT
+    B, T, H, W = 1024, 128, 16, 128
+    torch.manual_seed(8)
+    iq = (0.4 * torch.randn(B, 2, 128)).to(dev)
+    enc = IQEncoder(W, H, device=dev)
+
+    def run(budget_gb):
+        net = _net("radio_ml_conv_ref.yaml", (1, H, W), B, True)
+        net.pv_budget_bytes = budget_gb * 2 ** 30
+        net.reset()
+        res = net.test_sequence(iq=iq, encoder=enc, T=T, t0=0)
+        torch.cuda.synchronize()
+        return net, res
+    n1, r1 = run(150)
+    n2, r2 = run(150)
+    n3, r3 = run(12.6)          # 33.5 MB of pooled first-layer map per window: chunks of 385 windows
+    for i in range(7):
+        for other_n, other_r in ((n2, r2), (n3, r3)):
+            for x, y in zip(n1.dcll_slices[i].dclllayer.i2h.state, other_n.dcll_slices[i].dclllayer.i2h.state):
+                assert torch.equal(x, y), i
+            assert torch.equal(r1["logits"][i], other_r["logits"][i]), i
+            assert torch.equal(r1["clout"][i], other_r["clout"][i]) and torch.equal(r1["vote"][i], other_r["vote"][i])
+            assert torch.equal(r1["lowhigh"][i], other_r["lowhigh"][i])
+    assert torch.equal(r1["o"], r3["o"])
+    # oracle on samples 0 and 1023, first 3 steps
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv_ref.yaml"))
+    sds = [{k: v.detach().cpu().numpy() for k, v in s.dclllayer.state_dict().items()} for s in n1.dcll_slices]
+    orc = C.OracleConvNetwork(sds, convs, (H, W), 1.0)
+    pick = [0, B - 1]
+    cells = enc(iq, T, t0=0).cpu().numpy()
+    for t in range(3):
+        x = np.zeros((2, 1, H * W), np.float32)
+        x[np.arange(2), 0, cells[t, pick]] = 1
+        outs = orc.step(x.reshape(2, 1, H, W))
+        for i in range(7):
+            np.testing.assert_allclose(r1["logits"][i][t][pick].cpu().numpy(), outs[i]["p"], atol=LOGIT_TOL, rtol=0)
