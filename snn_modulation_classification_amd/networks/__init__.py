@@ -444,7 +444,7 @@ class ConvNetwork(torch.nn.Module):
 
     @torch.no_grad()
     def test_sequence(self, cells=None, collect=True, profile=None, fuse_readout=False, iq=None, encoder=None,
-                      T=None, t0=None, output_only=False, overlap_readout=None, keep_spikes=False):
+                      T=None, t0=None, output_only=False, overlap_readout=None, keep_spikes=False, shard=None):
         """Equivalent of `for t in range(T): net.test(x[t])` for input given as cell indices (T,B) int32 on device
         (one input spike per sample per step, what iq2spiketrain produces), or as the raw IQ batch `iq` (B,2,L) with an
         `IQEncoder` — then the quantisation runs inside the first layer's kernel (T steps from sample t0; t0 drawn
@@ -464,6 +464,10 @@ class ConvNetwork(torch.nn.Module):
         the HBM-bound work behind each of them — pv statistics, readout GEMM (in its LDS-free <= 64-VGPR form), argmax /
         vote — on the caller's stream, so that it executes in the gaps of the NEXT layer's matrix-bound kernel instead
         of after it; one pv buffer per layer instead of one.  Results are identical up to the readout's summation order.
+
+        `shard` = (start, total): `iq` holds samples start.. of a batch of `total` that is sharded over ranks — the encoder
+        then quantises every sample as the reference would at ITS position in the whole batch (torch's vector / scalar pow
+        paths, data/utils.py IQEncoder); default: `iq` is the whole batch.
 
         `keep_spikes`: also return every layer's packed output spike train, 'spikes' (per layer (T,B,C,HW/32) int32,
         bit pix%32 of word pix/32; copies — the working buffers are reused) — for parity checks against the reference.
@@ -490,6 +494,7 @@ class ConvNetwork(torch.nn.Module):
             dev = cells.device
         # Samples are independent, so a batch whose pv buffer (T*B*C*H*W floats per layer) would exceed the budget is
         # run in chunks — on the 128x128 plane T=128 x 512 windows would otherwise need 137 GB for pv alone.
+        s0, stot = (0, B) if shard is None else (int(shard[0]), int(shard[1]))
         per_sample = 4 * T * max(s.dclllayer.out_channels * int(np.prod(s.dclllayer.output_shape)) for s in self.dcll_slices)
         chunk = max(1, min(B, int(self.pv_budget_bytes // max(per_sample, 1))))
         if chunk < B:
@@ -500,8 +505,8 @@ class ConvNetwork(torch.nn.Module):
             for b0 in range(0, B, chunk):
                 b1 = min(B, b0 + chunk)
                 parts.append(self._sequence_chunk(
-                    (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0), encoder.tail(b1 - b0, b0, b1, B))
-                    if iq is not None
+                    (iq[b0:b1].contiguous(), encoder.thr_i, encoder.thr_q, int(t0),
+                     encoder.tail(b1 - b0, s0 + b0, s0 + b1, stot)) if iq is not None
                     else cells[:, b0:b1].contiguous(),
                     'iq' if iq is not None else 'cells', T, b1 - b0, dev, profile, fuse_readout, batch_slice=b0,
                     output_only=output_only, overlap=overlap_readout, keep_spikes=keep_spikes))
@@ -515,7 +520,7 @@ class ConvNetwork(torch.nn.Module):
             if keep_spikes:
                 res['spikes'] = cat('spikes', 1)
         else:
-            res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0), encoder.tail(B))
+            res = self._sequence_chunk((iq, encoder.thr_i, encoder.thr_q, int(t0), encoder.tail(B, s0, s0 + B, stot))
                                        if iq is not None else cells,
                                        'iq' if iq is not None else 'cells', T, B, dev, profile, fuse_readout,
                                        output_only=output_only, overlap=overlap_readout, keep_spikes=keep_spikes)

@@ -112,8 +112,10 @@ def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
     independent) and the per-layer correct counts + the confusion matrix are summed over the ranks."""
     T = args.n_iters_test
     rank, _, world = parallel.env_ranks()
+    shard = None
     if world > 1:
         lo, hi = parallel.shard_range(samples.shape[0], rank, world)
+        shard = (lo, samples.shape[0])          # my samples' positions in the whole batch (exact quantisation)
         samples, labels1h = samples[lo:hi], labels1h[lo:hi]
         net.batch_size = hi - lo
         if hi == lo:                                    # more ranks than samples: this rank only joins the reduction
@@ -125,7 +127,7 @@ def evaluate_batch(net, args, samples, labels1h, encoder, use_sequence):
         net.reset()
         net.eval()
         # raw IQ to the GPU; quantisation to I/Q-plane cells happens inside the first layer's kernel
-        net.test_sequence(iq=samples.to(pytorch_libdcll.device), encoder=encoder, T=T)
+        net.test_sequence(iq=samples.to(pytorch_libdcll.device), encoder=encoder, T=T, shard=shard)
     else:
         spikes, targets = iq2spiketrain(samples, labels1h, out_w=args.I_resolution, out_h=args.Q_resolution,
                                         min_I=args.I_bounds[0], max_I=args.I_bounds[1], min_Q=args.Q_bounds[0],

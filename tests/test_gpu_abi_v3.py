@@ -594,3 +594,29 @@ def test_config5_properties_at_batch_1024_t128(dev):
         outs = orc.step(x.reshape(2, 1, H, W))
         for i in range(7):
             np.testing.assert_allclose(r1["logits"][i][t][pick].cpu().numpy(), outs[i]["p"], atol=LOGIT_TOL, rtol=0)
+
+
+def test_sharded_evaluation_quantises_like_the_whole_batch(dev):
+    """test_radio_ml.py under ranks: every rank runs test_sequence(iq=its shard, shard=(start, total)); the fused encoder
+    must put each sample in the cell the reference's whole-batch quantiser would (positions 32..36 of a 37-window batch
+    take torch's scalar pow path, whichever rank holds them): shard results == whole-batch results, bit for bit, on
+    boundary-valued inputs."""
+    from test_host_logic import _boundary_iq
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    B, T = 37, 21
+    enc = IQEncoder(16, 16, device=dev)
+    tabs = [enc.thr_i.cpu().numpy(), enc.thr_q.cpu().numpy()]
+    if enc.thr_i_tail is not None:
+        tabs += [enc.thr_i_tail.cpu().numpy(), enc.thr_q_tail.cpu().numpy()]
+    iq = cu(_boundary_iq(B, 32, tabs, seed=5), dev)
+    whole = _net("radio_ml_conv.yaml", (1, 16, 16), B, False)
+    whole.reset()
+    rw = whole.test_sequence(iq=iq, encoder=enc, T=T, t0=4)
+    for lo, hi in ((0, 20), (20, 37)):
+        part = _net("radio_ml_conv.yaml", (1, 16, 16), hi - lo, False)
+        part.reset()
+        rp = part.test_sequence(iq=iq[lo:hi].contiguous(), encoder=enc, T=T, t0=4, shard=(lo, B))
+        for i in range(3):
+            assert torch.equal(rp["clout"][i], rw["clout"][i][:, lo:hi]) and torch.equal(rp["vote"][i], rw["vote"][i][lo:hi])
+            for x, y in zip(part.dcll_slices[i].dclllayer.i2h.state, whole.dcll_slices[i].dclllayer.i2h.state):
+                assert torch.equal(x, y[lo:hi]), (lo, i)

@@ -200,9 +200,11 @@ def main(argv=None):
                     gen_train = iter(train_data)
                     samples, labels = next(gen_train)
             net.global_batch = samples.shape[0]               # (the gradient all-reduce weighs the shards by it)
+            enc_pos = dict(start=0, total=samples.shape[0])   # my samples' positions in the whole batch (exact quantisation)
             if world > 1:                                     # my contiguous shard of the batch
                 a, b = parallel.shard_range(samples.shape[0], rank, world)
                 samples, labels = samples[a:b], labels[a:b]
+                enc_pos['start'] = a
             t_step = time.perf_counter()
             labels1h = to_one_hot(labels, target_size)
             net.reset()
@@ -211,7 +213,7 @@ def main(argv=None):
                 # raw IQ to the GPU, iq2spiketrain's quantisation as a kernel (same random crop draw), burn-in steps on
                 # the fused sequence kernels, learning steps on device-built planes
                 dev = pytorch_libdcll.device
-                cells = encoder(samples.to(dev), args.n_iters)
+                cells = encoder(samples.to(dev), args.n_iters, **enc_pos)
                 y = torch.as_tensor(np.asarray(labels1h), dtype=torch.float32).to(dev)
                 net.learn_sequence(cells, y)
                 labels_spikes = y.unsqueeze(0).expand(args.n_iters, -1, -1)
