@@ -7,8 +7,9 @@
 // of the flattened (H x W) plane of each sample — a tile is 32/W rows when the layer has become narrow (W = 16 ... 2
 // after the poolings), so the MFMA lanes stay full in all seven layers.  One 512-thread workgroup owns W3_NT = 8
 // consecutive tiles (256 pixels: whole rows, of one sample or — narrow layers — of several) for all T steps:
-//   - eps0 of its 64 x 256 trace elements in registers (thread = (input channel, tile): the 32 pixels of ONE input
-//     spike word), eps1 in an LDS image with one shared zero column between rows (the conv's horizontal padding);
+//   - eps0 of its 64 x 256 trace elements in registers (thread = (input channel = lane, tile = wave): the 32 pixels of
+//     ONE input spike word), eps1 in a pixel-major LDS image (layout below) with one shared zero position between rows
+//     (the conv's horizontal padding);
 //   - weights stationary in registers: wave (mt, g) holds the A fragments of output-channel tile mt (32 of the 64
 //     channels) for the whole chain K = 64 x 3 = 192 — 96 VGPRs — and runs the complete pinned fmaf chain
 //     (cp, kx, h: ci = 2cp + h) of its two pixel tiles 2g, 2g+1, one after the other: no hand-off between waves (unlike
@@ -21,7 +22,9 @@
 //     first form used a ds_swizzle per value and stored every pooled value from both lanes of its pair).  The pooled
 //     spike is (pooled v > 0) — max(s_a, s_b) exactly — so one v_cmp on that register yields the four 16-bit pooled
 //     half-words of the two channels; the half-words of a wave's two tiles are one 32-bit word of the next layer's input;
-//   - per step: trace update (all threads) | barrier | 2 x 96 MFMAs + epilogue per wave | barrier.
+//   - per step: trace update (all threads) | barrier | 2 x 96 MFMAs + epilogue per wave | barrier; wide layers keep two
+//     images (by step parity) and write step t+1's traces right behind the chains of step t: one barrier per step.
+// The conv weights may arrive as int8 + one fp32 scale per output channel (dcll_wsrc): converted once, in the prologue.
 // Outputs are the POOLED maps: spk_out (T,B,64,H*W/64) packed, pv_out (T,B,64,H,W/2); v_out (T,B,64,H,W) un-pooled.
 // Same pinned arithmetic as every other path (include/dcll_hip.h): bit-identical to the per-step kernels / the C oracle.
 #include "dcll_internal.h"
