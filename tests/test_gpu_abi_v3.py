@@ -39,6 +39,7 @@ SEQ_CASES = [
     ("c1_narrow", 1, 8, (16, 16), 7, 3, 1, 6, 2),        # k_lif_seq_c1, generic (guarded) epilogue
     ("c1t", 1, 32, (32, 32), 7, 3, 1, 5, 2),             # k_lif_seq_c1t
     ("w3_wide", 64, 64, (16, 64), (1, 3), (0, 1), (1, 2), 6, 2),     # k_lif_seq_w3<64, WIDE>
+    ("w3_mid", 64, 64, (16, 8), (1, 3), (0, 1), (1, 2), 6, 5),       # k_lif_seq_w3<64, !WIDE>, 4 rows per tile
     ("w3_narrow", 64, 64, (16, 4), (1, 3), (0, 1), (1, 2), 5, 3),    # k_lif_seq_w3<64, !WIDE>
     ("w3_first", 1, 64, (16, 128), (1, 3), (0, 1), (1, 2), 7, 2),    # k_lif_seq_w3<1>
 ]
@@ -219,7 +220,7 @@ def test_layer_opts_validation(dev):
 
 
 @pytest.mark.parametrize("case", [c for c in SEQ_CASES if c[0] in ("c32d", "c32", "c32t", "c1", "c1_narrow", "c1t",
-                                                                      "w3_wide", "w3_narrow", "w3_first")],
+                                                                      "w3_wide", "w3_mid", "w3_narrow", "w3_first")],
                          ids=lambda c: c[0])
 def test_presigmoid_buffer_holds_v_and_statistics_are_unchanged(dev, case):
     """pv_presigmoid: pv_out receives the bit-exact v (max-pooled where the layer pools) and the pv statistics counted on
