@@ -167,7 +167,7 @@ class IQEncoder:
                     # at min(thr) the path with the lower threshold already says cell j + 1, the other still j
                     j = int(d[0])
                     x = min(v_[j], s_[j])
-                    self._witness = (axis, float(x), int(j + 1) if s_[j] < v_[j] else int(j), n_cells_of(axis, out_w, out_h))
+                    self._witness = (axis, float(x), int(j + 1) if s_[j] < v_[j] else int(j), out_w if axis == 0 else out_h)
             if self._witness is not None:       # (else: the two paths agree on this host — one table serves all)
                 self.thr_i_tail, self.thr_q_tail = torch.from_numpy(si).to(device), torch.from_numpy(sq).to(device)
 
@@ -202,6 +202,3 @@ class IQEncoder:
         return ops.iq_encode(iq, self.thr_i, self.thr_q, t0, max_duration, self.w, self.h,
                              tail=self.tail(iq.shape[0], start=start, total=total))
 
-
-def n_cells_of(axis, out_w, out_h):
-    return out_w if axis == 0 else out_h
