@@ -918,3 +918,4 @@ def test_sequence_w3_vs_oracle(dev, cin, hw, wrp, T, B, zero_state):
     if wrp > 0:
         assert bits_equal(arp.cpu().numpy(), orc.state[2])
     assert 0.005 < nspk / (T * B * cout * H * Wd / 2) < 0.95, "degenerate test"
+
