@@ -1246,10 +1246,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32(const uint32_t *__restrict_
 
     // weight fragments: A[co = j][k = h] of MFMA (cp, tap) = W[j][4w + 2cp + h][tap]
     float wf[2][49];
-#pragma unroll
-    for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-        for (int k = 0; k < 49; ++k) wf[cp][k] = W.at(((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k, j);
+    load_wf_c32(W, j, w, h, wf);
 
     // trace state of my 4 channels: element (c, ii): channel 4w+c, pixel ii*64 + lane.  eps0 in registers, eps1 in
     // the LDS images at float offset ioff + c*CHF + ii*4*ROWF.
@@ -1580,10 +1577,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
     for (int i = tid; i < SLOT_FLOATS; i += 512) sbias[i] = bias[(i & 3) + 8 * (i >> 8) + 4 * ((i >> 7) & 1)];
 
     float wf[2][49];
-#pragma unroll
-    for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-        for (int k = 0; k < 49; ++k) wf[cp][k] = W.at(((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k, j);
+    load_wf_c32(W, j, w, h, wf);
 
     // eps0 of my 4 channels: register group grp holds channel (grp - w) & 3 (see the header), element ii = pixel
     // ii*64 + lane; eps1 lives in the LDS images at float offset ioff + c*CHF + ii*4*ROWF

@@ -62,6 +62,24 @@ struct dcll_wsrc {
     const float *scale;
     __device__ __forceinline__ float at(long idx, int co) const { return q ? (float)q[idx] * scale[co] : f[idx]; }
 };
+// the 2 x 49 stationary A fragments of a 32 -> 32 7x7 sequence kernel: W[j][4 w + 2 cp + h][tap]; ONE wave-uniform branch
+// on the weight format around the whole load (not one per weight)
+__device__ __forceinline__ void load_wf_c32(const dcll_wsrc &W, int j, int w, int h, float (&wf)[2][49])
+{
+    if (W.q) {
+        const float sc = W.scale[j];
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+            for (int k = 0; k < 49; ++k) wf[cp][k] = (float)W.q[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k] * sc;
+    } else {
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+            for (int k = 0; k < 49; ++k) wf[cp][k] = W.f[((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k];
+    }
+}
+
 static inline dcll_wsrc make_wsrc(const float *W, const dcll_layer_opts *o)
 {
     return (o && o->w_q8) ? dcll_wsrc{nullptr, o->w_q8, o->w_scale} : dcll_wsrc{W, nullptr, nullptr};

@@ -127,10 +127,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
     }
     // weight fragments (after the state prologue, so that its loads are not in flight on top of these 98 registers)
     float wf[2][49];
-#pragma unroll
-    for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-        for (int k = 0; k < 49; ++k) wf[cp][k] = W.at(((long)j * 32 + 4 * w + 2 * cp + h) * 49 + k, j);
+    load_wf_c32(W, j, w, h, wf);
 
     // refractory trace of my epilogue share: tiles (rows) m = 2k + wpar (k = pair index), quad wq
     float arp[4][4];

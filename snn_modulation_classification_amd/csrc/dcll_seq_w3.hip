@@ -110,8 +110,14 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
         wf[0] = W.at((32 * mt + jj) * 3 + h, 32 * mt + jj);
         wf[NK - 1] = h == 0 ? W.at((32 * mt + jj) * 3 + 2, 32 * mt + jj) : 0.0f;
     } else {                // k lanes = input-channel pair: step s = cp * 3 + kx -> W[co][2 cp + h][kx]
+        if (W.q) {          // (one wave-uniform branch on the weight format around the whole load)
+            const float sc = W.scale[32 * mt + jj];
 #pragma unroll
-        for (int s = 0; s < NK; ++s) wf[s] = W.at(((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3, 32 * mt + jj);
+            for (int s = 0; s < NK; ++s) wf[s] = (float)W.q[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3] * sc;
+        } else {
+#pragma unroll
+            for (int s = 0; s < NK; ++s) wf[s] = W.f[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3];
+        }
     }
     // ---- my two pixel tiles (independent chains) ----------------------------------------------------------------------
     const int perm = jj < 16 ? 2 * jj : 2 * (jj - 16) + 1;          // lane -> pixel of the tile (even | odd)
