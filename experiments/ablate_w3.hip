@@ -21,11 +21,14 @@ static float run(int B, int Wd, int T, const uint32_t *spk_in, const float *W, c
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(a);
         if (Wd >= 32)
-            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, true>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
+            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, 5>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
                                dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f);
-        else
-            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, false>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
-                               dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f);
+        else {
+#define W3_NARROW(LW_) hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, LW_>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr, \
+                               dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f)
+            if (logW == 4) W3_NARROW(4); else if (logW == 3) W3_NARROW(3); else if (logW == 2) W3_NARROW(2); else W3_NARROW(1);
+#undef W3_NARROW
+        }
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms;

@@ -45,12 +45,14 @@ constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 //     channels of a fragment read on 64 different banks.
 constexpr int W3_NPOS = 386;
 
-// WIDE: W >= 32 — a thread's 32 trace pixels lie in one row, their LDS offsets are immediates (for narrower planes every
-// element adds a wave-uniform row term: two more instructions per access)
+// LW: log2 of the plane width W, as a template parameter — 5 stands for every W >= 32 (WIDE: a thread's 32 trace pixels lie
+// in one row), 4 .. 1 are W = 16 .. 2, where pixel i of a thread sits i >> LW rows further on: with LW a compile-time
+// constant that row term is part of the immediate offset of every trace access (round 3; as a runtime value it cost an
+// address add per access — 64 VALU instructions per wave and step on the narrow layers).  The launcher maps the runtime width.
 // OUT bit0: pooled pv, bit1: un-pooled v, bit2 (with bit0): the pooled map is written BEFORE the sigmoid (dcll_layer_opts
 // pv_presigmoid: max-pooled v; the readout applies the sigmoid) — two quarter-rate transcendentals and two more VALU
 // instructions per value off the pipe this kernel shares with its MFMAs
-template <int CIN, bool REFRACTORY, int OUT, bool WIDE>
+template <int CIN, bool REFRACTORY, int OUT, int LW>
 __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
                                                      const dcll_wsrc W, const float *__restrict__ bias,
                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // images fit (2 x 74.8 KB), double-buffered by step parity: the traces of step t+1 are written into the other image
     // right after a wave's own chains of step t — one barrier per step instead of two, and the waves of a SIMD drift apart
     // (one in its trace / epilogue phase while the other issues MFMAs).
+    constexpr bool WIDE = LW >= 5;
     constexpr bool DB = WIDE && CIN == 64;
     constexpr int PST = CIN == 1 ? 1 : 66;              // floats per padded pixel position
     constexpr int IMG = (DB ? 266 : W3_NPOS) * PST + 8;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         e0[i] = tvalid ? eps0_g[sbase + i] : 0.0f;
-        if (tvalid) img[loff0 + (i + (WIDE ? 0 : (i >> logW))) * PST] = eps1_g[sbase + i];
+        if (tvalid) img[loff0 + (i + (WIDE ? 0 : (i >> LW))) * PST] = eps1_g[sbase + i];
     }
 
     // ---- weights of my output-channel tile, stationary: A[co = 32 mt + jj][k] ----------------------------------------
@@ -148,15 +151,15 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // flight would hold 32 more registers on top of weights + accumulators + states)
     auto trace_step = [&](const uint32_t wd, const int cl, const int src, const int dst) {
         const int pix0 = 32 * mtile + (CIN == 1 ? (tid & 31) : 0);          // my first pixel inside the sample plane
-        int lb = loff0, lw = logW;
+        int lb = loff0;
         // opaque per step: keeps the 32 element addresses (and their 32 wave-uniform row terms) out of loop-invariant
         // registers — they are two instructions each to recompute
-        asm volatile("" : "+v"(lb), "+s"(lw));
+        asm volatile("" : "+v"(lb));
 #pragma unroll
         for (int i0 = 0; i0 < NE; i0 += 8) {
             float e1[8];
 #pragma unroll
-            for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[src + lb + (i + (WIDE ? 0 : (i >> lw))) * PST];
+            for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[src + lb + (i + (WIDE ? 0 : (i >> LW))) * PST];
 #pragma unroll
             for (int i = i0; i < i0 + 8 && i < NE; ++i) {
                 if (CIN == 1) {
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                     const float dd = e0[i] * tm;
                     e1[i - i0] = cc + dd;
                 }
-                if (tvalid) img[dst + lb + (i + (WIDE ? 0 : (i >> lw))) * PST] = e1[i - i0];
+                if (tvalid) img[dst + lb + (i + (WIDE ? 0 : (i >> LW))) * PST] = e1[i - i0];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     for (int i = 0; i < NE; ++i) {
         if (tvalid) {
             eps0_g[sbase + i] = e0[i];
-            eps1_g[sbase + i] = img[fin + loff0 + (i + (WIDE ? 0 : (i >> logW))) * PST];
+            eps1_g[sbase + i] = img[fin + loff0 + (i + (WIDE ? 0 : (i >> LW))) * PST];
         }
     }
     if (REFRACTORY) {
@@ -335,7 +338,15 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, b, tau4,    \
                        eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp)
 #define DCLL_LAUNCH_W3(C, R, O)                                                                                         \
-    do { if (logW >= 5) DCLL_LAUNCH_W3W(C, R, O, true); else DCLL_LAUNCH_W3W(C, R, O, false); } while (0)
+    do {                                                                                                                \
+        switch (logW) {                                                                                                 \
+        case 1: DCLL_LAUNCH_W3W(C, R, O, 1); break;                                                                     \
+        case 2: DCLL_LAUNCH_W3W(C, R, O, 2); break;                                                                     \
+        case 3: DCLL_LAUNCH_W3W(C, R, O, 3); break;                                                                     \
+        case 4: DCLL_LAUNCH_W3W(C, R, O, 4); break;                                                                     \
+        default: DCLL_LAUNCH_W3W(C, R, O, 5); break;                                                                    \
+        }                                                                                                               \
+    } while (0)
 #define DCLL_LAUNCH_W3O(C, R)                                                                                           \
     switch (out) {                                                                                                      \
     case 0: DCLL_LAUNCH_W3(C, R, 0); break;                                                                              \
