@@ -4,6 +4,7 @@
 //  compare code-generation variants.)
 #include "../snn_modulation_classification_amd/csrc/dcll_seq_w3.hip"
 #include <vector>
+#include <algorithm>
 #include <stdlib.h>
 
 char *dcll_err_buf(void) { static char b[512]; return b; }
@@ -21,10 +22,10 @@ static float run(int B, int Wd, int T, const uint32_t *spk_in, const float *W, c
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(a);
         if (Wd >= 32)
-            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, 5>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
+            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, 5, true>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
                                dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f);
         else {
-#define W3_NARROW(LW_) hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, LW_>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr, \
+#define W3_NARROW(LW_) hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, LW_, true>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr, \
                                dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f)
             if (logW == 4) W3_NARROW(4); else if (logW == 3) W3_NARROW(3); else if (logW == 2) W3_NARROW(2); else W3_NARROW(1);
 #undef W3_NARROW
@@ -44,7 +45,10 @@ int main(int argc, char **argv)
     const long HW = 16L * Wd, nin = (long)B * 64 * HW, nsp = (long)T * B * 64 * (HW / 32);
     std::vector<uint32_t> hs(nsp);
     srand(1);
-    for (auto &x : hs) { uint32_t v = 0; for (int i = 0; i < 32; ++i) v |= (uint32_t)((rand() % 100) < 8) << i; x = v; }
+    // 8 % spike density; a 1 Mi-word pattern repeated (rand() per bit over 1e9 words took minutes of host time at B = 4096)
+    const size_t npat = std::min<size_t>(hs.size(), 1u << 20);
+    for (size_t k = 0; k < npat; ++k) { uint32_t v = 0; for (int i = 0; i < 32; ++i) v |= (uint32_t)((rand() % 100) < 8) << i; hs[k] = v; }
+    for (size_t k = npat; k < hs.size(); ++k) hs[k] = hs[k - npat];
     std::vector<float> hw(64 * 64 * 3), hb(64), ht(4 * 64);
     for (auto &x : hw) x = (rand() / (float)RAND_MAX - 0.5f) * 1e-5f;
     for (auto &x : hb) x = (rand() / (float)RAND_MAX - 0.5f) * 1e-3f;
@@ -63,5 +67,16 @@ int main(int argc, char **argv)
     const float ms = run(B, Wd, T, spk_in, W, bias, tau4, e0, e1, arp, spk_out, pv, 4);
     printf("k_lif_seq_w3<64> B=%d W=%d T=%d: %.2f ms = %.1f %% of the fp32-MFMA peak (ideal at 157.3 TF: %.2f ms)\n", B, Wd, T, ms,
            100.0 * ideal / ms, ideal);
+#ifdef W3_STAMPS
+    // phases of workgroup 0, summed over the launches of run(): cycles per step and wave (s_memtime ticks at 100 MHz)
+    unsigned long long st[8][8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(w3_stamps), sizeof(st));
+    const char *nm[8] = {"chain A", "epilogue A", "chain B", "epilogue B", "trace + spike words", "barrier", "barrier (narrow, 1st)", ""};
+    for (int w = 0; w < 8; ++w) {
+        printf("wave %d:", w);
+        for (int p = 0; p < 7; ++p) printf("  %s %.0f", nm[p], st[w][p] / (4.0 * T));
+        printf("   [memtime ticks per step]\n");
+    }
+#endif
     return 0;
 }

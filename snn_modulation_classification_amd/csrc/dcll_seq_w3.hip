@@ -30,9 +30,29 @@
 #include "dcll_internal.h"
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// Stores of the epilogue as buffer stores: a 128-bit descriptor per tile and step (base = the tile's first output row, in
+// SGPRs) + 32-bit scalar offset (channel plane, walks by scalar adds) + 32-bit lane byte offset — no 64-bit address per
+// store (left to the compiler, the flat form cost two scalar adds per store or, in some instantiations, a 64-bit VECTOR
+// sum: v_mad_i64_i32 + v_lshl_add_u64).  Offsets stay below 2^31: 64 channel planes of < 2^24 pixels.
+typedef int i32x4_rsrc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ long uniform_long(long x)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ auto tile_rsrc(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)uniform_long((long)base), 0, 0x7fffffff, 0x00020000);
+}
 constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 #ifndef W3_EPG
 #define W3_EPG 2                    // register pairs per epilogue group
+#endif
+#ifndef W3_ORDER
+#define W3_ORDER 0                  // 0: chain A, epilogue A, chain B, epilogue B; 1: both chains, then both epilogues
+#endif
+#ifndef W3_TRG
+#define W3_TRG 8                    // trace elements per group (read - update - write)
 #endif
 // eps1 image in LDS, PIXEL-major: element (channel ci, padded pixel position q) at q * PST + ci, PST = 66 (c_in = 64) —
 //   - q = p + (p >> log2 W) + 1 for pixel p of the workgroup's 256: one shared zero position between rows = the conv's
@@ -45,6 +65,20 @@ constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 //     channels of a fragment read on 64 different banks.
 constexpr int W3_NPOS = 386;
 
+// experiments/ablate_w3 -DW3_STAMPS: s_memtime per wave and phase of workgroup 0, summed over the steps (not in the product)
+#ifdef W3_STAMPS
+__device__ unsigned long long w3_stamps[8][8];
+// (summed in LDS with a return-less ds_add: a global read-modify-write per stamp costs more than the phases it measures)
+#define W3_STAMP(ph)                                                                                                    \
+    do {                                                                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                   \
+        if (lane == 0) __hip_atomic_fetch_add(&lstamps[w][ph], now_ - stamp_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        stamp_ = now_;                                                                                                  \
+    } while (0)
+#else
+#define W3_STAMP(ph)
+#endif
+
 // LW: log2 of the plane width W, as a template parameter — 5 stands for every W >= 32 (WIDE: a thread's 32 trace pixels lie
 // in one row), 4 .. 1 are W = 16 .. 2, where pixel i of a thread sits i >> LW rows further on: with LW a compile-time
 // constant that row term is part of the immediate offset of every trace access (round 3; as a runtime value it cost an
@@ -52,7 +86,10 @@ constexpr int W3_NPOS = 386;
 // OUT bit0: pooled pv, bit1: un-pooled v, bit2 (with bit0): the pooled map is written BEFORE the sigmoid (dcll_layer_opts
 // pv_presigmoid: max-pooled v; the readout applies the sigmoid) — two quarter-rate transcendentals and two more VALU
 // instructions per value off the pipe this kernel shares with its MFMAs
-template <int CIN, bool REFRACTORY, int OUT, int LW>
+// FULL: every workgroup has its 8 tiles (B * HW / 32 is a multiple of 8 — always so when HW >= 256): the validity of a tile
+// is a compile-time constant, and the ~100 scalar instructions per wave and step that predicate the stores on it (exec
+// masks, branches around every store group) are gone from the time loop.
+template <int CIN, bool REFRACTORY, int OUT, int LW, bool FULL>
 __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
                                                      const dcll_wsrc W, const float *__restrict__ bias,
                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
@@ -89,7 +126,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // CIN = 1:  threads 0..255 own one pixel each of the single channel
     const int ci_t = CIN == 1 ? 0 : lane, wq = CIN == 1 ? tid >> 5 : w;
     const long Gt = G0 + wq;
-    const bool tvalid = Gt < ntot && (CIN == 64 || tid < W3_PX);
+    const bool tvalid = (FULL || Gt < ntot) && (CIN == 64 || tid < W3_PX);
     const long bt = tvalid ? Gt / NTS : 0;
     const int mtile = tvalid ? (int)(Gt % NTS) : 0;
     const float ta = tau4[0 * CIN + ci_t], tm = tau4[1 * CIN + ci_t], tas = tau4[2 * CIN + ci_t], ts = tau4[3 * CIN + ci_t];
@@ -125,9 +162,12 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // ---- my two pixel tiles (independent chains) ----------------------------------------------------------------------
     const int perm = jj < 16 ? 2 * jj : 2 * (jj - 16) + 1;          // lane -> pixel of the tile (even | odd)
     const long GA = G0 + 2 * g;
-    const bool validA = GA < ntot, validB = GA + 1 < ntot;
-    const long bA = validA ? GA / NTS : 0, bB = validB ? (GA + 1) / NTS : 0;
-    const int mA = validA ? (int)(GA % NTS) : 0, mB = validB ? (int)((GA + 1) % NTS) : 0;
+    const bool validA = FULL || GA < ntot, validB = FULL || GA + 1 < ntot;
+    // (wave-uniform by construction; the 64-bit division leaves them in vector registers — moved to SGPRs here, so that
+    //  every address term derived from them in the time loop is scalar)
+    const long bA = uniform_long(validA ? GA / NTS : 0), bB = uniform_long(validB ? (GA + 1) / NTS : 0);
+    const int mA = __builtin_amdgcn_readfirstlane(validA ? (int)(GA % NTS) : 0);
+    const int mB = __builtin_amdgcn_readfirstlane(validB ? (int)((GA + 1) % NTS) : 0);
     const int pA = 64 * g + perm, pB = pA + 32;
     // B-fragment lane base: CIN = 64: channel h of the pair; CIN = 1: tap h of the pair (tap kx reads x + kx - 1)
     const int baseA = h + (pA + (pA >> logW)) * PST, baseB = h + (pB + (pB >> logW)) * PST;
@@ -152,30 +192,38 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     auto trace_step = [&](const uint32_t wd, const int cl, const int src, const int dst) {
         const int pix0 = 32 * mtile + (CIN == 1 ? (tid & 31) : 0);          // my first pixel inside the sample plane
         int lb = loff0;
+        const f32x2 ta2 = {ta, ta}, tm2 = {tm, tm}, tas2 = {tas, tas};
         // opaque per step: keeps the 32 element addresses (and their 32 wave-uniform row terms) out of loop-invariant
         // registers — they are two instructions each to recompute
         asm volatile("" : "+v"(lb));
 #pragma unroll
-        for (int i0 = 0; i0 < NE; i0 += 8) {
-            float e1[8];
+        for (int i0 = 0; i0 < NE; i0 += W3_TRG) {
+            float e1[W3_TRG];
 #pragma unroll
-            for (int i = i0; i < i0 + 8 && i < NE; ++i) e1[i - i0] = img[src + lb + (i + (WIDE ? 0 : (i >> LW))) * PST];
+            for (int i = i0; i < i0 + W3_TRG && i < NE; ++i) e1[i - i0] = img[src + lb + (i + (WIDE ? 0 : (i >> LW))) * PST];
+            if (CIN == 1) {
+                trace_update(cl == pix0 ? 1.0f : 0.0f, ta, tm, tas, ts, e0[0], e1[0]);
+            } else {
+                // x * tau_s for x in {0, 1} = the sign-extended input bit AND tau_s (v_bfe_i32 + v_and_b32: exact), then
+                // the two trace lines of dcll/pytorch_libdcll.py:493-494, every op rounded separately — on PAIRS of
+                // elements: v_pk_mul_f32 / v_pk_add_f32 are the same IEEE operations at two per lane and issue
 #pragma unroll
-            for (int i = i0; i < i0 + 8 && i < NE; ++i) {
-                if (CIN == 1) {
-                    trace_update(cl == pix0 ? 1.0f : 0.0f, ta, tm, tas, ts, e0[i], e1[i - i0]);
-                } else {
-                    // x * tau_s for x in {0, 1} = the sign-extended input bit AND tau_s (v_bfe_i32 + v_and_b32: exact), then
-                    // the two trace lines of dcll/pytorch_libdcll.py:493-494, every op rounded separately
-                    const float a = __int_as_float(__builtin_amdgcn_sbfe((int)wd, i, 1) & __float_as_int(ts));
-                    const float bb = tas * e0[i];
-                    e0[i] = a + bb;
-                    const float cc = ta * e1[i - i0];
-                    const float dd = e0[i] * tm;
-                    e1[i - i0] = cc + dd;
+                for (int i = i0; i < i0 + W3_TRG && i < NE; i += 2) {
+                    const f32x2 a = {__int_as_float(__builtin_amdgcn_sbfe((int)wd, i, 1) & __float_as_int(ts)),
+                                     __int_as_float(__builtin_amdgcn_sbfe((int)wd, i + 1, 1) & __float_as_int(ts))};
+                    f32x2 p0 = {e0[i], e0[i + 1]}, p1 = {e1[i - i0], e1[i - i0 + 1]};
+                    const f32x2 bb = tas2 * p0;
+                    p0 = a + bb;
+                    const f32x2 cc = ta2 * p1;
+                    const f32x2 dd = p0 * tm2;
+                    p1 = cc + dd;
+                    e0[i] = p0[0], e0[i + 1] = p0[1];
+                    e1[i - i0] = p1[0], e1[i - i0 + 1] = p1[1];
                 }
-                if (tvalid) img[dst + lb + (i + (WIDE ? 0 : (i >> LW))) * PST] = e1[i - i0];
             }
+#pragma unroll
+            for (int i = i0; i < i0 + W3_TRG && i < NE; ++i)
+                if (tvalid) img[dst + lb + (i + (WIDE ? 0 : (i >> LW))) * PST] = e1[i - i0];
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -183,11 +231,19 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
         trace_step(word, cell, 0, 0);
         lds_barrier();
     }
+#ifdef W3_STAMPS
+    __shared__ unsigned long long lstamps[8][8];
+    if (tid < 64) lstamps[tid >> 3][tid & 7] = 0;
+    __syncthreads();
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < T; ++t) {
         const int cur = DB ? (t & 1) * IMG : 0;             // image the chains of this step read
         if (!DB) {
             trace_step(word, cell, 0, 0);
+            W3_STAMP(4);
             lds_barrier();
+            W3_STAMP(6);
         }
         // next step's input: lands during the chains
         if (t + 1 < T) {
@@ -198,8 +254,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
         //      (two interleaved chains + a joint epilogue need 32 accumulator registers and twice the temporaries: with
         //      96 weight and 64 state registers that spilled ~160 VGPRs) ----
         int vwA = 0, vwB = 0;
-        auto do_tile = [&](const int base, float (&arp)[16], const bool valid, const long bb, const int mm, int &vw) {
-            f32x16 acc;
+        auto chain = [&](const int base, f32x16 &acc, const int st0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
             if (CIN == 1) {
@@ -223,32 +278,48 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            W3_STAMP(st0);
+        };
+        auto epilogue = [&](f32x16 &acc, float (&arp)[16], const bool valid, const long bb, const int mm, int &vw, const int st0) {
             // epilogue: refractory trace, threshold, (1,2) max-pool, sigmoid, pooled spike half-words — two accumulator
             // registers (channels cr, cr + 1) at a time.  Stores as wave-uniform base (per pair) + 32-bit lane offset.
             const long row = ((long)t * B + bb) * 64 + 32 * mt;
-            const char *pvb = (const char *)(pv_out + row * HW2), *vb = (const char *)(v_out + row * HW);
             // lane BYTE offsets.  Un-pooled v: value r of lane (h, jj) is channel cr(r) + 4 h, pixel perm(jj).  Pooled map
             // after the row swap: lane row rw = lane >> 4 holds channel cr + (rw & 1) + 4 (rw >> 1), pooled pixel lane & 15.
             const int rw = lane >> 4;
             unsigned lp = 4u * ((4 * (rw >> 1) + (rw & 1)) * HW2 + 16 * mm + (lane & 15)), lv = 4u * (4 * h * HW + 32 * mm + perm);
-            int hw2 = 4 * HW2, hw1 = 4 * HW;
-            // opaque per step: otherwise the per-value store addresses derived from them are hoisted out of the time loop
-            asm volatile("" : "+v"(lp), "+v"(lv), "+s"(hw2), "+s"(hw1));
+            // (lane offsets opaque per step: otherwise the per-value store addresses derived from them are hoisted out of the
+            //  time loop into registers).  The scalar bases walk from channel to channel: cr = 0 2 8 10 16 18 24 26 — steps of
+            //  2 and 6 channel planes, two scalar adds per store.
+            int d2p = 8 * HW2, d6p = 24 * HW2, d1v = 4 * HW, d5v = 20 * HW, pp = 0, vp = 0;
+            asm volatile("" : "+v"(lp), "+v"(lv), "+s"(d2p), "+s"(d6p), "+s"(d1v), "+s"(d5v), "+s"(pp), "+s"(vp));
+            const auto prs = tile_rsrc(pv_out + row * HW2), vrs = tile_rsrc(v_out + row * HW);
             static_for<0, 16 / (2 * W3_EPG)>([&](auto gc) {             // W3_EPG pairs at a time: keeps the temporaries few
                 constexpr int r0 = 2 * W3_EPG * decltype(gc)::value;
                 float pm[W3_EPG];
+                unsigned long long mk[W3_EPG];
                 int &vwr = vw;          // (named here: the asm operand of the inner generic lambda alone does not capture it)
                 static_for<0, W3_EPG>([&](auto kc) {
                     constexpr int k = decltype(kc)::value, r = r0 + 2 * k, cr = (r & 3) + 8 * (r >> 2);
                     float vx = acc[r], vy = acc[r + 1];
-                    bool sx, sy;
-                    if (REFRACTORY) {
-                        vx = refractory(acc[r], arp[r], alpharp, wrp, sx);
-                        vy = refractory(acc[r + 1], arp[r + 1], alpharp, wrp, sy);
+                    if (REFRACTORY) {       // refractory() of dcll_internal.h on the register pair (packed fp32: same IEEE ops)
+                        const f32x2 al2 = {alpharp, alpharp};
+                        const f32x2 a2 = al2 * f32x2{arp[r], arp[r + 1]};
+                        const f32x2 v2 = f32x2{acc[r], acc[r + 1]} + a2;
+                        vx = v2[0], vy = v2[1];
+                        const f32x2 sw2 = {vx > 0.0f ? wrp : 0.0f, vy > 0.0f ? wrp : 0.0f};        // s * wrp, exact
+                        const f32x2 n2 = a2 - sw2;
+                        arp[r] = n2[0], arp[r + 1] = n2[1];
+                        // pinned here: the new arp is not read before the next step, and the compiler would otherwise sink
+                        // all 32 updates (cmp, select, subtract) of both tiles to the end of the loop body — v and a of
+                        // every value live across the second chain and the trace phase (64 registers)
+                        asm volatile("" : "+v"(arp[r]), "+v"(arp[r + 1]), "+v"(vx), "+v"(vy));
                     }
-                    if ((OUT & 2) && valid) {
-                        *(float *)(vb + (long)cr * hw1 + lv) = vx;
-                        *(float *)(vb + (long)(cr + 1) * hw1 + lv) = vy;
+                    if ((OUT & 2) && valid) {           // channels cr, cr + 1; then on to the next pair (cr + 2 | cr + 6)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vx), vrs, lv, vp, 0);
+                        vp += d1v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vy), vrs, lv, vp, 0);
+                        vp += (r & 2) ? d5v : d1v;
                     }
                     // rows (16 lanes): vx = [even px | odd px | even px | odd px] of channels cr (h = 0), cr + 4 (h = 1);
                     // after the swap sw[0] = [vx.row0, vy.row0, vx.row2, vy.row2], sw[1] = [vx.row1, vy.row1, vx.row3, vy.row3]:
@@ -258,25 +329,60 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
                     asm("v_max_f32 %0, %1, %2" : "=v"(pm[k]) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
                     // pooled spike = max(s_a, s_b) = (pooled v > 0), exactly: bits 0..15 channel cr, 16..31 channel cr + 1
                     // (h = 0), 32..63 the same for h = 1 -> parked in lanes k' and 32 + k' of vw (k' = pair index)
-                    const unsigned long long mk = __ballot(pm[k] > 0.0f);
-                    int &vwi = vwr;
-                    // (wait states as the compiler places them around its own v_writelane, see k_lif_seq_c1)
-                    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
-                        : "+v"(vwi) : "s"((uint32_t)mk), "s"((uint32_t)(mk >> 32)), "n"(r / 2), "n"(32 + r / 2));
+                    mk[k] = __ballot(pm[k] > 0.0f);
+                    if (W3_EPG != 2 && W3_EPG != 4) {
+                        int &vwi = vwr;
+                        // (wait states as the compiler places them around its own v_writelane, see k_lif_seq_c1)
+                        asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, %4"
+                            : "+v"(vwi) : "s"((uint32_t)mk[k]), "s"((uint32_t)(mk[k] >> 32)), "n"(r / 2), "n"(32 + r / 2));
+                    }
                 });
+                if (W3_EPG == 2) {
+                    // the four masks of the group in one block: s_nop 1 covers the two wait states a v_writelane needs behind
+                    // the v_cmp that wrote its SGPR, whichever of the two compares the compiler placed last
+                    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\t"
+                        "v_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8"
+                        : "+v"(vwr) : "s"((uint32_t)mk[0]), "s"((uint32_t)(mk[0] >> 32)), "s"((uint32_t)mk[W3_EPG - 1]),
+                          "s"((uint32_t)(mk[W3_EPG - 1] >> 32)), "n"(r0 / 2), "n"(32 + r0 / 2), "n"(r0 / 2 + 1), "n"(33 + r0 / 2));
+                }
+                if (W3_EPG == 4) {
+                    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\t"
+                        "v_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
+                        "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\t"
+                        "v_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
+                        : "+v"(vwr) : "s"((uint32_t)mk[0]), "s"((uint32_t)(mk[0] >> 32)), "s"((uint32_t)mk[1 % W3_EPG]),
+                          "s"((uint32_t)(mk[1 % W3_EPG] >> 32)), "s"((uint32_t)mk[2 % W3_EPG]), "s"((uint32_t)(mk[2 % W3_EPG] >> 32)),
+                          "s"((uint32_t)mk[3 % W3_EPG]), "s"((uint32_t)(mk[3 % W3_EPG] >> 32)),
+                          "n"(r0 / 2), "n"(32 + r0 / 2), "n"(r0 / 2 + 1), "n"(33 + r0 / 2), "n"(r0 / 2 + 2), "n"(34 + r0 / 2),
+                          "n"(r0 / 2 + 3), "n"(35 + r0 / 2));
+                }
                 if ((OUT & 1) && valid) {
                     static_for<0, W3_EPG>([&](auto kc) {
                         constexpr int k = decltype(kc)::value, r = r0 + 2 * k, cr = (r & 3) + 8 * (r >> 2);
                         // sigmoid is monotone: sigmoid(max-pool(v)) == max-pool(sigmoid(v)) (up to its last ulp; pv is not
                         // bit-pinned) — half as many transcendentals; (OUT & 4): the readout applies it (pv_presigmoid)
-                        *(float *)(pvb + (long)cr * hw2 + lp) = (OUT & 4) ? pm[k] : sigmoidf_dev(pm[k]);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((OUT & 4) ? pm[k] : sigmoidf_dev(pm[k])), prs, lp, pp, 0);
+                        pp += (r & 2) ? d6p : d2p;
                     });
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            W3_STAMP(st0);
         };
-        do_tile(baseA, arpA, validA, bA, mA, vwA);
-        do_tile(baseB, arpB, validB, bB, mB, vwB);
+        f32x16 accA, accB;
+#if W3_ORDER == 0
+        chain(baseA, accA, 0);
+        epilogue(accA, arpA, validA, bA, mA, vwA, 1);
+        chain(baseB, accB, 2);
+        epilogue(accB, arpB, validB, bB, mB, vwB, 3);
+#else
+        // both chains first: a wave running a dependent MFMA chain owns its SIMD (the other wave gets one instruction per
+        // MFMA), so a wave whose second chain waits for its own first epilogue leaves the matrix pipe idle
+        chain(baseA, accA, 0);
+        chain(baseB, accB, 2);
+        epilogue(accA, arpA, validA, bA, mA, vwA, 1);
+        epilogue(accB, arpB, validB, bB, mB, vwB, 3);
+#endif
         // lanes q / 32 + q (q < 8) hold, for the channel pair cr(2q), cr(2q) + 1 (+ 4 h), the pooled half-words of my two
         // tiles as (channel cr | channel cr + 1 << 16): regrouped into the two 32-bit words (tile A | tile B << 16) of the
         // next layer's input
@@ -288,8 +394,14 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
             wp[(cq + 1) * (unsigned)NW2] = ((uint32_t)vwA >> 16) | ((uint32_t)vwB & 0xffff0000u);
         }
         if (DB && t + 1 < T) trace_step(word, cell, cur, cur ^ IMG);         // step t+1's traces into the other image
+        W3_STAMP(4);
         lds_barrier();
+        W3_STAMP(5);
     }
+#ifdef W3_STAMPS
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < 64) w3_stamps[tid >> 3][tid & 7] += lstamps[tid >> 3][tid & 7];
+#endif
     const int fin = DB ? ((T - 1) & 1) * IMG : 0;           // image holding eps1 of the last step
     // ---- state back to HBM ----
 #pragma unroll
@@ -335,8 +447,14 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x tiles exceeds the grid limit");
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0) | ((pv_out && presigmoid) ? 4 : 0);
 #define DCLL_LAUNCH_W3W(C, R, O, WD)                                                                                    \
-    hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, b, tau4,    \
-                       eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp)
+    do {                                                                                                                \
+        if (ntile % W3_NT == 0)                                                                                         \
+            hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD, true>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, \
+                               b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp);  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD, false>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, \
+                               b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp);  \
+    } while (0)
 #define DCLL_LAUNCH_W3(C, R, O)                                                                                         \
     do {                                                                                                                \
         switch (logW) {                                                                                                 \

@@ -848,14 +848,15 @@ def test_readout_direct_forms(dev, rows, K, N):
 @pytest.mark.parametrize("cin,hw,wrp,T,B,zero_state", [(64, (16, 64), 1.0, 7, 2, False), (64, (16, 16), 1.0, 6, 3, False),
                                                        (64, (16, 4), 0.0, 5, 3, True), (64, (16, 2), 1.0, 6, 5, False),
                                                        (64, (4, 32), 1.0, 5, 3, False), (64, (16, 8), 1.0, 7, 5, False), (64, (16, 16), 0.0, 9, 2, False),
+                                                       (64, (16, 8), 1.0, 5, 4, False), (64, (16, 4), 1.0, 5, 4, False), (64, (16, 2), 1.0, 5, 8, False),
                                                        (1, (16, 128), 1.0, 9, 2, False),
                                                        (1, (2, 128), 0.0, 6, 3, True)])
 def test_sequence_w3_vs_oracle(dev, cin, hw, wrp, T, B, zero_state):
     """k_lif_seq_w3 — the fused all-T kernel of the radio_ml_conv_ref.yaml geometry (64 channels, (1,3) kernel, pad
     (0,1), max-pool (1,2); pixel tiles over the flattened plane, pooling pairs in lanes j / j+16) — == C oracle
     stepping, bit for bit: un-pooled v, POOLED spikes (packed) and the final state; pooled pv within the sigmoid
-    tolerance.  Widths from 64 down to 2 (a tile = 1/2 ... 16 rows), ragged workgroups (B x tiles not a multiple of 8),
-    first layer from cell indices."""
+    tolerance.  Widths from 64 down to 2 (a tile = 1/2 ... 16 rows), ragged workgroups (B x tiles not a multiple of 8)
+    and full ones (the kernel's FULL specialisation) at every narrow width, first layer from cell indices."""
     from snn_modulation_classification_amd import ops
     from oracle import c_oracle as C
     rng = np.random.RandomState(31)
