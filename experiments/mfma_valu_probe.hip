@@ -65,14 +65,14 @@ __global__ __launch_bounds__(512) void k_probe(unsigned long long *out, float *s
 // LDS; waves 4-7: groups of instructions (KIND) until the flag is up, counting them.
 //   KIND 0: 1 v_add_f32   1: v_add_f32 + s_nop 0   2: v_add_f32 + 2 s_add_u32   3: v_add_f32 + global_store_dword
 //   KIND 4: 1 s_add_u32 only   5: v_cmp + v_cndmask (VALU -> VCC -> VALU)   6: 2 independent v_add_f32
-template <int KIND>
+template <int KIND, int NACC = 1>
 __global__ __launch_bounds__(512) void k_share(unsigned long long *out, float *sink, float *dump, int iters)
 {
     __shared__ volatile int flag[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x < 4) flag[threadIdx.x] = 0;
-    f32x16 acc;
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    f32x16 acc, acc2;
+    for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
     float v[8];
     for (int k = 0; k < 8; ++k) v[k] = lane * 1e-3f + k;
     const float x = 1.0f + lane * 1e-6f, y = 0.5f, c = 1e-6f;
@@ -80,13 +80,18 @@ __global__ __launch_bounds__(512) void k_share(unsigned long long *out, float *s
     unsigned long long groups = 0;
     float *dp = dump + (blockIdx.x * 512 + threadIdx.x);
     __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
     if (w < 4) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+            for (int u = 0; u < 32; ++u) {
+                if (NACC % 10 == 2 && (u & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+            }
         }
-        if (lane == 0) flag[w] = 1;
+        if (lane == 0) { flag[w] = 1; out[blockIdx.x * 8 + w] = __builtin_readcyclecounter() - t0; }
     } else {
+        if (NACC >= 10) __builtin_amdgcn_s_setprio(3);      // NACC 11 / 12: as 1 / 2 with the second wave at the highest priority
         while (flag[w - 4] == 0) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -102,27 +107,29 @@ __global__ __launch_bounds__(512) void k_share(unsigned long long *out, float *s
         }
     }
     float s = sc;
-    for (int r = 0; r < 16; ++r) s += acc[r];
+    for (int r = 0; r < 16; ++r) s += acc[r] + acc2[r];
     for (int k = 0; k < 8; ++k) s += v[k];
     if (s == 12345.678f) sink[0] = s;
-    if (lane == 0) out[blockIdx.x * 8 + w] = groups;
+    if (lane == 0 && w >= 4) out[blockIdx.x * 8 + w] = groups;
 }
 
-template <int KIND>
+template <int KIND, int NACC = 1>
 static void run_share(int iters, const char *what)
 {
     const int nwg = 256;
     unsigned long long *out; float *sink, *dump;
     hipMalloc(&out, (size_t)nwg * 8 * 8); hipMalloc(&sink, 16); hipMalloc(&dump, (size_t)nwg * 512 * 4);
     hipMemset(out, 0, (size_t)nwg * 8 * 8);
-    hipLaunchKernelGGL((k_share<KIND>), dim3(nwg), dim3(512), 0, 0, out, sink, dump, iters);
+    hipLaunchKernelGGL((k_share<KIND, NACC>), dim3(nwg), dim3(512), 0, 0, out, sink, dump, iters);
+    if (hipDeviceSynchronize() != hipSuccess) printf("launch failed: %s\n", hipGetErrorString(hipGetLastError()));
     hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)nwg * 8);
     hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
-    double g = 0;
+    double g = 0, cyc = 0;
     for (int b = 0; b < nwg; ++b)
-        for (int w = 4; w < 8; ++w) g += h[b * 8 + w];
-    printf("second wave during the first wave's chain, groups of [%s]: %.2f groups per MFMA\n", what, g / (nwg * 4.0) / (32.0 * iters));
+        for (int w = 0; w < 8; ++w) (w < 4 ? cyc : g) += h[b * 8 + w];
+    printf("%s chain; second wave issues [%s]: chain %.1f cycles per MFMA, second wave %.2f groups per MFMA\n",
+           NACC == 2 ? "two interleaved accumulators" : NACC == 1 ? "one dependent" : NACC == 11 ? "one dependent (second wave s_setprio 3)" : "two interleaved accumulators (second wave s_setprio 3)", what, cyc / (nwg * 4.0) / (32.0 * iters), g / (nwg * 4.0) / (32.0 * iters));
     hipFree(out); hipFree(sink); hipFree(dump);
 }
 
@@ -161,6 +168,16 @@ int main()
     run<4, true, 0>(it); run<8, true, 0>(it); run<16, true, 0>(it);
     run<0, false, 2>(it); run<4, false, 2>(it); run<8, false, 2>(it); run<16, false, 2>(it);
     run<1, false, 1>(it); run<4, false, 1>(it); run<16, false, 1>(it); run<4, true, 1>(it);
+    run_share<0, 11>(it, "v_add_f32");
+    run_share<0, 12>(it, "v_add_f32");
+    run_share<5, 12>(it, "v_cmp_lt_f32 -> vcc -> v_cndmask_b32");
+    run_share<4, 12>(it, "s_add_u32");
+    run_share<0, 2>(it, "v_add_f32");
+    run_share<6, 2>(it, "2 independent v_add_f32");
+    run_share<2, 2>(it, "v_add_f32, 2 s_add_u32");
+    run_share<3, 2>(it, "v_add_f32, global_store_dword");
+    run_share<4, 2>(it, "s_add_u32");
+    run_share<5, 2>(it, "v_cmp_lt_f32 -> vcc -> v_cndmask_b32");
     run_share<0>(it, "v_add_f32");
     run_share<6>(it, "2 independent v_add_f32");
     run_share<1>(it, "v_add_f32, s_nop 0");
