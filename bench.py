@@ -160,6 +160,20 @@ def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                 "launch_ms_per_step": sum(w3_ms) / steps, "launches_per_step": len(w3_ms) / steps,
                 "algorithmic_flop_per_step": flop_w3 / steps}
+    if roof:
+        # HBM traffic of the six launches: PMC counters cannot be read from inside this process — the summary of the separate
+        # `rocprofv3 --pmc` passes of this command (profiles/collect_r03.sh ref) is used when it is for this batch
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_ref_b%d.json" % B)) as f:
+                ker = json.load(f)["kernels"]
+            w3 = {k: v for k, v in ker.items() if k.startswith("k_lif_seq_w3<64")}
+            if sum(v["launches"] for v in w3.values()) == 6:
+                roof["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in w3.values())
+                roof["traffic_unit"] = "HBM bytes per step over the six launches (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)"
+                roof["traffic_source"] = ("profiles/r03_pmc_ref_b%d.json (builder-side rocprofv3 --pmc passes of this command; "
+                                          "not measured in this run)" % B)
+        except (OSError, KeyError, ValueError):
+            pass
     kernel_ms = {k: float(np.sum([s_.elapsed_time(e_) for s_, e_ in v])) / steps for k, v in prof.items()}
     hbm = {}
     if kernel_ms.get("lif_c1"):
