@@ -218,6 +218,23 @@ def _free_port():
     return p
 
 
+def visible_gpu_count():
+    """GPUs this job may use, counted WITHOUT the HIP runtime: the DRM render nodes this process can open (a container
+    that was given one GPU of an 8-GPU host has one), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES.  Only where there is no /dev/dri torch's own device query is asked — the launcher must not
+    bring a runtime up."""
+    try:
+        nodes = [d for d in os.listdir("/dev/dri") if d.startswith("renderD")]
+    except OSError:
+        return torch.cuda.device_count()
+    n = sum(1 for d in nodes if os.access(os.path.join("/dev/dri", d), os.R_OK | os.W_OK))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_local_ranks(n, argv=None, timeout=None):
     """Start `n` fresh processes of the running script (one rank per GPU of this node) with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, wait for them and return the exit code (0 iff every rank exited 0).
@@ -229,9 +246,7 @@ def spawn_local_ranks(n, argv=None, timeout=None):
     env = dict(os.environ)
     env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # (counting devices: torch asks amdsmi / the HIP runtime's device query — no context, no stream, no allocation is
-    #  created in this process; the ranks are fresh processes either way, never forks of an initialised parent)
-    n_dev = torch.cuda.device_count()
+    n_dev = visible_gpu_count()
     if n_dev < n and "DCLL_DIST_BACKEND" not in env:
         env["DCLL_DIST_BACKEND"] = "gloo"
         print("[launcher] %d ranks on %d GPU(s): rehearsal, ranks share devices, backend gloo" % (n, n_dev),

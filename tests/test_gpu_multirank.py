@@ -11,6 +11,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import ROOT
 
@@ -179,3 +180,11 @@ def test_rccl_code_path_on_a_one_rank_group_equals_the_plain_run(tmp_path):
     assert "backend nccl" in lines["rccl"]["config"]["parallelism"] and "backend none" in lines["plain"]["config"]["parallelism"]
     assert lines["rccl"]["n_gpus"] == 1 and lines["rccl"]["value"] > 0
     assert lines["rccl"]["vote_accuracy_vs_random_labels"] == lines["plain"]["vote_accuracy_vs_random_labels"]
+
+
+@pytest.mark.gpu
+def test_launcher_counts_the_gpus_without_a_runtime():
+    """spawn_local_ranks decides "rehearsal: ranks share devices" from parallel.visible_gpu_count(), which must not bring
+    the HIP runtime up in the launcher (DRM render nodes + *_VISIBLE_DEVICES): it has to agree with what a rank sees."""
+    from snn_modulation_classification_amd import parallel
+    assert parallel.visible_gpu_count() == torch.cuda.device_count()
