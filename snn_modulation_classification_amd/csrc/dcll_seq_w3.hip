@@ -51,6 +51,13 @@ constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 #ifndef W3_ORDER
 #define W3_ORDER 0                  // 0: chain A, epilogue A, chain B, epilogue B; 1: both chains, then both epilogues
 #endif
+// experiments/ablate_w3 B W first: neither changes the first layer's 4.7 TB/s (experiments/README.md)
+#ifndef W3_DB_FIRST
+#define W3_DB_FIRST 0               // first layer (c_in = 1): two images by step parity and one barrier per step
+#endif
+#ifndef W3_WAVES_FIRST
+#define W3_WAVES_FIRST 2            // first layer: waves per SIMD the register budget allows (4 = two workgroups per CU)
+#endif
 #ifndef W3_TRG
 #define W3_TRG 8                    // trace elements per group (read - update - write)
 #endif
@@ -90,7 +97,7 @@ __device__ unsigned long long w3_stamps[8][8];
 // is a compile-time constant, and the ~100 scalar instructions per wave and step that predicate the stores on it (exec
 // masks, branches around every store group) are gone from the time loop.
 template <int CIN, bool REFRACTORY, int OUT, int LW, bool FULL>
-__global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
+__global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
                                                      const dcll_wsrc W, const float *__restrict__ bias,
                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
                                                      float *__restrict__ eps1_g, float *__restrict__ arp_g,
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_w3(const uint32_t *__restrict__
     // right after a wave's own chains of step t — one barrier per step instead of two, and the waves of a SIMD drift apart
     // (one in its trace / epilogue phase while the other issues MFMAs).
     constexpr bool WIDE = LW >= 5;
-    constexpr bool DB = WIDE && CIN == 64;
+    constexpr bool DB = WIDE && (CIN == 64 || W3_DB_FIRST);
     constexpr int PST = CIN == 1 ? 1 : 66;              // floats per padded pixel position
     constexpr int IMG = (DB ? 266 : W3_NPOS) * PST + 8;
     __shared__ __attribute__((aligned(16))) float img[(DB ? 2 : 1) * IMG];
