@@ -1564,7 +1564,11 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
     float *slots = lds + 2 * IMG_FLOATS;        // [wave][tile of the pair][16 x 64]
     float *sbias = slots + NWAVE * 2 * SLOT_FLOATS;     // the bias as a slot-shaped tile: wave 0's chain input
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // chain position w of hardware wave i: 0 1 4 5 2 3 6 7 — the two waves of a SIMD (i, i + 4) are then TWO positions apart
+    // and work, in every stage, on the tile pairs p and p + 2: one border pair (whose all-padding tap rows are skipped,
+    // below) and one inner pair on every SIMD, instead of the same pair on both
+    const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = (DBG & 4) ? wi : ((wi & 1) | ((wi & 4) >> 1) | ((wi & 2) << 1));
     const int wq = w & 3, wpar = w >> 2;        // my epilogue share: quad wq of the pair's tile wpar
     const long b = blockIdx.x;
     // Highest wave priority for the whole kernel: all eight waves carry it, so nothing changes among them, but the waves
@@ -1615,6 +1619,9 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
     // ROWF = 19 floats behind the first, which makes the B-fragment reads bank-conflict free — isolates what the 2-way
     // conflicts on three banks of the real layout cost.
     const int bbase = (4 * w + h) * CHF + (j >> 4) * ((DBG & 2) ? 16 : ROWF) + (j & 15);
+    // epilogue stores: lane byte offset inside the (8 channels x 256 pixels) block of quad wq — channel rr + 4 h, pixel
+    // 32 (2 U + wpar) + j; the (rr, U) part is an immediate of each store
+    const unsigned eoff = 4u * (4 * h * 256 + 32 * wpar + j);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -1683,10 +1690,15 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         const bool tr = active && t + 1 < T;
         //   first B-fragment row of the chains
         const int i0 = (t & 1) * IMG_FLOATS + bbase + p * 4 * ROWF;
+        // tap rows that lie in the zero padding for BOTH image rows of a tile are skipped — fmaf(w, 0, acc) == acc: the pair
+        // p = 0 (image rows 0..3) has none of tile A's tap rows ky = 0, 1 (LDS rows rho = 0, 1), the pair p = 3 none of tile
+        // B's ky = 5, 6 (rho = 7, 8): 168 instead of 196 MFMAs for those two of the four pairs
+        const bool skip = !(DBG & 4);
+        const int rl = (skip && p == 0) ? 2 : 0;        // first LDS row of my chains
         float bq[2][7];
         if (active) {
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = lds[i0 + kx];
+            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = lds[i0 + rl * ROWF + kx];
         }
         // ---- (2) trace share (dcll/pytorch_libdcll.py:493-494, every op rounded separately) ----
         if (tr) {
@@ -1705,10 +1717,12 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         // ---- (1) epilogue share ----
         if (epi) {
             const int te = qe >> 2, me = 2 * U + wpar;
-            // stores as wave-uniform base + 32-bit lane offset (+ an immediate per value): no 64-bit address VALU
-            const long ubase = (((long)te * B + b) * 32 + 8 * wq) * 256;       // channel 8 wq of this step and sample
-            float *pvb = pv_out + ubase, *vb = v_out + ubase;
-            const unsigned loff = 4 * h * 256 + 32 * me + j;                    // + rr*256 = channel rr + 8 wq + 4 h
+            // buffer stores: descriptor = channel 8 wq of this step and sample (wave-uniform, SGPRs) + the loop-invariant
+            // lane byte offset + an IMMEDIATE per value and pair (rr * 256 + 64 U floats): no address registers at all
+            // (flat stores kept a 64-bit lane pointer per U alive across the loop — with the three chain variants below
+            // they were spilled, and their reload sat in this phase)
+            const long ubase = (((long)te * B + b) * 32 + 8 * wq) * 256;
+            const auto prs = tile_rsrc(pv_out + ubase), vrs = tile_rsrc(v_out + ubase);
             uint32_t myword = 0;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -1719,10 +1733,11 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
                 const unsigned long long mk = __ballot(s);
                 const uint32_t mine = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
                 myword = (j == rr) ? mine : myword;
-                if (OUT & 1) pvb[loff + rr * 256] = sigmoidf_dev(v);
-                if (OUT & 2) vb[loff + rr * 256] = v;
+                if (OUT & 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sigmoidf_dev(v)), prs, eoff + 4u * (rr * 256 + 64 * U), 0, 0);
+                if (OUT & 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), vrs, eoff + 4u * (rr * 256 + 64 * U), 0, 0);
             }
-            if (spk_out && j < 4) (spk_out + (ubase >> 5))[(4 * h + j) * 8 + me] = myword;
+            if (spk_out && j < 4)
+                __builtin_amdgcn_raw_buffer_store_b32(myword, tile_rsrc(spk_out + (ubase >> 5)), 4u * ((4 * h + j) * 8 + wpar) + 8u * U, 0, 0);
         }
         if (DBG & 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
         // every slot read of this stage has completed before any wave writes its slots again
@@ -1734,33 +1749,45 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         fetch_trace_inputs(g + 1);
         // ---- (3) my K-slice of both chains ----
         if (active) {
-            // LDS rows 0..8 below the pair's first image row, per channel pair: row rho is tap row ky = rho of tile A
+            // LDS rows RL..RH-1 below the pair's first image row, per channel pair: row rho is tap row ky = rho of tile A
             // (rho <= 6) and tap row ky = rho - 2 of tile B (rho >= 2); next row fetched before the MFMAs of this one.
+            auto chains = [&](auto RLC, auto RHC) {
+                constexpr int RL = decltype(RLC)::value, RH = decltype(RHC)::value, NRH = RH - RL, NR = 2 * NRH;
 #pragma unroll
-            for (int r = 0; r < 18; ++r) {
-                const int cp = r / 9, rho = r % 9;
-                if (r + 1 < 18) {
-                    const int cpn = (r + 1) / 9, rhon = (r + 1) % 9;
+                for (int r = 0; r < NR; ++r) {
+                    const int cp = r / NRH, rho = RL + r % NRH;
+                    if (r + 1 < NR) {
+                        const int cpn = (r + 1) / NRH, rhon = RL + (r + 1) % NRH;
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = lds[i0 + cpn * 2 * CHF + rhon * ROWF + kx];
+                        for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = lds[i0 + cpn * 2 * CHF + rhon * ROWF + kx];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        if (rho <= 6)
+                            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][rho * 7 + kx], bq[r & 1][kx], accA, 0, 0, 0);
+                        if (rho >= 2)
+                            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][(rho - 2) * 7 + kx], bq[r & 1][kx], accB, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (cp == 1 && rho == 6 && r + 1 < NR) {     // tile A is complete (its last tap row) while B still runs
+                        f32x4 *dpa = (f32x4 *)(slots + (w * 2) * SLOT_FLOATS) + lane;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            dpa[c * 64] = f32x4{accA[4 * c + 0], accA[4 * c + 1], accA[4 * c + 2], accA[4 * c + 3]};
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    if (rho <= 6)
-                        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][rho * 7 + kx], bq[r & 1][kx], accA, 0, 0, 0);
-                    if (rho >= 2)
-                        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cp][(rho - 2) * 7 + kx], bq[r & 1][kx], accB, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (r == 15) {          // tile A is complete (its last tap row was rho = 6 of the second channel pair)
+                if (RH == 7) {          // (last pair: both tiles end with the same row)
                     f32x4 *dpa = (f32x4 *)(slots + (w * 2) * SLOT_FLOATS) + lane;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         dpa[c * 64] = f32x4{accA[4 * c + 0], accA[4 * c + 1], accA[4 * c + 2], accA[4 * c + 3]};
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            if (skip && p == 0) chains(std::integral_constant<int, 2>{}, std::integral_constant<int, 9>{});
+            else if (skip && p == 3) chains(std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{});
+            else chains(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
             f32x4 *dp = (f32x4 *)(slots + (w * 2 + 1) * SLOT_FLOATS) + lane;
 #pragma unroll
             for (int c = 0; c < 4; ++c)

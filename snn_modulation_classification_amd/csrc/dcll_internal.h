@@ -162,6 +162,19 @@ __device__ __forceinline__ float refractory(float pvmem, float &arp, float alpha
     return v;
 }
 
+// Buffer-store addressing for the epilogues of the sequence kernels: a 128-bit descriptor (base = a wave-uniform pointer, in
+// SGPRs) + 32-bit scalar or immediate offset + 32-bit lane byte offset — no 64-bit address per store and no address
+// register pairs to keep (or spill) across the time loop.  Offsets must stay below 2^31.
+__device__ __forceinline__ long uniform_long(long x)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ auto tile_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)uniform_long((long)base), 0, 0x7fffffff, 0x00020000);
+}
+
 // compile-time loop: f(std::integral_constant<int, R0>{}), ..., f(std::integral_constant<int, R1 - 1>{})
 template <int R0, int R1, class F>
 __device__ __forceinline__ void static_for(F &&f)

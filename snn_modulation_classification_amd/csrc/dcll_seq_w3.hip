@@ -30,20 +30,10 @@
 #include "dcll_internal.h"
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-// Stores of the epilogue as buffer stores: a 128-bit descriptor per tile and step (base = the tile's first output row, in
-// SGPRs) + 32-bit scalar offset (channel plane, walks by scalar adds) + 32-bit lane byte offset — no 64-bit address per
-// store (left to the compiler, the flat form cost two scalar adds per store or, in some instantiations, a 64-bit VECTOR
-// sum: v_mad_i64_i32 + v_lshl_add_u64).  Offsets stay below 2^31: 64 channel planes of < 2^24 pixels.
-typedef int i32x4_rsrc __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ long uniform_long(long x)
-{
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)x >> 32));
-    return (long)(((unsigned long)hi << 32) | lo);
-}
-__device__ __forceinline__ auto tile_rsrc(const float *base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc((void *)uniform_long((long)base), 0, 0x7fffffff, 0x00020000);
-}
+// Stores of the epilogue as buffer stores (tile_rsrc, dcll_internal.h): a 128-bit descriptor per tile and step (base = the
+// tile's first output row, in SGPRs) + 32-bit scalar offset (channel plane, walks by scalar adds) + 32-bit lane byte offset —
+// no 64-bit address per store (left to the compiler, the flat form cost two scalar adds per store or, in some
+// instantiations, a 64-bit VECTOR sum: v_mad_i64_i32 + v_lshl_add_u64).  Offsets stay below 2^31: 64 planes of < 2^24 pixels.
 constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 #ifndef W3_EPG
 #define W3_EPG 2                    // register pairs per epilogue group
