@@ -437,6 +437,12 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)",
                          "avg_launch_ms": avg_c32_s * 1e3, "launches": len(c32_ms),
                          "algorithmic_flop_per_launch": flop_per_launch,
+                         # the 16x16 kernel skips the tap rows that lie in the zero padding for both rows of a border
+                         # tile (4 of the 56 (tile, tap row) combinations: fmaf(w, 0, acc) == acc): what the matrix pipe
+                         # executes is 13/14 of the algorithmic count, so `frac` (algorithmic) may exceed
+                         # what the pipe alone allows — the pipe's own busy fraction is frac * executed / algorithmic
+                         "executed_over_algorithmic_flop": (13.0 / 14.0) if R == 16 else 1.0,
+                         "matrix_pipe_frac": achieved / PEAK_FP32_MFMA_TFLOPS * ((13.0 / 14.0) if R == 16 else 1.0),
                          "hbm": {"achieved_GBps": (traffic / avg_c32_s / 1e9) if traffic else None,
                                  "peak_GBps": PEAK_HBM_GBS,
                                  "frac": (traffic / avg_c32_s / 1e9 / PEAK_HBM_GBS) if traffic else None}},
