@@ -201,3 +201,15 @@ def test_launcher_starts_ranks_and_relays_rank0(tmp_path):
     assert "noise from rank" in r.stderr
     r = subprocess.run([sys.executable, str(script), "fail", "2"], capture_output=True, text=True, env=env, timeout=150)
     assert r.returncode == 7
+
+
+def test_visible_gpu_count_agrees_with_torch_and_honours_visible_devices(monkeypatch):
+    """The launcher's runtime-free GPU count (DRM render nodes; torch's query only where there is no /dev/dri) equals what
+    torch reports in this process, and *_VISIBLE_DEVICES narrows it."""
+    import torch
+    from snn_modulation_classification_amd import parallel
+    n = parallel.visible_gpu_count()
+    assert n == torch.cuda.device_count()
+    if os.path.isdir("/dev/dri"):
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+        assert parallel.visible_gpu_count() == 0
