@@ -52,11 +52,31 @@ def build_net(batch, device):
     return net, convs
 
 
-def per_step_paths(dev, batch=512, steps=48):
+def _spin_calibration(dev):
+    """torch.cuda._sleep cycles per millisecond on this device (its clock is not the shader clock everywhere)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize(dev)
+    n = 20_000_000
+    e0.record()
+    torch.cuda._sleep(n)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return n / max(e0.elapsed_time(e1), 1e-3)
+
+
+def per_step_paths(dev, batch=512, steps=48, reps=3):
     """The reference's per-timestep protocol on the same network, reported beside the headline (not part of `value`):
     `net.test(x[t])` (test_radio_ml.py:142-146) and `net.learn(x[t], labels)` (train.py:249-251: SmoothL1Loss, Adam
-    betas (0, .95), weight_decay 10) at the reference scripts' batch 512, wall time per timestep over `steps` steps after
-    the burn-in / warm-up (HIP kernels only in the loop; at this batch eager launches — hipGraph replays are used up to batch 128)."""
+    betas (0, .95), weight_decay 10) at the reference scripts' batch 512, per timestep over `steps` steps after the
+    burn-in / warm-up, best of `reps` repetitions.  Two clocks per path, so that the record can tell a slow HOST from a
+    slow DEVICE:
+      wall_ms    host wall clock around the loop (+ a final synchronize): what a user of the loop sees;
+      device_ms  HIP-event time of the same launches executing BACK TO BACK: the stream is first blocked by a spin kernel
+                 for about the wall time of the loop, the host enqueues all `steps` timesteps behind it, and the events
+                 around them then bracket pure device work (no launch gaps).
+    wall_ms / device_ms ~ 1: the device sets the pace; >> 1: the host's launch path does (then hipGraph replays help —
+    ConvNetwork decides that by measurement per geometry, `graph_decision`)."""
     convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
     args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
     torch.manual_seed(1)
@@ -65,25 +85,44 @@ def per_step_paths(dev, batch=512, steps=48):
                       opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0},
                       learning_rates=[2.5e-10], burnin=2)
     net.reset(True)
-    n = steps + 8
+    warm = 24                                  # burn-in, eager steps, the graph-vs-eager measurement of ConvNetwork
+    n = steps + warm
     x = torch.zeros(n, batch, 1, R * R, device=dev)
     x.scatter_(3, torch.randint(0, R * R, (n, batch), device=dev)[:, :, None, None], 1.0)
     x = x.reshape(n, batch, 1, R, R)
     y = torch.zeros(batch, N_CLASSES, device=dev)
     y[torch.arange(batch), torch.randint(0, N_CLASSES, (batch,))] = 1
-    out = {"batch": batch, "timesteps_timed": steps}
+    cyc_per_ms = _spin_calibration(dev)
+    out = {"batch": batch, "timesteps_timed": steps, "repetitions": reps}
     for name, fn in (("test", lambda t: net.test(x[t])), ("learn", lambda t: net.learn(x[t], y))):
         net.reset()
-        for t in range(8):                     # (learn: burn-in, two eager learning steps, the graph capture)
+        for t in range(warm):
             fn(t)
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for t in range(8, n):
-            fn(t)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / steps
+        walls, devs = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for t in range(warm, n):
+                fn(t)
+            torch.cuda.synchronize(dev)
+            walls.append((time.perf_counter() - t0) / steps)
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(int(1.15 * min(walls) * steps * 1e3 * cyc_per_ms))     # the host gets ahead of the device
+            e0.record()
+            for t in range(warm, n):
+                fn(t)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            devs.append(e0.elapsed_time(e1) / steps)
+        dt = min(walls)
         out[name + "_ms_per_timestep"] = 1e3 * dt
+        out[name + "_wall_ms_per_timestep_all"] = [1e3 * w for w in walls]
+        out[name + "_device_ms_per_timestep"] = min(devs)
+        out[name + "_device_ms_per_timestep_all"] = devs
+        out[name + "_wall_over_device"] = 1e3 * dt / max(min(devs), 1e-9)
         out[name + "_windows_per_s_at_T128"] = batch / (dt * T_STEPS)
+    out["graph_decision"] = net.graph_decisions()
     return out
 
 
@@ -222,6 +261,64 @@ def bench_ref_network(a):
         dist.destroy_process_group()
 
 
+def sweep_point(dev, B, steps=3, warmup=1):
+    """One more batch size of the headline workload (BASELINE configs 2 and 3: batch 512 / 8192 on one MI355X): the same
+    step as main()'s on a network of its own — value, ms per step and the roofline fraction of the hot kernel from the
+    HIP events of its launches.  A batch above the pv budget runs in chunks (8192 = 6144 + 2048)."""
+    net, _ = build_net(B, dev)
+    enc = IQEncoder(R, R, device=dev)
+    g = torch.Generator().manual_seed(11)
+    iq = (0.4 * torch.randn(B, 2, L_IQ, generator=g)).to(dev)
+    labels = torch.randint(0, N_CLASSES, (B,), generator=g).to(dev)
+    prof = {}
+
+    def step(profile=None):
+        net.zero_states()
+        net.reset()
+        res = net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False, profile=profile)
+        return parallel.tallies(res["vote"], labels, N_CLASSES)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(profile=prof)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    c32_ms = [s_.elapsed_time(e_) for s_, e_ in prof.get("lif_c32", [])]
+    flop = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T_STEPS * B * 2 * steps          # both 32->32 layers, all steps
+    ach = flop / (sum(c32_ms) / 1e3) / 1e12 if c32_ms else float("nan")
+    rec = {"batch": B, "value": B * steps / dt, "unit": "IQ windows/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps,
+           "roofline": {"kernel": "k_lif_seq_c32d" if R == 16 else "k_lif_seq_c32t", "bound": "mfma", "achieved": ach,
+                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                        "launches": len(c32_ms), "launch_ms_total_per_step": sum(c32_ms) / steps},
+           "kernel_ms_per_step": {k: float(np.sum([s_.elapsed_time(e_) for s_, e_ in v])) / steps for k, v in prof.items()}}
+    del net
+    torch.cuda.empty_cache()
+    return rec
+
+
+def trained_top1(dev, n_batches=4, batch=512, train_steps=25):
+    """north_star's "top-1 within 0.1 % of reference" on a network that has learned (oracle/trained_parity.py): train
+    radio_ml_conv.yaml with train.py on the synthetic modulation set, restore the checkpoint the reference's way, evaluate
+    the same held-out windows on the fused HIP path and on the CPU reference path (oracle/torch_ref.py)."""
+    import tempfile
+    from oracle import trained_parity
+    torch.set_num_threads(max(1, min(16, usable_cores())))        # (the CPU leg: an over-subscribed pool is far slower)
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        ckpt = trained_parity.train_checkpoint(tmp, steps=train_steps, batch=batch)
+        t_train = time.perf_counter() - t0
+        net, ref, _, enc = trained_parity.restore_pair(ckpt, batch, device=dev)
+    rep = trained_parity.evaluate(net, ref, enc, trained_parity.held_out_batches(n_batches, batch), count_flips=True, log=log)
+    rep["training"] = ("train.py --synthetic: %d batches of %d windows, T=128, 16x16, arp 1.0, burn-in 20, SmoothL1 + Adam "
+                       "(lr 1e-6; output_ 1e-4), %.1f s incl. the two evaluations train.py runs" % (train_steps, batch, t_train))
+    rep["held_out"] = "%d x %d synthetic modulation windows, SNR cycling 6 .. 30 dB, zero neuron state per batch" % (n_batches, batch)
+    return rep
+
+
 def log(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -301,7 +398,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=None,
                     help="IQ windows per GPU per step (weak scaling); default 4096 (16x16 plane) / 64 (larger planes)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="STRONG scaling: IQ windows per step over ALL GPUs (north_star: 'batch 4096 ... at 1/2/4/8 GPUs'); "
+                         "every rank runs its contiguous shard of G / N windows and the JSON line says \"scaling\": "
+                         "\"strong\".  Default: weak scaling with --batch windows per GPU")
     ap.add_argument("--plane", type=int, default=16, help="I/Q plane resolution R (R x R cells): 16 or a multiple of 32")
+    ap.add_argument("--batch-sweep", type=int, default=1,
+                    help="1 (default, N=1 headline run only): also run BASELINE configs 2 and 3 (batch 512 and 8192, 3 steps "
+                         "each) and report them as `batch_sweep`")
+    ap.add_argument("--trained", type=int, default=1,
+                    help="1 (default, N=1 headline run only): also train the network on the synthetic modulation set (train.py, "
+                         "25 batches of 512) and compare top-1 of the fused path with the CPU reference path on 2048 held-out "
+                         "windows: `trained_top1`")
     ap.add_argument("--cpu-windows", type=int, default=None,
                     help="CPU baseline batch (0 = skip); default 512 = batch_size_test of the reference's scripts "
                          "(4 on planes larger than 16x16, where the CPU path needs seconds per window)")
@@ -341,6 +449,12 @@ def main():
     dev = torch.device("cuda", parallel.local_device(local_rank))
     torch.cuda.set_device(dev)
     B = a.batch
+    strong = a.global_batch is not None
+    if strong:
+        lo, hi = parallel.shard_range(a.global_batch, rank, world)
+        B = hi - lo
+        assert B > 0, "--global-batch %d leaves rank %d of %d without windows" % (a.global_batch, rank, world)
+    total_windows = a.global_batch if strong else world * B
 
     net, convs = build_net(B, dev)
     enc = IQEncoder(R, R, device=dev)
@@ -381,10 +495,27 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     log("timed region done: %.3f s for %d steps" % (dt, a.steps))
+    # the same K steps with the raw IQ handed over as a HOST buffer each step ("with and without
+    # encode+upload", reference test_radio_ml.py:133-135 — there a dense T*B*R*R fp32 spike tensor, here 1 KB of raw IQ per
+    # window from pinned memory; the encoding runs inside the first layer's kernel either way).  Never `value`.
+    iq_host = iq.cpu().pin_memory()
+
+    def step_upload():
+        iq.copy_(iq_host, non_blocking=True)
+        return step()
+
+    step_upload()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step_upload()
+    fence()
+    dt_up = time.perf_counter() - t0
     if parallel.is_distributed():
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt, dt_up], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, dt_up = float(tmax[0].item()), float(tmax[1].item())
+    log("upload-inclusive region done: %.3f s for %d steps" % (dt_up, a.steps))
 
     # dominant kernel: HIP-event time of every k_lif_seq_c32d launch of the timed region (same stream as the launch)
     c32_ms = [s.elapsed_time(e) for s, e in prof.get("lif_c32", [])]
@@ -419,15 +550,19 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": world * B * a.steps / dt,
+            "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": total_windows * a.steps / dt,
             "unit": "IQ windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "radio_ml_conv.yaml, %dx%d I/Q plane, T=128, arp=1.0, random_tau, batch %d per GPU%s, "
+            "config": {"workload": "radio_ml_conv.yaml, %dx%d I/Q plane, T=128, arp=1.0, random_tau, %s%s, "
                                    "synthetic IQ 0.4*randn(B,2,128), seeded init" %
-                                   (R, R, B, (" (north_star headline batch)" if (B == 4096 and R == 16) else "") +
+                                   (R, R, ("global batch %d sharded over %d GPU(s) (strong scaling)" % (total_windows, world))
+                                    if strong else ("batch %d per GPU" % B),
+                                    (" (north_star headline batch)" if ((total_windows if strong else B) == 4096 and R == 16)
+                                     else "") +
                                     (", OUTPUT-ONLY serving mode (hidden-layer readouts skipped)" if a.output_only else "")),
-                       "batch_per_gpu": B, "global_batch": B * world, "T": T_STEPS, "plane": [R, R],
+                       "batch_per_gpu": B, "global_batch": total_windows, "T": T_STEPS, "plane": [R, R],
                        "parallelism": "batch shards, %d rank(s) on %d GPU(s)%s, tally all-reduce only (backend %s)" %
                                       (world, min(world, torch.cuda.device_count()),
                                        " — REHEARSAL: ranks share a device" if world > torch.cuda.device_count() else "",
@@ -448,6 +583,10 @@ def main():
                                  "frac": (traffic / avg_c32_s / 1e9 / PEAK_HBM_GBS) if traffic else None}},
             "kernel_ms_per_launch": kernel_ms,
             "vote_accuracy_vs_random_labels": [float(x) for x in acc.cpu()],
+            "value_incl_upload": total_windows * a.steps / dt_up,
+            "ms_per_step_incl_upload": 1e3 * dt_up / a.steps,
+            "upload": "raw IQ (B,2,128) fp32 = %d bytes per step per GPU, pinned host memory -> HBM on the launch stream, in "
+                      "front of every step; `value` is the device-resident form" % (B * 2 * L_IQ * 4),
         }
         # the HBM-bound kernels around the hot one (north_star: achieved HBM GB/s of the LIF-update kernel against the
         # roofline): bytes they must move by this design (pv written once by the first layer's kernel, read once by a
@@ -471,6 +610,15 @@ def main():
                 out["per_step_paths"] = per_step_paths(dev)
             except Exception as e:                  # noqa: BLE001
                 out["per_step_paths"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and R == 16 and a.batch_sweep and B == 4096:
+            # BASELINE configs 2 and 3 beside the headline (never at its price)
+            try:
+                net._seq_buffers.clear()
+                torch.cuda.empty_cache()
+                out["batch_sweep"] = [sweep_point(dev, b_) for b_ in (512, 8192)]
+                log("batch sweep done: %s" % [(r_["batch"], round(r_["value"])) for r_ in out["batch_sweep"]])
+            except Exception as e:                  # noqa: BLE001
+                out["batch_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and R == 16 and a.config5 and B == 4096:
             # BASELINE config 5 beside the headline (never at its price): its own network, 3 steps at batch 4096
             try:
@@ -480,6 +628,11 @@ def main():
             except Exception as e:                  # noqa: BLE001
                 out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
+        if world == 1 and R == 16 and a.trained and a.cpu_windows > 0 and B == 4096:
+            try:
+                out["trained_top1"] = trained_top1(dev)
+            except Exception as e:                  # noqa: BLE001
+                out["trained_top1"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and a.cpu_windows > 0:
             cells = enc(iq, T_STEPS, t0=0)          # the same quantisation as a separate kernel, for the CPU leg
             nw = min(a.cpu_windows, B)

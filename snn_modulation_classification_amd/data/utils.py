@@ -157,7 +157,7 @@ class IQEncoder:
         tq = cell_thresholds(Q_bounds[0], Q_bounds[1], out_h, do_gamma)
         self.thr_i, self.thr_q = torch.from_numpy(ti).to(device), torch.from_numpy(tq).to(device)
         self.thr_i_tail = self.thr_q_tail = None
-        self._witness, self._masks = None, {}
+        self._witness, self._masks, self._dev_masks = None, {}, {}
         if exact_tail:
             si = cell_thresholds(I_bounds[0], I_bounds[1], out_w, do_gamma, path='scalar')
             sq = cell_thresholds(Q_bounds[0], Q_bounds[1], out_h, do_gamma, path='scalar')
@@ -172,13 +172,16 @@ class IQEncoder:
                 self.thr_i_tail, self.thr_q_tail = torch.from_numpy(si).to(device), torch.from_numpy(sq).to(device)
 
     def tail_mask_host(self, B):
-        """uint8 (B): 1 where torch's quantiser sends position b of a length-B vector through its scalar pow path."""
-        m = self._masks.get(B)
+        """uint8 (B): 1 where torch's quantiser sends position b of a length-B vector through its scalar pow path.
+        Above torch's parallel grain (32 768 elements) the vector is cut into one chunk per thread and every chunk END takes
+        the scalar path, so the positions also depend on the thread count in force: it is part of the cache key."""
+        key = (B, torch.get_num_threads())
+        m = self._masks.get(key)
         if m is None:
             axis, x, scalar_cell, n_cells = self._witness
             lo, hi = self._bounds[axis]
             got = _quantise(torch.full((B,), x, dtype=torch.float32), lo, hi, n_cells, self._gamma).numpy()
-            m = self._masks[B] = (got == scalar_cell).astype(np.uint8)
+            m = self._masks[key] = (got == scalar_cell).astype(np.uint8)
         return m
 
     def tail(self, B, start=0, stop=None, total=None):
@@ -188,10 +191,14 @@ class IQEncoder:
             return None
         total = B if total is None else total
         stop = start + B if stop is None else stop
-        mask = self.tail_mask_host(total)[start:stop]
-        if not mask.any():
-            return None
-        return self.thr_i_tail, self.thr_q_tail, torch.from_numpy(np.ascontiguousarray(mask)).to(self.device)
+        key = (total, start, stop, torch.get_num_threads())
+        if key not in self._dev_masks:              # one upload per (batch, shard), not one per call of the hot path
+            mask = self.tail_mask_host(total)[start:stop]
+            if len(self._dev_masks) > 64:
+                self._dev_masks.clear()
+            self._dev_masks[key] = torch.from_numpy(np.ascontiguousarray(mask)).to(self.device) if mask.any() else None
+        dm = self._dev_masks[key]
+        return None if dm is None else (self.thr_i_tail, self.thr_q_tail, dm)
 
     def __call__(self, iq, max_duration, t0=None, start=0, total=None):
         from .. import ops

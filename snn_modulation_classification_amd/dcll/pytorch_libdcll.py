@@ -142,7 +142,9 @@ class ContinuousConv2D(nn.Module):
         """Keep the conv weight's int8 form (q int8 like `weight`, scale fp32 (c_out,)) beside the fp32 Parameter, which
         must hold exactly the dequantised values q * scale (quant.apply_int8_weights writes both).  From now on the
         kernels read the int8 tensor through the C ABI (dcll_layer_opts) — bit-identical results, a quarter of the
-        weight bytes.  Dropped as soon as `weight` is modified (a learning step, load_state_dict)."""
+        weight bytes.  Dropped as soon as `weight` is modified: an in-place torch op or load_state_dict (seen through the
+        tensor's version counter), reset_parameters, or a native learning step — dcll_adam_step writes through the raw
+        pointer, which no version counter sees, so the learning paths call Conv2dDCLLlayer.weights_written()."""
         if q is None:
             self._q8 = None
             return
@@ -190,6 +192,7 @@ class ContinuousConv2D(nn.Module):
         self.weight.data.uniform_(-stdv * 1e-2, stdv * 1e-2)
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
+        self._q8 = None                     # (.data writes leave the version counter alone)
 
     def randomize_tau(self, im_dims, low=[5, 5], high=[10, 35]):
         """tau_m ~ U(5,35) ms, tau_s ~ U(5,10) ms per input channel, stored as (C,H,W) (reference :391-405).
@@ -405,6 +408,17 @@ class Conv2dDCLLlayer(nn.Module):
         self.i2o.weight.data.uniform_(-stdv, stdv)
         if self.i2o.bias is not None:
             self.i2o.bias.data.uniform_(-stdv, stdv)
+        self.weights_written()
+
+    def weights_written(self):
+        """Drop everything derived from this layer's weights: the int8 form of the conv weight and the stacked / permuted
+        readout matrices.  Their caches are keyed on the tensors' version counters, which in-place torch ops and
+        load_state_dict advance — but NOT a write through `.data` or through the raw device pointer (dcll_adam_step, the
+        native learning step): whoever writes that way calls this."""
+        if getattr(self, 'i2h', None) is not None:
+            self.i2h._q8 = None
+        self._stack_cache = None
+        self._ro_cache = None
 
     def get_output_shape(self):
         conv_shape = self.i2h.get_output_shape(self.im_dims)
@@ -659,6 +673,9 @@ class DenseDCLLlayer(nn.Module):
             raise NotImplementedError('lc_dropout is not implemented by the HIP path')
 
     reset_lc_parameters = Conv2dDCLLlayer.reset_lc_parameters
+
+    def weights_written(self):
+        """(nothing is derived from a dense layer's weights)"""
 
     def forward(self, input):
         """-> (output spikes, pvoutput, pv, pvmem)  (reference :250-255)."""
@@ -934,6 +951,7 @@ class DCLLBase(nn.Module):
                 parallel.allreduce_mean_tensors(self._grad_tensors(), local_n=input.shape[0])
                 if do_train:
                     ops.adam_step(self._adam_tensors())
+                    self.dclllayer.weights_written()
             # (the loss value lives in a reused one-element device buffer: valid until the next step of this slice)
             return output, pvoutput, pv, pvmem, (loss.reshape(()) if learned else torch.Tensor([0]))
         learn_now = (self.iter + 1) >= self.burnin

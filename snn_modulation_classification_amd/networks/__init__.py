@@ -68,6 +68,9 @@ class ConvNetwork(torch.nn.Module):
         self.graph_learn = os.environ.get('DCLL_GRAPH_LEARN', '1') != '0'
         self._learn_graphs, self._learn_eager_steps, self._learn_last_key = {}, {}, None
         self._test_graphs, self._test_eager_steps = {}, {}
+        # graph-or-eager decisions taken by measurement, per (path, input geometry): see _graph_tuned
+        self.graph_autotune = os.environ.get('DCLL_GRAPH_AUTOTUNE', '1') != '0'
+        self._graph_tune = {}
         # largest pv buffer (one layer, all T steps) the sequence path allocates; bigger batches run in chunks
         self.pv_budget_bytes = float(os.environ.get('DCLL_PV_BUDGET_GB', '24')) * 2 ** 30
         # sequence path: the layer kernels can write v and let the readout GEMM apply the sigmoid (dcll_layer_opts
@@ -79,11 +82,20 @@ class ConvNetwork(torch.nn.Module):
         self.presigmoid = os.environ.get('DCLL_PRESIGMOID', 'auto')
 
     # -- reference protocol (per step) ----------------------------------------------------------------------------
-    def learn(self, x, labels):
+    def learn(self, x, labels, global_batch=None):
         """One timestep of local learning in every slice (reference :175-180).  When every slice's step is native
         (DCLLBase._native_learning) the three phases are batched over the slices: all forwards + backwards (a slice's
         weight update only matters from the NEXT timestep on, and slice l+1 consumes slice l's spikes, not its
-        weights), then ONE bucketed all-reduce of all gradients (multi-rank), then ONE Adam launch for all tensors."""
+        weights), then ONE bucketed all-reduce of all gradients (multi-rank), then ONE Adam launch for all tensors.
+        `global_batch` (ranks only): samples of the whole batch this shard belongs to, for this call; default: the
+        attribute `self.global_batch` the entry points set per batch (None = the collective derives it from a count
+        element).  A shard larger than the batch it claims to be part of is refused — a stale value would weigh the
+        gradients wrongly without any other symptom."""
+        if global_batch is None:
+            global_batch = self.global_batch
+        if global_batch is not None and x.shape[0] > global_batch:
+            raise ValueError('shard of %d samples of a global batch of %d: set net.global_batch (or pass global_batch=) '
+                             'for THIS batch' % (x.shape[0], global_batch))
         if not all(s._native_learning() is not None for s in self.dcll_slices):
             spikes = x
             for s in self.dcll_slices:
@@ -97,8 +109,10 @@ class ConvNetwork(torch.nn.Module):
         if ranks:
             for s in self.dcll_slices:
                 s._grads_into_slab()
-        if self._graph_learn_ok(x, labels, key) and self._learn_graphed(x, labels, key):
-            return
+        if self._graph_learn_ok(x, labels, key):
+            if self._learn_graphed(x, labels, key, global_batch):
+                return
+            self._graph_interrupted('learn', key)          # (capture dropped or refused: this step runs eagerly)
         # Under ranks every slice's gradients are ONE slab whose all-reduce starts as soon as its backward is enqueued and
         # runs under the next slice's forward / backward (slice l+1 needs slice l's spikes, not its gradients); the
         # single Adam launch waits for all of them.
@@ -108,11 +122,13 @@ class ConvNetwork(torch.nn.Module):
             if l:
                 learned.append(s)
                 if ranks:
-                    pending.append(parallel.allreduce_slab_begin(s._grad_slab, x.shape[0], self.global_batch))
+                    pending.append(parallel.allreduce_slab_begin(s._grad_slab, x.shape[0], global_batch))
         for h in pending:
             parallel.allreduce_slab_end(h)
         if learned:
             ops.adam_step([t for s in learned for t in s._adam_tensors()])
+            for s in learned:
+                s.dclllayer.weights_written()          # (raw-pointer write: no version counter sees it)
             if len(learned) == len(self.dcll_slices):
                 self._learn_eager_steps[key] = self._learn_eager_steps.get(key, 0) + 1
 
@@ -124,24 +140,79 @@ class ConvNetwork(torch.nn.Module):
     # (torch.cuda.CUDAGraph = hipGraph) on static input buffers and replayed: the step-dependent scalars are read on the
     # device (dcll_adam_step_dyn), refreshed from the host before each replay.
     _DYN_RING = 32
-    # graphs only where the eager loop is host-bound: up to 128 samples of a 16x16 plane (learn: 0.46 -> 0.34 ms at
-    # B = 128, but 0.48 -> 0.49 at B = 256 and 0.73 -> 0.76 at B = 512; larger planes are GPU-bound at any batch)
+    # Where a replay beats the eager loop depends on the HOST: on the pool's usual boxes the eager loop is host-bound up to
+    # 128 samples of a 16x16 plane (learn: 0.46 -> 0.34 ms at B = 128, but 0.48 -> 0.49 at B = 256 and 0.73 -> 0.76 at
+    # B = 512), while a slower host launches the same ~25 kernels of a B = 512 timestep in 2 ms against 0.73 ms of device
+    # work (round-3 driver run).  So: replays unconditionally up to GRAPH_MAX_PIXELS, and between that and
+    # GRAPH_TUNE_MAX_PIXELS the choice is MEASURED on the running job (_graph_tuned): TUNE_STEPS eager timesteps against
+    # TUNE_STEPS replays, wall clock between two synchronisations each — four host syncs per geometry, once.  Larger
+    # planes are device-bound on any host.
     GRAPH_MAX_PIXELS = 128 * 256
+    GRAPH_TUNE_MAX_PIXELS = 2048 * 256
+    TUNE_STEPS = 6
 
     def _graph_small(self, x):
         return x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] <= self.GRAPH_MAX_PIXELS
 
+    def _graph_tuned(self, path, x, key):
+        """Whether this step of `path` ('learn' / 'test') on geometry `key` should be a graph replay.  Small workloads: yes.
+        Mid-size ones: the running job is timed — the first TUNE_STEPS eligible steps eagerly, one replay to take the
+        capture, TUNE_STEPS replays — and the faster form is kept (ties: eager, it has no static-buffer copies).  A step
+        that is not eligible (burn-in, pv statistics) restarts the window it falls into (graph_interrupted)."""
+        if self._graph_small(x):
+            return True
+        if not (self.graph_autotune and x.dim() == 4 and
+                x.shape[0] * x.shape[2] * x.shape[3] <= self.GRAPH_TUNE_MAX_PIXELS):
+            return False
+        import time
+        tk = (path, key)
+        st = self._graph_tune.get(tk)
+        if st is None:
+            st = self._graph_tune[tk] = dict(phase='eager', n=0, t0=0.0, eager_ms=None, graph_ms=None, use_graph=None)
+        if st['use_graph'] is not None:
+            return st['use_graph']
+        if st['phase'] in ('eager', 'graph') and st['n'] == self.TUNE_STEPS:
+            torch.cuda.synchronize(x.device)
+            ms = 1e3 * (time.perf_counter() - st['t0']) / self.TUNE_STEPS
+            if st['phase'] == 'eager':
+                st.update(eager_ms=ms, phase='capture', n=0)
+            else:
+                st.update(graph_ms=ms, use_graph=bool(ms < 0.97 * st['eager_ms']))
+                return st['use_graph']
+        if st['phase'] == 'capture':               # one untimed replay takes the capture
+            st.update(phase='graph', n=0)
+            return True
+        if st['n'] == 0:
+            torch.cuda.synchronize(x.device)
+            st['t0'] = time.perf_counter()
+        st['n'] += 1
+        return st['phase'] == 'graph'
+
+    def _graph_interrupted(self, path, key):
+        """An ineligible step (burn-in, statistics, a dropped capture) fell into a measurement window: start it again."""
+        st = self._graph_tune.get((path, key))
+        if st is not None and st['use_graph'] is None and st['phase'] in ('eager', 'graph'):
+            st['n'] = 0
+
+    def graph_decisions(self):
+        """{path: {geometry: {'eager_ms', 'graph_ms', 'use_graph'}}} of the measured graph-or-eager choices so far."""
+        out = {}
+        for (path, key), st in self._graph_tune.items():
+            out.setdefault(path, {})[str(key)] = {k: st[k] for k in ('eager_ms', 'graph_ms', 'use_graph')}
+        return out
+
     def _graph_learn_ok(self, x, labels, key):
-        if not (self.graph_learn and x.is_cuda and x.dtype == torch.float32 and labels.dtype == torch.float32 and
-                self._graph_small(x)):
+        if not (self.graph_learn and x.is_cuda and x.dtype == torch.float32 and labels.dtype == torch.float32):
             return False
         if self._learn_eager_steps.get(key, 0) < 2:            # buffers, .grad and Adam state exist after eager steps
+            self._graph_interrupted('learn', key)
             return False
         for s in self.dcll_slices:
             it = s.iter + 1
             if it < s.burnin or (s.collect_stats and it % 20 == 0):      # burn-in and histogram steps run eagerly
+                self._graph_interrupted('learn', key)
                 return False
-        return True
+        return self._graph_tuned('learn', x, key)
 
     def _graph_signature(self):
         """Everything a captured step has baked in: addresses of state, parameters, gradients and optimizer state, and
@@ -166,7 +237,7 @@ class ConvNetwork(torch.nn.Module):
         return tuple(sig)
 
     @torch.no_grad()
-    def _learn_graphed(self, x, labels, key):
+    def _learn_graphed(self, x, labels, key, global_batch=None):
         """One learning timestep by replaying its captured graph -> True; False (nothing done) when the capture on
         record no longer matches the tensors in use — the caller then runs eager steps, after which a new one is taken."""
         sig = self._graph_signature()
@@ -205,13 +276,14 @@ class ConvNetwork(torch.nn.Module):
             pending = []
             for seg, s in zip(g['segments'], self.dcll_slices):
                 seg.replay()
-                pending.append(parallel.allreduce_slab_begin(s._grad_slab, x.shape[0], self.global_batch))
+                pending.append(parallel.allreduce_slab_begin(s._grad_slab, x.shape[0], global_batch))
             for h in pending:
                 parallel.allreduce_slab_end(h)
             g['graph'].replay()
         rec = g['clout'].clone()
         for i, s in enumerate(self.dcll_slices):
             s.iter += 1
+            s.dclllayer.weights_written()              # (the replayed Adam launch wrote through raw pointers)
             if g['records'][i]:
                 s._clout.append(rec[i])
         return True
@@ -293,8 +365,10 @@ class ConvNetwork(torch.nn.Module):
     def test(self, x):
         """One inference timestep in every slice (reference :182-185).  At batches where the host's launch path sets
         the pace the step is replayed from a captured hipGraph (see _test_graphed)."""
-        if self._graph_test_ok(x) and self._test_graphed(x):
-            return
+        if self._graph_test_ok(x):
+            if self._test_graphed(x):
+                return
+            self._graph_interrupted('test', tuple(x.shape))
         spikes = x
         for s in self.dcll_slices:
             spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
@@ -310,17 +384,18 @@ class ConvNetwork(torch.nn.Module):
     # every-20th-step pv statistics run eagerly.
 
     def _graph_test_ok(self, x):
-        if not (self.graph_learn and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and
-                self._graph_small(x)):
+        if not (self.graph_learn and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
             return False
         if self._test_eager_steps.get(tuple(x.shape), 0) < 2:      # state and lazily built caches exist after eager steps
+            self._graph_interrupted('test', tuple(x.shape))
             return False
         for s in self.dcll_slices:
             if not isinstance(s, DCLLClassification) or not isinstance(s.dclllayer, Conv2dDCLLlayer):
                 return False
             if s.collect_stats and (s.iter + 1) % 20 == 0:
+                self._graph_interrupted('test', tuple(x.shape))
                 return False
-        return True
+        return self._graph_tuned('test', x, tuple(x.shape))
 
     def _test_signature(self):
         sig = []
@@ -331,6 +406,8 @@ class ConvNetwork(torch.nn.Module):
                                            L.i2h.tau_s__dt, L.i2o.weight, L.i2o.bias)]
             if L.output_layer:
                 sig += [L.output_.weight.data_ptr(), L.output_.bias.data_ptr()]
+            q8 = L.i2h.int8_weights()            # (a capture taken on the int8 form must not outlive it)
+            sig.append(None if q8 is None else (q8[0].data_ptr(), q8[1].data_ptr()))
         return tuple(sig)
 
     @torch.no_grad()

@@ -60,6 +60,12 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
         if backend == "nccl":
+            # RCCL refuses two ranks on one device (and hangs the others in the rendezvous): say so before joining
+            n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            if torch.cuda.device_count() < n_local:
+                sys.exit("rank %d: %d local rank(s) over RCCL but this process sees %d GPU(s) — use --gpus <= %d, or "
+                         "DCLL_DIST_BACKEND=gloo for a rehearsal in which ranks share devices"
+                         % (rank, n_local, torch.cuda.device_count(), max(torch.cuda.device_count(), 1)))
             torch.cuda.set_device(local_device(local_rank))
             kw["device_id"] = torch.device("cuda", local_device(local_rank))
         # Both backends announce themselves with a printf on STDOUT while the group / the communicator forms (gloo its
@@ -218,16 +224,48 @@ def _free_port():
     return p
 
 
+def _is_amd_compute_node(name):
+    """A DRM render node counts as a GPU of this job only if its PCI vendor is AMD (0x1002) — an iGPU or display adapter of
+    another vendor, or a virtual render node, is no place for an RCCL rank.  Where sysfs does not say (no `device/vendor`
+    entry: some containers mount /dev/dri without /sys/class/drm) the node is kept."""
+    try:
+        with open(os.path.join("/sys/class/drm", name, "device", "vendor")) as f:
+            return int(f.read().strip(), 16) == 0x1002
+    except (OSError, ValueError):
+        return True
+
+
+def _kfd_gpu_count():
+    """GPU agents the compute driver (amdkfd) exposes: topology nodes with SIMDs (CPU nodes have simd_count 0), or None
+    where the topology cannot be read."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(root):
+            with open(os.path.join(root, d, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        n += int(line.split()[1]) > 0
+                        break
+        return n
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def visible_gpu_count():
-    """GPUs this job may use, counted WITHOUT the HIP runtime: the DRM render nodes this process can open (a container
-    that was given one GPU of an 8-GPU host has one), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
-    CUDA_VISIBLE_DEVICES.  Only where there is no /dev/dri torch's own device query is asked — the launcher must not
-    bring a runtime up."""
+    """GPUs this job may use, counted WITHOUT the HIP runtime: the AMD DRM render nodes this process can open (a container
+    that was given one GPU of an 8-GPU host has one), not more than the compute driver's topology lists, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  Only where there is no /dev/dri torch's own
+    device query is asked — the launcher must not bring a runtime up.  (An over-count would start RCCL ranks on fewer
+    compute GPUs than ranks; every rank therefore re-checks against its runtime: local_device.)"""
     try:
         nodes = [d for d in os.listdir("/dev/dri") if d.startswith("renderD")]
     except OSError:
         return torch.cuda.device_count()
-    n = sum(1 for d in nodes if os.access(os.path.join("/dev/dri", d), os.R_OK | os.W_OK))
+    n = sum(1 for d in nodes if os.access(os.path.join("/dev/dri", d), os.R_OK | os.W_OK) and _is_amd_compute_node(d))
+    kfd = _kfd_gpu_count()
+    if kfd:                                       # (0 / None: topology hidden from this container — no information)
+        n = min(n, kfd)
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:

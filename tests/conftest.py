@@ -52,3 +52,11 @@ def golden_meta():
 def unpack_bits(packed, n):
     """Inverse of make_golden.pack_bits: (..., ceil(n/8)) uint8 -> (..., n) float32."""
     return np.unpackbits(packed, axis=-1, bitorder="little")[..., :n].astype(np.float32)
+
+
+@pytest.fixture(scope="session")
+def trained_checkpoint(tmp_path_factory):
+    """A parameters_{step}.pth written by the build's train.py on the GPU: radio_ml_conv.yaml trained for 40 batches of
+    512 synthetic modulation windows (oracle/trained_parity.py) — the trained-weights parity tests share it."""
+    from oracle import trained_parity
+    return trained_parity.train_checkpoint(str(tmp_path_factory.mktemp("trained")), steps=40)

@@ -384,6 +384,55 @@ def test_int8_form_is_dropped_when_the_weight_changes(dev):
     assert net.dcll_slices[0].dclllayer.i2h.int8_weights() is not None
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_native_learning_step_drops_int8_form_and_readout_caches(dev, graph, monkeypatch):
+    """dcll_adam_step writes the parameters through raw device pointers — no tensor version counter moves — so the
+    learning paths (train_dcll, ConvNetwork.learn eager and as a hipGraph replay) must invalidate what was derived from
+    the weights themselves: after quant.apply_int8_weights + native learning steps the layers read the (updated) fp32
+    weight again, and the stacked output-layer readout equals the live output_ weight."""
+    import os
+    from argparse import Namespace
+    from conftest import ROOT
+    from snn_modulation_classification_amd import quant
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    monkeypatch.setenv("DCLL_GRAPH_LEARN", "1" if graph else "0")
+    convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    torch.manual_seed(2)
+    np.random.seed(2)
+    B = 8
+    net = ConvNetwork(args, (1, 16, 16), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                      opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0},
+                      learning_rates=[1e-4], burnin=2)
+    net.reset(True)
+    assert all(s._native_learning() is not None for s in net.dcll_slices)
+    quant.apply_int8_weights(net)
+    last = net.dcll_slices[-1].dclllayer
+    Wt0, _ = last.stacked_readout()
+    Wt0 = Wt0.clone()
+    w_before = [s.dclllayer.i2h.weight.detach().clone() for s in net.dcll_slices]
+    rng = np.random.RandomState(0)
+    y = torch.zeros(B, 24, device=dev)
+    y[torch.arange(B), torch.from_numpy(rng.randint(0, 24, B))] = 1
+    n_steps = 8 if graph else 3               # (the capture is taken after two eager learning steps)
+    for t in range(n_steps):
+        x = torch.zeros(B, 256, device=dev)
+        x[torch.arange(B), torch.from_numpy(rng.randint(0, 256, B))] = 1
+        net.learn(x.reshape(B, 1, 16, 16), y)
+    torch.cuda.synchronize()
+    if graph:
+        assert net._learn_graphs, "the learning step was not replayed from a captured graph"
+    for s, w0 in zip(net.dcll_slices, w_before):
+        assert not torch.equal(s.dclllayer.i2h.weight, w0), "the step did not train"
+        assert s.dclllayer.i2h.int8_weights() is None
+    Wt, bias = last.stacked_readout()
+    assert torch.equal(Wt[24:], last.output_.weight) and torch.equal(bias[24:], last.output_.bias)
+    assert not torch.equal(Wt, Wt0)
+    Wp, _ = last.fused_readout_weights()
+    from snn_modulation_classification_amd import ops
+    assert torch.equal(Wp, ops.permute_readout(torch.cat([last.i2o.weight, last.output_.weight], 0)))
+
+
 # (in_features, out_features, B, T, tensor tau, wrp)
 DENSE_CASES = [(40, 24, 5, 4, False, 1.0), (40, 24, 5, 4, True, 0.0), (257, 130, 133, 3, True, 1.0), (1024, 128, 70, 6, True, 1.0),
                (1000, 96, 33, 5, False, 0.0), (7, 3, 1, 5, True, 1.0), (2050, 64, 40, 3, True, 1.0), (96, 200, 64, 4, False, 1.0)]

@@ -920,3 +920,92 @@ def test_sequence_w3_vs_oracle(dev, cin, hw, wrp, T, B, zero_state):
         assert bits_equal(arp.cpu().numpy(), orc.state[2])
     assert 0.005 < nspk / (T * B * cout * H * Wd / 2) < 0.95, "degenerate test"
 
+
+
+@pytest.mark.parametrize("case", ["radio_l1", "radio_l2_out", "radio_norp", "scalar_tau", "mnist_l2", "ref_tuple", "pool3"])
+def test_integration_md_binding_executes_and_matches_oracle(golden, golden_meta, dev, case):
+    """INTEGRATION.md section B documents the binding a maintainer of the reference would add to route
+    Conv2dDCLLlayer.forward (reference dcll/pytorch_libdcll.py:599-608, called at :657) through dcll_conv_lif_step.  This
+    test EXECUTES that documentation: the fenced block with `def hip_forward` is extracted from INTEGRATION.md, exec'd
+    (only the library's file name is replaced by its in-tree path), bound as `forward` onto a minimal object that carries
+    the attribute set of the REFERENCE's layer classes (i2h.{in_channels, out_channels, kernel_size, padding, weight, bias,
+    alpha, tau_m__dt, alphas, tau_s__dt, state, init_state, get_output_shape[, wrp, alpharp]}, i2o, output_, im_dims,
+    pooling, target_size, output_layer, output_shape — none of this build's classes), and three free-running steps of a
+    G1 golden case are checked against the C oracle: v / spikes / state bit for bit, logits within 1e-4."""
+    import os
+    import re
+    import types
+    from collections import namedtuple
+    from conftest import ROOT
+    from oracle import c_oracle as C
+    from snn_modulation_classification_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def hip_forward" in b]
+    assert len(blocks) == 1, "INTEGRATION.md must hold exactly one fenced python block defining hip_forward"
+    src = blocks[0]
+    assert src.count('ctypes.CDLL("libdcll_hip.so")') == 1
+    _lib.get()                                     # (built, and torch's HIP runtime is the one in the process)
+    src = src.replace('ctypes.CDLL("libdcll_hip.so")', 'ctypes.CDLL(%r)' % _lib.SO_PATH)
+    ns = {}
+    exec(compile(src, "INTEGRATION.md:hip_forward", "exec"), ns)
+
+    g = golden("g1_layer_steps.npz")
+    m = golden_meta["g1"][case]
+    sd = g.sub("g1/%s/sd/" % case)
+    t = {k: cu(v, dev) for k, v in sd.items()}
+    B, cin, cout = m["B"], m["cin"], m["cout"]
+    pair = lambda v: tuple(v) if hasattr(v, "__len__") else (v, v)
+    kh, kw = pair(m["k"])
+    pad, pool, im = pair(m["pad"]), pair(m["pool"]), tuple(m["im"])
+    refractory = m["wrp"] > 0
+    State = namedtuple("NeuronState", ("eps0", "eps1", "arp") if refractory else ("eps0", "eps1"))
+
+    i2h = types.SimpleNamespace(in_channels=cin, out_channels=cout, kernel_size=(kh, kw), padding=pad,
+                                weight=t["i2h.weight"], bias=t["i2h.bias"], alpha=t["i2h.alpha"],
+                                tau_m__dt=t["i2h.tau_m__dt"], alphas=t["i2h.alphas"], tau_s__dt=t["i2h.tau_s__dt"])
+    if refractory:                                 # (the reference's plain variant has neither attribute)
+        i2h.wrp, i2h.alpharp = m["wrp"], m["alpharp"]
+    i2h.get_output_shape = lambda dims: (dims[0] + 2 * pad[0] - kh + 1, dims[1] + 2 * pad[1] - kw + 1)   # reference :368-375
+
+    def init_state(batch, dims, init_value=0):     # reference :377-389 / :468-483
+        ch_, cw_ = i2h.get_output_shape(dims)
+        st = [torch.zeros(batch, cin, *dims, device=dev), torch.zeros(batch, cin, *dims, device=dev)]
+        if refractory:
+            st.append(torch.zeros(batch, cout, ch_, cw_, device=dev))
+        i2h.state = State(*st)
+    i2h.init_state = init_state
+    init_state(B + 1, im)                          # wrong batch on purpose: the stub must re-allocate like :488-491
+    ch, cw = i2h.get_output_shape(im)
+    oh, ow = (ch + 2 * ((pool[0] - 1) // 2) - pool[0]) // pool[0] + 1, (cw + 2 * ((pool[1] - 1) // 2) - pool[1]) // pool[1] + 1
+    layer = types.SimpleNamespace(i2h=i2h, im_dims=im, pooling=pool, target_size=24, output_layer=bool(m["output_layer"]),
+                                  output_shape=(oh, ow),
+                                  i2o=types.SimpleNamespace(weight=t["i2o.weight"], bias=t["i2o.bias"]))
+    if m["output_layer"]:
+        layer.output_ = types.SimpleNamespace(weight=t["output_.weight"], bias=t["output_.bias"])
+    layer.forward = types.MethodType(ns["hip_forward"], layer)
+
+    orc = C.OracleConvLayer(sd, m["im"], m["pad"], m["pool"], m["wrp"], m["alpharp"], m["output_layer"])
+    for step in range(3):
+        x = g["g1/%s/x%d" % (case, step)]
+        out, p, pv, v = layer.forward(cu(x, dev))
+        torch.cuda.synchronize()
+        oo, op, opv, ov, os_ = orc.forward(x)
+        assert i2h.state.eps0.shape[0] == B
+        assert bits_equal(i2h.state.eps0.cpu().numpy(), orc.state[0])
+        assert bits_equal(i2h.state.eps1.cpu().numpy(), orc.state[1])
+        assert bits_equal(v.cpu().numpy(), ov)
+        if refractory:
+            assert bits_equal(i2h.state.arp.cpu().numpy(), orc.state[2])
+        np.testing.assert_allclose(pv.cpu().numpy(), opv, atol=PV_TOL, rtol=0)
+        np.testing.assert_allclose(p.cpu().numpy(), op, atol=LOGIT_TOL, rtol=0)
+        if m["output_layer"]:
+            np.testing.assert_allclose(out.cpu().numpy(), oo, atol=LOGIT_TOL, rtol=0)
+        else:
+            assert np.array_equal(out.cpu().numpy(), os_)
+    # the documented error convention: a negative status + dcll_last_error() -> RuntimeError, nothing thrown across the ABI
+    bad = types.SimpleNamespace(**vars(layer))
+    bad.i2h = types.SimpleNamespace(**vars(i2h))
+    bad.i2h.kernel_size = (0, kw)
+    bad.forward = types.MethodType(ns["hip_forward"], bad)
+    with pytest.raises(RuntimeError):
+        bad.forward(cu(g["g1/%s/x0" % case], dev))

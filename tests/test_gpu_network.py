@@ -692,6 +692,37 @@ def test_top1_agreement_and_spike_flips_vs_reference_cpu_path_10240_windows(caps
     #  SURVEY 7 H1 measured 3e-6 of all values below 1e-7 — not a defect count: it is reported above, not bounded here)
 
 
+@pytest.mark.timeout(2400)
+def test_top1_parity_on_trained_weights_10240_windows(trained_checkpoint, capsys):
+    """north_star: "top-1 accuracy within 0.1 % of reference" — on a network that has LEARNED something.  The reference's
+    protocol is train (train.py:239-254, checkpoint :297-303) -> restore (test_radio_ml.py:97-110) -> evaluate (:142-146,
+    accuracy_by_vote dcll/pytorch_libdcll.py:44-61).  Here: radio_ml_conv.yaml trained by the build's train.py on the GPU
+    (40 batches of 512 synthetic modulation windows, 16x16, arp 1.0, T=128; conftest.trained_checkpoint), restored the
+    reference's way, and the SAME 20 x 512 held-out windows (SNR 6 .. 30 dB) evaluated on (i) the fused HIP path and (ii)
+    oracle/torch_ref.py on the restored tensors:
+      * every layer's top-1 is far above chance (1/24) — the comparison is not made in the degenerate regime of the seeded
+        init, where biases dominate and accuracy = chance;
+      * |top-1(GPU) - top-1(reference CPU path)| <= 0.1 % per layer, votes agree on >= 99.9 % of the windows per layer,
+        the per-step argmax of the output layer on >= 99.9 % of the (t, window) pairs;
+      * spike flips of the trained network reported beside the untrained ones (test above), first flips inside the band."""
+    from oracle import trained_parity
+    NB, B = 20, 512
+    net, ref, convs, enc = trained_parity.restore_pair(trained_checkpoint, B)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    batches = trained_parity.held_out_batches(NB, B)
+    rep = trained_parity.evaluate(net, ref, enc, batches, count_flips=True)
+    with capsys.disabled():
+        print("\n[top-1 on trained weights, fused HIP path vs reference CPU path] %s" % json.dumps(rep))
+    assert rep["windows"] == NB * B >= 10240
+    assert min(rep["top1_gpu"]) > 5 * rep["chance"] and min(rep["top1_cpu_reference_path"]) > 5 * rep["chance"], rep
+    assert max(rep["top1_abs_diff"]) <= 1e-3, rep
+    assert min(rep["vote_agreement_per_layer"]) >= 0.999, rep
+    assert rep["output_layer_per_step_argmax_agreement"] >= 0.999, rep
+    fl = rep["spike_flips"]
+    assert fl["first_flips_outside_rounding_band"] == 0, fl
+    assert fl["first_flips_inside_rounding_band"] == fl["windows_with_a_flip"]
+
+
 class _Writer:
     def __init__(self):
         self.scalars = {}
