@@ -94,6 +94,11 @@ def per_step_paths(dev, batch=512, steps=48, reps=3):
     y[torch.arange(batch), torch.randint(0, N_CLASSES, (batch,))] = 1
     cyc_per_ms = _spin_calibration(dev)
     out = {"batch": batch, "timesteps_timed": steps, "repetitions": reps}
+    # A full pass of CPython's cyclic collector over this process's heap (~265 k tracked objects, most of them torch's
+    # import-time ones) takes ~100 ms: landing in a 48-timestep window it reads as +2 ms per timestep (round-3 driver run:
+    # learn 1.99 instead of 0.73 ms; experiments/per_step_outliers.py shows the collector's own clock).  The entry
+    # points freeze the start-up heap (parallel.freeze_startup_heap): later full passes only walk what the loop allocated.
+    parallel.freeze_startup_heap()
     for name, fn in (("test", lambda t: net.test(x[t])), ("learn", lambda t: net.learn(x[t], y))):
         net.reset()
         for t in range(warm):

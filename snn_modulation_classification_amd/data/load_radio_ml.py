@@ -6,9 +6,12 @@ the first `per_h5_frac` of the examples is used, split into train / test at `tra
 INTERLEAVED (sample k of block j sits at index j + k * n_blocks), samples shaped (2, 1, L) float32, labels int64.
 
 Block sources, tried in this order inside `data_dir`:
-  class{c}_snr{s}.hdf5   the reference's per-(class, SNR) split of RadioML 2018.01A ('X': (n, 1024, 2)); needs h5py,
-                         which this image does not have — the import is attempted only when such files exist
+  class{c}_snr{s}.hdf5   the reference's per-(class, SNR) split of RadioML 2018.01A ('X': (n, 1024, 2)), read with h5py
+                         when it is installed, else with the build's own minimal reader (data/mini_hdf5.py: contiguous
+                         datasets of old-style files, which is what h5py's create_dataset(data=...) writes)
   class{c}_snr{s}.npy    the same blocks as plain numpy files (n, L, 2) — build-specific, h5py-free
+  GOLD_XYZ_OSC.0001_1024.hdf5   the monolithic 2018.01A file ('X' (N,1024,2) f32, 'Y' (N,24) one-hot, 'Z' (N,1) SNR): split
+                         into per-(class, SNR) blocks on first use like the reference does (:23-50) — as .npy blocks
   RML2016.10a_dict.pkl   RadioML 2016.10a: pickled dict {(modulation, snr): (n, 2, 128)} (11 classes) — the dataset
                          BASELINE.json names; the reference itself cannot read it
 """
@@ -20,6 +23,40 @@ import torch
 from torch.utils.data import DataLoader, TensorDataset
 
 RML2016_FILES = ("RML2016.10a_dict.pkl", "RML2016.10a_dict.dat")
+GOLD_2018 = "GOLD_XYZ_OSC.0001_1024.hdf5"
+
+
+def open_hdf5(path):
+    """A read-only mapping name -> array-like of the datasets in the root group of `path`: h5py.File when h5py is
+    installed, else data/mini_hdf5.MiniHdf5 (numpy memmaps).  The caller slices what it needs."""
+    try:
+        import h5py
+    except ImportError:
+        from .mini_hdf5 import MiniHdf5
+        return MiniHdf5(path)
+    return h5py.File(path, "r")
+
+
+def split_gold_file(data_dir, log=print):
+    """The reference's first-use split of the monolithic RadioML 2018.01A file into per-(class, SNR) blocks
+    (data/load_radio_ml.py:23-50: labels = argmax of the one-hot 'Y', SNR = 'Z'[:, 0], one block per class and SNR, examples
+    in file order), written as class{c}_snr{s}.npy (the h5py-free block format of this build).  X is sliced class by class
+    through a memmap (the file is 20 GB; the data is ordered by class, :31-34)."""
+    f = open_hdf5(os.path.join(data_dir, GOLD_2018))
+    Y = np.argmax(np.asarray(f["Y"][:]), axis=1)
+    Z = np.asarray(f["Z"][:])[:, 0]
+    X = f["X"]
+    for c in range(int(Y.max()) + 1):
+        idx = np.nonzero(Y == c)[0]
+        if len(idx) == 0:
+            continue
+        lo, hi = int(idx[0]), int(idx[-1]) + 1            # one class = one contiguous stretch of the file
+        class_x = np.asarray(X[lo:hi])[idx - lo]
+        class_z = Z[idx]
+        for snr in np.unique(class_z):
+            path = os.path.join(data_dir, "class%d_snr%d.npy" % (c, int(snr)))
+            np.save(path, np.ascontiguousarray(class_x[class_z == snr], dtype=np.float32))
+            log("Wrote (SNR {z}, class {cl}) data to `{path}`.".format(z=int(snr), cl=c, path=path))
 
 
 def _block_2018(data_dir, class_idx, snr):
@@ -28,13 +65,7 @@ def _block_2018(data_dir, class_idx, snr):
     if os.path.exists(stem + ".npy"):
         return np.load(stem + ".npy").astype(np.float32, copy=False)
     if os.path.exists(stem + ".hdf5"):
-        try:
-            import h5py
-        except ImportError:
-            raise RuntimeError("%s.hdf5 needs h5py, which is not installed; convert the blocks to .npy "
-                               "(same name, array (n, L, 2))" % stem)
-        with h5py.File(stem + ".hdf5", "r") as f:
-            return f["X"][:].astype(np.float32, copy=False)
+        return np.asarray(open_hdf5(stem + ".hdf5")["X"][:]).astype(np.float32, copy=False)
     return None
 
 
@@ -60,6 +91,9 @@ def load_split(data_dir, train, min_snr=6, max_snr=30, per_h5_frac=0.5, train_fr
         get = lambda c, s: table.get((c, s))
     else:
         n_classes = 24
+        if (os.path.exists(os.path.join(data_dir, GOLD_2018)) and
+                not any(os.path.exists(os.path.join(data_dir, "class23_snr30" + ext)) for ext in (".hdf5", ".npy"))):
+            split_gold_file(data_dir)                 # the reference's trigger: no class23_snr30 block yet (:23)
         get = lambda c, s: _block_2018(data_dir, c, s)
     blocks = []
     for c in range(n_classes):

@@ -202,6 +202,7 @@ def main(argv=None):
             say('-' * 80)
         net = net.to(pytorch_libdcll.device)
         net.reset(True)
+        parallel.freeze_startup_heap()      # (a full GC pass over the start-up heap costs ~100 ms inside the T-loop)
         use_sequence = net.sequence_supported() and not args.no_sequence_path
         encoder = IQEncoder(args.I_resolution, args.Q_resolution, args.I_bounds, args.Q_bounds,
                             device=pytorch_libdcll.device) if use_sequence else None

@@ -526,3 +526,68 @@ def test_iq_threshold_tables_and_tail_mask_reproduce_the_host_encoder(B):
         ci = (iq[mask, 0][:, :, None] >= ti[None, None, :]).sum(2)
         one = (iq[mask, 0][:, :, None] >= enc.thr_i_tail.numpy()[None, None, :]).sum(2)
         assert (ci != one).any()
+
+
+# -- RadioML 2018.01A on disk (reference data/load_radio_ml.py:10-109) -------------------------------------
+from conftest import GOLDEN  # noqa: E402
+RML2018 = os.path.join(GOLDEN, "radioml2018")
+
+
+def test_mini_hdf5_reads_files_written_by_the_real_library():
+    """data/mini_hdf5.py against HDF5 files written by h5py 3.3.0 / HDF5 1.10.6 the way the reference writes them
+    (tests/golden/make_hdf5_fixtures.py): the monolithic X / Y / Z layout and a per-(class, SNR) block — shapes, dtypes and
+    every value; unsupported layouts are refused by name, not mis-read."""
+    from snn_modulation_classification_amd.data.mini_hdf5 import Hdf5Unsupported, MiniHdf5
+    exp = np.load(os.path.join(RML2018, "expected.npz"))
+    f = MiniHdf5(os.path.join(RML2018, "gold_mini", "GOLD_XYZ_OSC.0001_1024.hdf5"))
+    assert f.keys() == ["X", "Y", "Z"] and "X" in f and "W" not in f
+    for k, dt in (("X", np.float32), ("Y", np.int64), ("Z", np.int64)):
+        a = f[k]
+        assert a.dtype == dt and a.shape == exp[k].shape and np.array_equal(np.asarray(a), exp[k])
+        assert np.array_equal(np.asarray(a[5:9]), exp[k][5:9])            # sliced like an h5py dataset
+    b = MiniHdf5(os.path.join(RML2018, "blocks", "class7_snr30.hdf5"))
+    assert np.array_equal(np.asarray(b["X"]), exp["class7_snr30"])
+    with pytest.raises(KeyError):
+        f["nope"]
+    with pytest.raises(Hdf5Unsupported):
+        MiniHdf5(os.path.join(RML2018, "expected.npz"))                   # not an HDF5 file
+
+
+def test_radio_ml_2018_hdf5_blocks_through_the_loader(tmp_path):
+    """The .hdf5 branch of the loader (reference :52-109) on real per-(class, SNR) HDF5 blocks: the reference's use / train /
+    test fractions and its INTERLEAVED ordering (sample k of block j at index j + k * n_blocks, :90-93)."""
+    from snn_modulation_classification_amd.data import load_radio_ml as L
+    exp = np.load(os.path.join(RML2018, "expected.npz"))
+    d = os.path.join(RML2018, "blocks")
+    X, Y, n_cls = L.load_split(d, True, min_snr=28, max_snr=30, per_h5_frac=0.8, train_frac=0.75)
+    # 5 examples per block: use int(.8 * 5) = 4, train int(.75 * 4) = 3; blocks ordered class-major, SNR-minor
+    assert n_cls == 24 and X.shape == (48 * 3, 2, 1, 8) and X.dtype == np.float32
+    for j, (c, s) in enumerate((c, s) for c in range(24) for s in (28, 30)):
+        blk = exp["class%d_snr%d" % (c, s)]
+        for k in range(3):
+            assert Y[j + 48 * k] == c
+            assert np.array_equal(X[j + 48 * k, :, 0, :], blk[k].T)
+    Xt, Yt, _ = L.load_split(d, False, min_snr=28, max_snr=30, per_h5_frac=0.8, train_frac=0.75)
+    assert Xt.shape == (48, 2, 1, 8) and np.array_equal(Xt[5, :, 0, :], exp["class2_snr30"][3].T) and Yt[5] == 2
+    loader = L.get_radio_ml_loader(16, train=False, data_dir=d, min_snr=28, max_snr=30, per_h5_frac=0.8, train_frac=0.75)
+    xb, yb = next(iter(loader))
+    assert tuple(xb.shape) == (16, 2, 1, 8) and yb.dtype == torch.int64
+
+
+def test_radio_ml_2018_monolithic_file_is_split_on_first_use(tmp_path):
+    """GOLD_XYZ_OSC.0001_1024.hdf5 alone in the data directory: the loader first splits it per (class, SNR) like the
+    reference's dataset constructor (:23-50: label = argmax of 'Y', SNR = 'Z'[:, 0], file order kept), then loads."""
+    import shutil
+    from snn_modulation_classification_amd.data import load_radio_ml as L
+    exp = np.load(os.path.join(RML2018, "expected.npz"))
+    shutil.copy(os.path.join(RML2018, "gold_mini", L.GOLD_2018), tmp_path / L.GOLD_2018)
+    X, Y, _ = L.load_split(str(tmp_path), True, min_snr=28, max_snr=30, per_h5_frac=1.0, train_frac=1.0)
+    assert X.shape == (48 * 3, 2, 1, 8)
+    lab, snr = exp["Y"].argmax(1), exp["Z"][:, 0]
+    for c in (0, 11, 23):
+        for s in (28, 30):
+            want = exp["X"][(lab == c) & (snr == s)]
+            got = np.load(tmp_path / ("class%d_snr%d.npy" % (c, s)))
+            assert got.dtype == np.float32 and np.array_equal(got, want)
+    j = 2 * 11 + 1                                   # block (class 11, SNR 30)
+    assert np.array_equal(X[j + 48 * 2, :, 0, :], exp["X"][(lab == 11) & (snr == 30)][2].T)

@@ -131,6 +131,7 @@ def main(argv=None):
         print('-' * 80)
     net = net.to(pytorch_libdcll.device)
     net.reset(True)
+    parallel.freeze_startup_heap()          # (a full GC pass over the start-up heap costs ~100 ms inside the T-loop)
 
     if not args.no_save:
         with open(os.path.join(out_dir, 'args.txt'), 'w') as f:
@@ -279,6 +280,7 @@ def main_mnist(args):
         print('Loaded the SNN model from `%s`.' % args.restore_path)
     net = net.to(pytorch_libdcll.device)
     net.reset(True)
+    parallel.freeze_startup_heap()          # (a full GC pass over the start-up heap costs ~100 ms inside the T-loop)
     n_test = int(np.ceil(float(args.n_test_samples) / args.batch_size_test))
     if args.synthetic:
         g = torch.Generator().manual_seed(args.seed)
