@@ -40,6 +40,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 PEAK_HBM_GBS = 8000.0
 
 
+def executed_frac(plane):
+    """MFMA k-steps the 32->32 layer kernel issues / the algorithmic count.  16x16 (k_lif_seq_c32d, tiles of two image
+    rows): the tap rows that lie in the zero padding for both rows of a border tile are not multiplied — 4 of the 56
+    (tile, tap row) combinations of a sample.  Larger planes (k_lif_seq_c32t): everything is multiplied; skipping the 6 of
+    56 padded (image row, tap row) combinations of the first / last tile row was built twice in round 4 and measured
+    slower both times (experiments/rejected/c32t_padding_skip_variants.patch.txt)."""
+    return 13.0 / 14.0 if plane == 16 else 1.0
+
+
 def build_net(batch, device):
     convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks",
                                            "radio_ml_conv.yaml"))
@@ -577,12 +586,12 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)",
                          "avg_launch_ms": avg_c32_s * 1e3, "launches": len(c32_ms),
                          "algorithmic_flop_per_launch": flop_per_launch,
-                         # the 16x16 kernel skips the tap rows that lie in the zero padding for both rows of a border
-                         # tile (4 of the 56 (tile, tap row) combinations: fmaf(w, 0, acc) == acc): what the matrix pipe
-                         # executes is 13/14 of the algorithmic count, so `frac` (algorithmic) may exceed
-                         # what the pipe alone allows — the pipe's own busy fraction is frac * executed / algorithmic
-                         "executed_over_algorithmic_flop": (13.0 / 14.0) if R == 16 else 1.0,
-                         "matrix_pipe_frac": achieved / PEAK_FP32_MFMA_TFLOPS * ((13.0 / 14.0) if R == 16 else 1.0),
+                         # the kernels skip tap rows that lie wholly in the zero padding (fmaf(w, 0, acc) == acc;
+                         # executed_frac): what the matrix pipe executes is less than the algorithmic count, so `frac`
+                         # (algorithmic) may exceed what the pipe alone allows — the pipe's own busy fraction
+                         # is frac * executed / algorithmic
+                         "executed_over_algorithmic_flop": executed_frac(R),
+                         "matrix_pipe_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_frac(R),
                          "hbm": {"achieved_GBps": (traffic / avg_c32_s / 1e9) if traffic else None,
                                  "peak_GBps": PEAK_HBM_GBS,
                                  "frac": (traffic / avg_c32_s / 1e9 / PEAK_HBM_GBS) if traffic else None}},

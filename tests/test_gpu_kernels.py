@@ -170,7 +170,8 @@ def test_sequence_output_variants_agree(dev, hw, T, wrp):
 
 
 @pytest.mark.parametrize("hw,wrp,T,B,zero_state", [((32, 32), 1.0, 11, 2, True), ((16, 64), 0.0, 10, 3, False),
-                                                    ((24, 96), 1.0, 9, 2, False), ((128, 128), 1.0, 3, 1, True)])
+                                                    ((24, 96), 1.0, 9, 2, False), ((128, 128), 1.0, 3, 1, True),
+                                                    ((8, 64), 1.0, 9, 2, False)])
 def test_sequence_c32_tiled_vs_oracle(dev, hw, wrp, T, B, zero_state):
     """k_lif_seq_c32t (large planes: one workgroup per 8 x 32 tile with a recomputed 3-pixel trace halo) == C oracle
     stepping, bit for bit, incl. the final state; planes with 1, 2, 3 and 4 tiles per row / column exercise every
