@@ -15,6 +15,22 @@ static float run(int B, float *x, float *W, float *bias, float *tau, float *e0, 
     }
     return best * 1e3f;
 }
+// per-wave shader-clock stamps (DBG & 32): phases of the kernel, averaged over all waves
+template <int DBG>
+static void stamps(int B, float *x, float *W, float *bias, float *tau, float *e0, float *e1, float *arp, float *s, float *pv, float *v)
+{
+    run<DBG | 32>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+    std::vector<unsigned long long> h((size_t)B * 16);
+    hipMemcpy(h.data(), arp + (size_t)B * 8192, h.size() * 8, hipMemcpyDeviceToHost);
+    double pro = 0, loop = 0, epi = 0; unsigned long long t0 = ~0ull, t1 = 0;
+    for (int i = 0; i < B * 4; ++i) {
+        pro += h[4 * i + 1] - h[4 * i]; loop += h[4 * i + 2] - h[4 * i + 1]; epi += h[4 * i + 3] - h[4 * i + 2];
+        if (h[4 * i] < t0) t0 = h[4 * i];
+        if (h[4 * i + 3] > t1) t1 = h[4 * i + 3];
+    }
+    printf("   stamps DBG=%d B=%d: prologue %.0f  chunk loop %.0f (MFMA time of a wave: %d, of a SIMD's %d waves: %d)  epilogue %.0f  first entry -> last exit %llu cycles\n",
+           DBG, B, pro / (B * 4), loop / (B * 4), 1568 * 64, B >= 512 ? 2 : 1, (B >= 512 ? 2 : 1) * 1568 * 64, epi / (B * 4), t1 - t0);
+}
 int main()
 {
     const int BM = 4096;
@@ -37,6 +53,10 @@ int main()
         float g = run<14>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         float h = run<30>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         printf("%6d %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f\n", B, f, a, c, d, e, g, h, 2.0 * 32 * 1568 * 256 * (double)B / 157.3e12 * 1e6);
+    }
+    for (int B : {256, 512}) {
+        stamps<0>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
+        stamps<30>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
     }
     return 0;
 }

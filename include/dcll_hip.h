@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCLL_ABI_VERSION 3
+#define DCLL_ABI_VERSION 4
 
 enum {
     DCLL_OK = 0,
@@ -329,12 +329,29 @@ int dcll_readout_mode(const float *pv, const float *Wt, const float *bias, float
  * tiles go to caller-provided scratch and are added in slice order (deterministic).  Served, with N <= 64 and 16-byte
  * aligned pv / Wt: K >= 65536, K % 4096 == 0 (large planes, K = c_out*128*128: slices of 4096 for rows <= 2048, else 8
  * slices — any row count), or rows <= 2048 with
- * 2048 <= K < 65536, K % 256 == 0 (the 16x16 plane, K = 8192: slices of 256);
+ * 2048 <= K < 65536, K % 256 == 0 (the 16x16 plane, K = 8192: slices of 256 — of 128 for rows <= 512 and N <= 32);
  * scratch_floats >= dcll_readout_splitk_scratch(rows, K, N) (0 = this shape is not supported, use dcll_readout).
  */
 int64_t dcll_readout_splitk_scratch(int64_t rows, int32_t K, int32_t N);
 int dcll_readout_splitk(const float *pv, const float *Wt, const float *bias, float *out, float *scratch,
                         int64_t scratch_floats, int64_t rows, int32_t K, int32_t N, void *stream);
+
+/*
+ * ABI 4 — the readouts of ONE layer step and everything behind them in two launches (per-step calls: rows = batch):
+ *   Conv2dDCLLlayer.forward :602-606     p = i2o(flatten(pv)) and, on the output layer, o = output_(flatten(pv)): ONE
+ *                                        split-K pass over pv against the N1 + N2 STACKED rows Wt / bias (N2 = 0 or N1);
+ *   DCLLClassification.forward :724-728  clout (rows) int32 = argmax of o (of p when N2 == 0), first maximum; NULL = off;
+ *   DCLLBase.train_dcll :692-704         target != NULL: g_p, g_o = gradients of the mean local losses of kind `kind`
+ *                                        (dcll_local_loss_grad without the loss value; NULL = inference step).
+ * p (rows, N1) and o (rows, N2) come out as separate contiguous arrays, bit-identical to dcll_readout_splitk per column.
+ * Shapes: rows <= 2048, 2048 <= K < 65536, K % 256 == 0, N1 + N2 <= 64, 16-byte aligned pv / Wt — else
+ * DCLL_ERR_UNSUPPORTED (callers fall back to dcll_readout + dcll_argmax_vote / dcll_local_loss_grad);
+ * scratch_floats >= dcll_step_readouts_scratch(rows, K, N1, N2).
+ */
+int64_t dcll_step_readouts_scratch(int64_t rows, int32_t K, int32_t N1, int32_t N2);
+int dcll_step_readouts(const float *pv, const float *Wt, const float *bias, float *scratch, int64_t scratch_floats,
+                       int64_t rows, int32_t K, int32_t N1, int32_t N2, float *p, float *o, int32_t *clout,
+                       const float *target, float *g_p, float *g_o, int32_t kind, void *stream);
 
 /*
  * Per-step argmax + vote (DCLLClassification.forward :724-728, get_predictions_by_vote :44-56):

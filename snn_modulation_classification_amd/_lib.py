@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_PKG, "libdcll_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class DCLLHipError(RuntimeError):
@@ -94,6 +94,8 @@ SIGNATURES = {
     "dcll_readout_mode": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "dcll_readout_splitk_scratch": (_I64, [_I64, _I32, _I32]),
     "dcll_readout_splitk": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    "dcll_step_readouts_scratch": (_I64, [_I64, _I32, _I32, _I32]),
+    "dcll_step_readouts": (_I32, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "dcll_argmax_vote": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "dcll_iq_encode": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "dcll_unpack_spikes": (_I32, [_P, _P, _I64, _P]),

@@ -1948,7 +1948,8 @@ static int splitk_slice(int64_t rows, int32_t K, int32_t N)
         // the row count, so a row's logits do not depend on how a batch is chunked.
         return rows <= 2048 ? 4096 : K / 8;
     }
-    if (rows <= 2048 && K >= 2048 && K < 65536 && K % 256 == 0) return 256;
+    // (rows <= 512: 64 slices of 128 — 32 slices x rows/128 row tiles would leave half of the 256 CUs without a workgroup)
+    if (rows <= 2048 && K >= 2048 && K < 65536 && K % 256 == 0) return (rows <= 512 && N <= 32) ? 128 : 256;
     return 0;
 }
 
@@ -2087,6 +2088,10 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // my tile pair: image rows 4w..4w+3
     const long b = blockIdx.x;
+    // DBG & 32 (experiments/ablate_step.hip): shader-clock stamps of every wave — kernel entry, first MFMA row, end of the
+    // chunk loop, end of the epilogue — written behind the arp plane of the launch (timing only)
+    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+    if (DBG & 32) stamp0 = __builtin_amdgcn_s_memtime();
 
     for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
@@ -2142,6 +2147,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
     const int bbase = h * CHF + ((j >> 4) + 4 * w) * ROWF + (j & 15);
+    if (DBG & 32) stamp1 = __builtin_amdgcn_s_memtime();
     for (int cp = 0; cp < 16; ++cp) {
         if (cp + 1 < 16) {                                 // land during the MFMAs below
             if (!(DBG & 8)) fetch_w(cp + 1);
@@ -2179,6 +2185,10 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         }
         if (!(DBG & 16)) __syncthreads();
     }
+    if (DBG & 32) {
+        asm volatile("" ::"v"(accA[0]), "v"(accB[0]));
+        stamp2 = __builtin_amdgcn_s_memtime();
+    }
     // epilogue of my two tiles: channel (r&3) + 8(r>>2) + 4h, pixel 32(2w + tl) + j
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
@@ -2201,6 +2211,12 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             out_pv[o] = sigmoidf_dev(v);
             if (out_v) out_v[o] = v;
         }
+    if ((DBG & 32) && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+        unsigned long long *dst = (unsigned long long *)(arp_g + (long)gridDim.x * 8192) + (b * 4 + w) * 4;
+        dst[0] = stamp0; dst[1] = stamp1; dst[2] = stamp2; dst[3] = stamp3;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

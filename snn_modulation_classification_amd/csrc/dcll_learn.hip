@@ -88,6 +88,114 @@ extern "C" int dcll_local_loss_grad(const float *p, const float *o, const float 
     return DCLL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_step_readout_finish — everything behind the split-K readout GEMM of ONE layer step in one launch (round 4: the
+// per-step paths spent 63 of 340 us per timestep in eight 5-11 us readout launches and three argmax / loss launches):
+// one WAVE per batch row, lane n = stacked readout row n (i2o's N1 rows, then output_'s N2 on the output layer: both
+// share ONE pass over pv).  The lane adds its slices' partial values in k_readout_sum's order (four quarter sub-sums in
+// slice order, ((q0 + q1) + q2) + q3, then the bias: bit-identical to dcll_readout_splitk), writes p / o as separate
+// contiguous (rows, N1) / (rows, N2) arrays, the row's argmax as DCLLClassification.forward records it (:724-728: of o
+// on the output layer, else of p; first maximum like torch.argmax) and — LEARN — the local-loss gradients of
+// k_loss_grad (mean reduction over rows * N1 logits each).
+// ------------------------------------------------------------------------------------------------------------
+template <bool LEARN>
+__global__ __launch_bounds__(256) void k_step_readout_finish(const float *__restrict__ part, const float *__restrict__ bias,
+                                                              long rows, int N1, int N2, int nslice,
+                                                              float *__restrict__ p, float *__restrict__ o,
+                                                              int32_t *__restrict__ clout, const float *__restrict__ target,
+                                                              float *__restrict__ g_p, float *__restrict__ g_o, int kind)
+{
+    // one workgroup per batch row: wave g adds quarter g of the slices for column `lane` (eight loads in flight, added in
+    // slice order), wave 0 combines the four quarters in k_readout_sum's order and does the row's tail
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long r = blockIdx.x;
+    const int N = N1 + N2;
+    const long n_out = rows * N, i = r * N + lane;
+    float acc = 0.0f;
+    if (lane < N) {
+        const int per = (nslice + 3) / 4, s0 = grp * per, s1 = min(nslice, s0 + per);
+        for (int sl = s0; sl < s1; sl += 8) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = sl + k < s1 ? part[(long)(sl + k) * n_out + i] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (sl + k < s1) acc += t[k];
+        }
+    }
+    red[grp][lane] = acc;
+    __syncthreads();
+    if (grp != 0) return;
+    float val = -INFINITY;
+    if (lane < N) {
+        val = (bias ? bias[lane] : 0.0f) + (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]);
+        if (lane < N1) p[r * N1 + lane] = val;
+        else o[r * N2 + (lane - N1)] = val;
+        if (LEARN) {
+            const int n = lane < N1 ? lane : lane - N1;
+            const float inv = 1.0f / (float)(rows * N1);
+            float l, g;
+            loss_elem(val - target[r * N1 + n], kind, l, g);
+            if (lane < N1) g_p[r * N1 + n] = g * inv;
+            else g_o[r * N2 + n] = g * inv;
+        }
+    }
+    if (!clout) return;
+    // argmax over the lanes of the recorded output: (value, index) butterfly; the larger value wins, among equal values the
+    // smaller index (= torch.argmax's first maximum); lanes outside the output carry -inf
+    const int lo = N2 > 0 ? N1 : 0, hi = N2 > 0 ? N : N1;
+    const bool mine = lane >= lo && lane < hi;
+    float bv = mine ? val : -INFINITY;
+    int bi = mine ? lane - lo : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        const bool take = ov > bv || (ov == bv && oi < bi);
+        bv = take ? ov : bv;
+        bi = take ? oi : bi;
+    }
+    if (lane == 0) clout[r] = bi == 0x7fffffff ? 0 : bi;
+}
+
+extern "C" int64_t dcll_step_readouts_scratch(int64_t rows, int32_t K, int32_t N1, int32_t N2)
+{
+    if (K >= 65536 || N1 + N2 > 64 || N1 < 1 || N2 < 0) return 0;          // (long rows: dcll_readout_splitk's 4096-column form)
+    return dcll_readout_splitk_scratch(rows, K, N1 + N2);
+}
+
+extern "C" int dcll_step_readouts(const float *pv, const float *Wt, const float *bias, float *scratch, int64_t scratch_floats,
+                                  int64_t rows, int32_t K, int32_t N1, int32_t N2, float *p, float *o, int32_t *clout,
+                                  const float *target, float *g_p, float *g_o, int32_t kind, void *stream)
+{
+    if (rows == 0) return DCLL_OK;
+    const int N = N1 + N2;
+    if (!pv || !Wt || !scratch || !p || rows < 0 || K < 1 || N1 < 1 || N2 < 0 || (N2 > 0 && (!o || N2 != N1)) ||
+        (target && (!g_p || (N2 > 0 && !g_o))))
+        return fail(DCLL_ERR_INVALID, "dcll_step_readouts: bad argument");
+    if (target && kind != DCLL_LOSS_SMOOTH_L1 && kind != DCLL_LOSS_MSE)
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_step_readouts: SmoothL1Loss (beta 1) and MSELoss, mean reduction");
+    const int64_t need = dcll_step_readouts_scratch(rows, K, N1, N2);
+    if (need == 0 || ((((uintptr_t)pv | (uintptr_t)Wt)) & 15) != 0)
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_step_readouts: needs rows <= 2048, 2048 <= K < 65536, K % 256 == 0, N1 + N2 <= 64 "
+                                          "and 16-byte aligned operands (else dcll_readout + dcll_argmax_vote / dcll_local_loss_grad)");
+    if (scratch_floats < need) return fail(DCLL_ERR_INVALID, "dcll_step_readouts: scratch too small (dcll_step_readouts_scratch)");
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = (int)((int64_t)K * rows * N / need);        // the slice width dcll_readout_splitk uses for this shape
+    int rc = dcll_launch_readout_t16(pv, Wt, nullptr, scratch, rows, K, N, ks, st);
+    if (rc) return rc;
+    const dim3 grid((unsigned)rows);
+    if (target)
+        hipLaunchKernelGGL(k_step_readout_finish<true>, grid, dim3(256), 0, st, scratch, bias, (long)rows, N1, N2, K / ks, p, o,
+                           clout, target, g_p, g_o, kind);
+    else
+        hipLaunchKernelGGL(k_step_readout_finish<false>, grid, dim3(256), 0, st, scratch, bias, (long)rows, N1, N2, K / ks, p, o,
+                           clout, target, g_p, g_o, kind);
+    HIP_CHECK_LAUNCH("k_step_readout_finish");
+    return DCLL_OK;
+}
+
 // torch.optim.Adam (amsgrad = False, maximize = False), one thread per parameter element of the concatenated tensors:
 //   g = grad + weight_decay * p ; m = lerp(m, g, 1 - beta1) ; v = beta2 * v + (1 - beta2) * g * g
 //   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)         bc1 = 1 - beta1^step, bc2 = 1 - beta2^step (host, float64)

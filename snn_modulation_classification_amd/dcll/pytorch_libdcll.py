@@ -272,9 +272,9 @@ class ContinuousConv2D(nn.Module):
                 rows.append(flat[:, 0])
         return torch.stack(rows).contiguous()
 
-    def _step(self, input, pooling=(1, 1), i2o=None, output_=None, out=None):
+    def _step(self, input, pooling=(1, 1), i2o=None, output_=None, out=None, stacked=None, finish=None, want_v=True):
         """Run one step through dcll_conv_lif_step; returns (s_pooled, p, o, pv_pooled, v).  `out`: optional dict of
-        reusable output buffers (ops.conv_lif_step)."""
+        reusable output buffers; `stacked` / `finish`: the fused readout tail of the step (ops.conv_lif_step)."""
         if not self.spiking:
             raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
         self._check_batch(input)
@@ -288,7 +288,7 @@ class ContinuousConv2D(nn.Module):
                 st.eps0, st.eps1, arp,
                 None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
                 None if output_ is None else output_.weight, None if output_ is None else output_.bias, out=out,
-                q8=self.int8_weights())
+                q8=self.int8_weights(), stacked=stacked, finish=finish, want_v=want_v)
 
     def forward(self, input):
         """-> (output spikes, pv, pvmem), un-pooled (reference :407-426)."""
@@ -411,14 +411,13 @@ class Conv2dDCLLlayer(nn.Module):
         self.weights_written()
 
     def weights_written(self):
-        """Drop everything derived from this layer's weights: the int8 form of the conv weight and the stacked / permuted
-        readout matrices.  Their caches are keyed on the tensors' version counters, which in-place torch ops and
+        """Drop everything derived from this layer's weights: the int8 form of the conv weight and the permuted readout
+        matrix of the fused sequence epilogue.  Their caches are keyed on the tensors' version counters, which in-place torch ops and
         load_state_dict advance — but NOT a write through `.data` or through the raw device pointer (dcll_adam_step, the
         native learning step): whoever writes that way calls this."""
         if getattr(self, 'i2h', None) is not None:
             self.i2h._q8 = None
-        self._stack_cache = None
-        self._ro_cache = None
+        self._ro_cache = None                   # (the stacked readout aliases the parameters: nothing to drop)
 
     def get_output_shape(self):
         conv_shape = self.i2h.get_output_shape(self.im_dims)
@@ -441,7 +440,12 @@ class Conv2dDCLLlayer(nn.Module):
                 return o, p, pv, v
             s, p, pv, v = out
             return s, p, pv, v
-        s, p, o, pv, v = self.i2h._step(input, self.pooling, self.i2o, self.output_ if self.output_layer else None)
+        # (`_finish`: a slice asks for the step's fused tail — the recorded argmax — DCLLClassification.forward;
+        #  `_skip_vmem`: ConvNetwork.test discards the tuple, so the un-pooled membrane map is not written: pvmem = None)
+        s, p, o, pv, v = self.i2h._step(input, self.pooling, self.i2o, self.output_ if self.output_layer else None,
+                                        stacked=self.stacked_readout() if self.output_layer else None,
+                                        finish=self.__dict__.get('_finish'),
+                                        want_v=not self.__dict__.get('_skip_vmem', False))
         return (o if self.output_layer else s), p, pv, v
 
     def init_hiddens(self, batch_size, init_value=0):
@@ -475,18 +479,24 @@ class Conv2dDCLLlayer(nn.Module):
 
     def stacked_readout(self):
         """(weight (24|48, K), bias) of i2o, with output_ stacked behind it on the output layer — one readout GEMM
-        then serves both (reference :602-606).  Cached until a weight tensor changes."""
-        mods = [self.i2o] + ([self.output_] if self.output_layer else [])
-        if len(mods) == 1:
+        then serves both (reference :602-606).  Free of copies: the two Linear modules' parameters are made VIEWS of one
+        stacked storage (their `.data` re-bound once, values kept), so every later write to them — an in-place torch op,
+        load_state_dict's copy_, dcll_adam_step through the raw pointer — is a write to the stacked matrix; only a re-bind
+        of `.data` (module.to(), .cpu()) breaks the aliasing, which is detected here by address and re-established."""
+        if not self.output_layer:
             return self.i2o.weight, self.i2o.bias
-        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
-        cache = getattr(self, '_stack_cache', None)
-        if cache is None or cache[0] != key:
+        W1, W2, b1, b2 = self.i2o.weight, self.output_.weight, self.i2o.bias, self.output_.bias
+        n, K = W1.shape
+        st = self.__dict__.get('_stacked')
+        if not (st is not None and st[0].device == W1.device and W1.data_ptr() == st[0].data_ptr() and
+                W2.data_ptr() == st[0].data_ptr() + 4 * n * K and b1.data_ptr() == st[1].data_ptr() and
+                b2.data_ptr() == st[1].data_ptr() + 4 * n and W2.shape == W1.shape):
             with torch.no_grad():
-                cache = (key, torch.cat([m.weight.detach() for m in mods], 0).contiguous(),
-                         torch.cat([m.bias.detach() for m in mods], 0).contiguous())
-            self._stack_cache = cache
-        return cache[1], cache[2]
+                Wt = torch.cat([W1.detach(), W2.detach()], 0).contiguous()
+                bias = torch.cat([b1.detach(), b2.detach()], 0).contiguous()
+                W1.data, W2.data, b1.data, b2.data = Wt[:n], Wt[n:], bias[:n], bias[n:]
+            st = self._stacked = (Wt, bias)
+        return st
 
     def fused_readout_weights(self):
         """(permuted weights, bias) of the readout(s) for the fused epilogue of the 'packed' sequence kernel:
@@ -849,18 +859,29 @@ class DCLLBase(nn.Module):
         bufs = self.__dict__.setdefault('_learn_bufs', {})
         self.iter += 1
         with torch.no_grad():
-            s, p, o, pv, v = i2h._step(input, L.pooling, L.i2o, L.output_ if L.output_layer else None, out=bufs)
+            learned = self.iter >= self.burnin
+            # (DCLLClassification records the per-step argmax once the burn-in is over, :724-728)
+            rec = isinstance(self, DCLLClassification)
+            fin = None
+            if learned and not want_loss:
+                # the readouts' finishing launch also yields the local-loss gradients and the recorded argmax
+                fin = dict(clout=(clout_out if clout_out is not None else True) if rec else None, target=target,
+                           kind=self._native_learning())
+            s, p, o, pv, v = i2h._step(input, L.pooling, L.i2o, L.output_ if L.output_layer else None, out=bufs,
+                                       stacked=L.stacked_readout() if L.output_layer else None, finish=fin)
             if self.collect_stats and (self.iter % 20) == 0:
                 self.activity_hist.append((ops.pv_lowhigh(pv, 1, self.iter - 1)[0], pv.numel()))
-            learned = self.iter >= self.burnin
             if learned:
-                # (DCLLClassification records the per-step argmax once the burn-in is over, :724-728: same kernel)
-                rec = isinstance(self, DCLLClassification)
-                res = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(), out=bufs,
-                                          want_loss=want_loss, want_clout=rec, clout_out=clout_out)
-                g_p, g_o, loss = res[:3]
-                if rec and clout_out is None:
-                    self._clout.append(res[3])
+                if fin is not None and fin.get('done'):
+                    g_p, g_o, loss = fin['g_p'], fin['g_o'], None
+                    if rec and clout_out is None:
+                        self._clout.append(fin['clout'])
+                else:
+                    res = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(), out=bufs,
+                                              want_loss=want_loss, want_clout=rec, clout_out=clout_out)
+                    g_p, g_o, loss = res[:3]
+                    if rec and clout_out is None:
+                        self._clout.append(res[3])
                 prm = [i2h.weight, i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
                 for q in prm:
                     if q.grad is None:
@@ -985,11 +1006,23 @@ class DCLLBase(nn.Module):
 
 class DCLLClassification(DCLLBase):
     def forward(self, input, ignore_burnin=False):
-        o, p, pv, pvmem = super().forward(input)
-        if ignore_burnin or self.iter >= self.burnin:
-            logits = o if self.dclllayer.output_layer else p
+        L = self.dclllayer
+        record = ignore_burnin or (self.iter + 1) >= self.burnin
+        fused = (record and isinstance(L, Conv2dDCLLlayer) and
+                 not (getattr(L, 'build_graph', False) and torch.is_grad_enabled()))      # (not the autograd node)
+        if fused:
+            L._finish = {'clout': True}         # the step's finishing launch also writes the argmax recorded below
+        try:
+            o, p, pv, pvmem = super().forward(input)
+        finally:
+            fin = L.__dict__.pop('_finish', None) if fused else None
+        if record:
             # kept on the device (no sync per step, unlike the reference's .cpu() at :726-728); converted on demand
-            self._clout.append(ops.argmax(logits.detach()))          # k_argmax: first maximum wins, like torch.argmax
+            if fin is not None and fin.get('done') and fin.get('clout') is not None:
+                self._clout.append(fin['clout'])
+            else:
+                logits = o if L.output_layer else p
+                self._clout.append(ops.argmax(logits.detach()))      # k_argmax: first maximum wins, like torch.argmax
         return o, p, pv, pvmem
 
     def set_sequence_result(self, clout_dev, n_steps, lowhigh=None, numel=0, vote=None):

@@ -362,6 +362,24 @@ class ConvNetwork(torch.nn.Module):
             for k in range(planes.shape[0]):
                 self.learn(planes[k].reshape(B, 1, H, W), labels)
 
+    def _no_vmem(self):
+        """Context in which the layers' per-step forward does not write pvmem (the 4th element of its tuple is None):
+        net.test discards every layer's tuple except the spikes it chains (reference :182-185), and the un-pooled membrane
+        map is 32 KB per sample and layer step of pure HBM write traffic."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            layers = [s.dclllayer for s in self.dcll_slices if isinstance(s.dclllayer, Conv2dDCLLlayer)]
+            for L in layers:
+                L._skip_vmem = True
+            try:
+                yield
+            finally:
+                for L in layers:
+                    L.__dict__.pop('_skip_vmem', None)
+        return ctx()
+
     def test(self, x):
         """One inference timestep in every slice (reference :182-185).  At batches where the host's launch path sets
         the pace the step is replayed from a captured hipGraph (see _test_graphed)."""
@@ -370,8 +388,9 @@ class ConvNetwork(torch.nn.Module):
                 return
             self._graph_interrupted('test', tuple(x.shape))
         spikes = x
-        for s in self.dcll_slices:
-            spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
+        with self._no_vmem():
+            for s in self.dcll_slices:
+                spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
         if isinstance(x, torch.Tensor):
             key = tuple(x.shape)
             self._test_eager_steps[key] = self._test_eager_steps.get(key, 0) + 1
@@ -428,7 +447,7 @@ class ConvNetwork(torch.nn.Module):
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(x.device)
             try:
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'), self._no_vmem():
                     spikes, rows = g['x'], []
                     for s in self.dcll_slices:
                         spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)

@@ -84,13 +84,18 @@ def _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=None, tau4=None):
 
 
 def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None,
-                  out_W=None, out_b=None, want_v=True, out=None, q8=None):
+                  out_W=None, out_b=None, want_v=True, out=None, q8=None, stacked=None, finish=None):
     """One Conv2dDCLLlayer.forward step (dcll/pytorch_libdcll.py:599-608); state tensors are updated in place.
 
     Returns (s_pooled, p, o, pv_pooled, v) — p / o are None when the corresponding weights are None.
     `out`: optional dict of preallocated outputs ('s', 'pv', 'v', 'p', 'o', 'scratch'; filled in when absent) — the
     learning loop reuses one set per layer instead of allocating five tensors per step.
     `q8`: (int8 weights, per-output-channel scale) — the kernels then read the conv weight as int8 (W may be None).
+    `stacked`: (Wt, bias) = i2o's rows with output_'s stacked behind them (Conv2dDCLLlayer.stacked_readout): on the output
+    layer both readouts then share ONE pass over pv (dcll_step_readouts).
+    `finish`: dict asking dcll_step_readouts for what follows the readouts of this step — 'clout': True or an int32 (B)
+    tensor to write the recorded argmax to; 'target' (B, target) + 'kind': the local-loss gradients — left in `finish` as
+    'clout', 'g_p', 'g_o' (only where the fused path serves the shape: finish['done'] says so).
     """
     out = {} if out is None else out
     B = x.shape[0]
@@ -121,6 +126,25 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     p = buf('p', (B, desc.target), i2o_W is not None)
     o = buf('o', (B, desc.target), bool(desc.output_layer))
     scratch = buf('scratch', (2, B, desc.c_out, ch, cw), pooled)
+    if finish is not None:
+        finish['done'] = False
+    n2 = desc.target if desc.output_layer else 0
+    if (i2o_W is not None and B <= 2048 and 2 * desc.target <= 64 and
+            _lib.get().dcll_step_readouts_scratch(B, K_ro, desc.target, n2) > 0 and pv.data_ptr() % 16 == 0 and
+            (stacked is not None or not desc.output_layer) and
+            (i2o_W if stacked is None else stacked[0]).data_ptr() % 16 == 0):
+        # few rows (rows = batch): conv + neuron kernel, ONE split-K readout pass over pv for i2o (+ output_), ONE finishing
+        # launch (slice sums, p / o, the recorded argmax, the local-loss gradients)
+        d2 = ConvDesc.from_buffer_copy(desc)
+        d2.output_layer = 0
+        rc = _lib.get().dcll_conv_lif_step(
+            ctypes.byref(d2), ptr(x), ptr(W), ptr(b), ptr(alpha), ptr(tau_m), ptr(alphas), ptr(tau_s),
+            ptr(eps0), ptr(eps1), ptr(arp), None, None, None, None,
+            ptr(s), None, None, ptr(pv), ptr(v), ptr(scratch), opts, B, stream_ptr())
+        check(rc, "dcll_conv_lif_step")
+        Wt, bias = (i2o_W, i2o_b) if stacked is None else stacked
+        step_readouts(pv.reshape(B, -1), Wt, bias, desc.target, n2, p, o, scratch=out, finish=finish)
+        return s, p, o, pv, v
     if (i2o_W is not None and B <= 2048 and _lib.get().dcll_readout_splitk_scratch(B, K_ro, desc.target) > 0 and
             pv.data_ptr() % 16 == 0 and i2o_W.data_ptr() % 16 == 0 and
             (not desc.output_layer or out_W.data_ptr() % 16 == 0)):
@@ -395,6 +419,52 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
 
 
 READOUT_AUTO, READOUT_CORESIDENT, READOUT_LDS, READOUT_T16 = 0, 1, 2, 3       # dcll_readout_mode (include/dcll_hip.h)
+
+
+def step_readouts(pv2d, Wt, bias, N1, N2, p, o, scratch=None, finish=None):
+    """dcll_step_readouts: the readouts of one layer step (rows = batch) against the N1 + N2 stacked rows Wt / bias in one
+    split-K pass + one finishing launch that writes p (rows, N1), o (rows, N2) and — `finish` (see conv_lif_step) — the
+    recorded argmax and the local-loss gradients.  `scratch`: dict keeping the partial-sum area ('step_ro') and the
+    gradient buffers between calls."""
+    rows, K = pv2d.shape
+    _expect(Wt, "Wt", torch.float32, (N1 + N2, K))
+    _expect(bias, "bias", torch.float32, (N1 + N2,))
+    _expect(p, "p", torch.float32, (rows, N1))
+    if N2:
+        _expect(o, "o", torch.float32, (rows, N2))
+    lib = _lib.get()
+    scratch = {} if scratch is None else scratch
+    need = lib.dcll_step_readouts_scratch(rows, K, N1, N2)
+    area = scratch.get('step_ro')
+    if area is None or area.numel() < need or area.device != pv2d.device:
+        area = scratch['step_ro'] = torch.empty((need,), device=pv2d.device, dtype=torch.float32)
+    clout = target = g_p = g_o = None
+    kind = 0
+    if finish is not None:
+        cl = finish.get('clout')
+        if cl is True:
+            cl = torch.empty((rows,), device=pv2d.device, dtype=torch.int32)
+        if cl is not None and cl is not False:
+            _expect(cl, "clout", torch.int32, (rows,))
+            clout = cl
+        target = finish.get('target')
+        if target is not None:
+            _expect(target, "target", torch.float32, (rows, N1))
+            target = target.contiguous()
+            kind = int(finish['kind'])
+
+            def gbuf(key, n):
+                t = scratch.get(key)
+                if t is None or tuple(t.shape) != (rows, n) or t.device != pv2d.device:
+                    t = scratch[key] = torch.empty((rows, n), device=pv2d.device, dtype=torch.float32)
+                return t
+            g_p = gbuf('g_p', N1)
+            g_o = gbuf('g_o', N2) if N2 else None
+    check(lib.dcll_step_readouts(ptr(pv2d), ptr(Wt), ptr(bias), ptr(area), need, rows, K, N1, N2, ptr(p), ptr(o), ptr(clout),
+                                 ptr(target), ptr(g_p), ptr(g_o), kind, stream_ptr()), "dcll_step_readouts")
+    if finish is not None:
+        finish.update(done=True, clout=clout, g_p=g_p, g_o=g_o)
+    return p, o
 
 
 def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO, scratch=None):

@@ -538,11 +538,12 @@ def test_readout_gemm_long_rows(dev, rows, K, N):
                                       (2048, 8192, 33), (2300, 131072, 24)])
 def test_readout_few_rows_long_k(dev, rows, K, N):
     """dcll_readout_splitk (through ops.readout): few rows — the per-step readouts, rows = batch — with K split over the
-    chip: 4096-column slices of a very long K (128x128 plane), 256-column slices on the 16x16 plane (K = 8192); partial
-    tiles summed in slice order (run-to-run identical)."""
+    chip: 4096-column slices of a very long K (128x128 plane), 256-column slices on the 16x16 plane (K = 8192; 128-column
+    slices up to 512 rows of <= 32 readout rows: 256 instead of 128 workgroups); partial tiles summed in slice order
+    (run-to-run identical)."""
     from snn_modulation_classification_amd import ops, _lib
     assert _lib.get().dcll_readout_splitk_scratch(rows, K, N) == \
-        ((8 if rows > 2048 else K // 4096) if K >= 65536 else K // 256) * rows * N
+        ((8 if rows > 2048 else K // 4096) if K >= 65536 else K // (128 if (rows <= 512 and N <= 32) else 256)) * rows * N
     assert _lib.get().dcll_readout_splitk_scratch(rows, 8192 + 32, N) == 0
     assert _lib.get().dcll_readout_splitk_scratch(4096, 8192, N) == 0          # many rows: the plain GEMM
     rng = np.random.RandomState(4)
@@ -1010,3 +1011,50 @@ def test_integration_md_binding_executes_and_matches_oracle(golden, golden_meta,
     bad.forward = types.MethodType(ns["hip_forward"], bad)
     with pytest.raises(RuntimeError):
         bad.forward(cu(g["g1/%s/x0" % case], dev))
+
+
+@pytest.mark.parametrize("rows,K,N2,learn", [(512, 8192, 0, False), (512, 8192, 24, True), (37, 8192, 24, False),
+                                              (1024, 2048, 0, True), (5, 4096, 24, True)])
+def test_step_readouts_fused_tail_equals_the_separate_calls(dev, rows, K, N2, learn):
+    """dcll_step_readouts (ABI 4): ONE split-K pass over pv against the stacked i2o / output_ rows + ONE finishing launch ==
+    dcll_readout_splitk per readout (bit for bit per column wherever both use the same slice width), k_argmax's first maximum
+    (ties included) and dcll_local_loss_grad's gradients — the launches it replaces in every per-step call."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(rows + K + N2)
+    N1 = 24
+    pv = cu(rng.uniform(0, 1, size=(rows, K)).astype(np.float32), dev)
+    Wt = cu(rng.uniform(-.0055, .0055, size=(N1 + N2, K)).astype(np.float32), dev)
+    bias = cu(rng.uniform(-.0055, .0055, size=(N1 + N2,)).astype(np.float32), dev)
+    if rows >= 8:                                   # exact ties between readout rows: the first one must win
+        Wt[N2 + 3] = Wt[N2 + 11]
+        bias[N2 + 3] = bias[N2 + 11]
+    target = torch.zeros(rows, N1, device=dev)
+    target[torch.arange(rows), torch.from_numpy(rng.randint(0, N1, rows))] = 1
+    p = torch.empty(rows, N1, device=dev)
+    o = torch.empty(rows, N2, device=dev) if N2 else None
+    fin = dict(clout=True)
+    if learn:
+        fin.update(target=target, kind=ops.LOSS_KINDS['SmoothL1Loss'])
+    ops.step_readouts(pv, Wt, bias, N1, N2, p, o, finish=fin)
+    assert fin['done']
+    # the slice width of the split-K pass depends on (rows, N): up to 512 rows the stacked 48-row pass runs 32 slices, a
+    # 24-row pass 64 — there the separate calls add the same products in another order (logit tolerance), else bit-equal
+    same = not (rows <= 512 and N2 > 0)
+    eq = (lambda a, b: torch.equal(a, b)) if same else (lambda a, b: bool((a - b).abs().max() <= 1e-5))
+    ref_p = ops.readout(pv, Wt[:N1].contiguous(), bias[:N1].contiguous())
+    assert eq(p, ref_p)
+    logits = p
+    if N2:
+        ref_o = ops.readout(pv, Wt[N1:].contiguous(), bias[N1:].contiguous())
+        assert eq(o, ref_o)
+        logits = o
+    assert torch.equal(fin['clout'], ops.argmax(logits))
+    assert torch.equal(fin['clout'].long(), logits.argmax(1))
+    if learn:
+        g_p, g_o, _, cl = ops.local_loss_grad(p, o if N2 else None, target, ops.LOSS_KINDS['SmoothL1Loss'],
+                                              want_loss=False, want_clout=True)
+        assert torch.equal(fin['g_p'], g_p) and torch.equal(fin['clout'], cl)
+        if N2:
+            assert torch.equal(fin['g_o'], g_o)
+    else:
+        assert fin['g_p'] is None
