@@ -20,16 +20,17 @@ template <int DBG>
 static void stamps(int B, float *x, float *W, float *bias, float *tau, float *e0, float *e1, float *arp, float *s, float *pv, float *v)
 {
     run<DBG | 32>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
-    std::vector<unsigned long long> h((size_t)B * 16);
+    std::vector<unsigned long long> h((size_t)B * 24);
     hipMemcpy(h.data(), arp + (size_t)B * 8192, h.size() * 8, hipMemcpyDeviceToHost);
-    double pro = 0, loop = 0, epi = 0; unsigned long long t0 = ~0ull, t1 = 0;
+    double pro = 0, loop = 0, epi = 0, clk = 0; unsigned long long t0 = ~0ull, t1 = 0;
     for (int i = 0; i < B * 4; ++i) {
-        pro += h[4 * i + 1] - h[4 * i]; loop += h[4 * i + 2] - h[4 * i + 1]; epi += h[4 * i + 3] - h[4 * i + 2];
-        if (h[4 * i] < t0) t0 = h[4 * i];
-        if (h[4 * i + 3] > t1) t1 = h[4 * i + 3];
+        pro += h[6 * i + 1] - h[6 * i]; loop += h[6 * i + 2] - h[6 * i + 1]; epi += h[6 * i + 3] - h[6 * i + 2];
+        clk += (double)(h[6 * i + 3] - h[6 * i]) / (double)(h[6 * i + 5] - h[6 * i + 4]) * 0.1;     // GHz
+        if (h[6 * i + 4] < t0) t0 = h[6 * i + 4];
+        if (h[6 * i + 5] > t1) t1 = h[6 * i + 5];
     }
-    printf("   stamps DBG=%d B=%d: prologue %.0f  chunk loop %.0f (MFMA time of a wave: %d, of a SIMD's %d waves: %d)  epilogue %.0f  first entry -> last exit %llu cycles\n",
-           DBG, B, pro / (B * 4), loop / (B * 4), 1568 * 64, B >= 512 ? 2 : 1, (B >= 512 ? 2 : 1) * 1568 * 64, epi / (B * 4), t1 - t0);
+    printf("   stamps DBG=%d B=%d: prologue %.0f  chunk loop %.0f (MFMA time of a wave: %d, of a SIMD's %d waves: %d)  epilogue %.0f  shader clock %.3f GHz  first entry -> last exit %.1f us\n",
+           DBG, B, pro / (B * 4), loop / (B * 4), 1568 * 64, B >= 512 ? 2 : 1, (B >= 512 ? 2 : 1) * 1568 * 64, epi / (B * 4), clk / (B * 4), (t1 - t0) * 0.01);
 }
 int main()
 {

@@ -379,10 +379,21 @@ constexpr int WG32_GLD = 257;
 // SPLIT: workgroups per batch chunk (blockIdx.y), each with 6 / SPLIT of every wave's column tiles — small batches have
 // fewer samples than the GPU has CUs, so a sample's 49 column tiles are spread over several workgroups (which all
 // stage the same g and image; the columns they write are disjoint, the fixed-order reduce is unchanged).
-template <int RF, int CF, bool TILED, int SPLIT = 1>
+// DBG (experiments/ablate_wgrad.hip only; 0 in the product): 1 = per-wave shader-clock totals of the phases (staging incl.
+// barriers / bias sum / MFMA loop / partial-sum stores) written behind the partial sums; 2 = no MFMAs; 4 = no stores
+template <int RF, int CF, bool TILED, int SPLIT = 1, int DBG = 0>
 __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__ gvf, const float *__restrict__ eps1,
                                                         float *__restrict__ part, int B, int H, int Wd)
 {
+    unsigned long long tA = 0, tStage = 0, tBias = 0, tMfma = 0, tEnd = 0, tEntry = 0;
+    if (DBG & 1) tEntry = tA = __builtin_amdgcn_s_memtime();
+    auto lap = [&](unsigned long long &acc) {
+        if (DBG & 1) {
+            const unsigned long long n = __builtin_amdgcn_s_memtime();
+            acc += n - tA;
+            tA = n;
+        }
+    };
     constexpr int IMG = TILED ? 32 * CF : IMG_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[IMG + 32 * WG32_GLD];
     float *img = lds, *gl = lds + IMG;
@@ -462,24 +473,54 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
         }
         __syncthreads();
         if (job + gridDim.x < njob) fetch(job + gridDim.x);
+        lap(tStage);
         {   // bias gradient: co = 4w + lane/16, pixels lane%16 + 16*k
             const float *gr = gl + (4 * w + (lane >> 4)) * WG32_GLD + (lane & 15);
 #pragma unroll
             for (int k = 0; k < 16; ++k) bsum += gr[16 * k];
         }
+        lap(tBias);
         const float *ga = gl + j * WG32_GLD + h;              // A: co = j, pixel p + h
-        for (int seg = 0; seg < 8; ++seg) {                   // 16 pixel pairs = two image rows per segment
-            const bool mine = seg == w && last48;             // wave-uniform: my eighth of tile 48
-#pragma unroll 4
-            for (int pp = 16 * seg; pp < 16 * seg + 16; ++pp) {
-                const int p = 2 * pp;
-                const float a = ga[p];
-                const int poff = (p >> 4) * RF + (p & 15);
+        // my six whole tiles over all 128 pixel pairs: branch-free (a scalar branch between two groups of MFMAs holds the MFMA
+        // issue — the per-pair test for the tile-48 share that used to sit here cost the loop 14 % — and an if / else around
+        // two copies of the loop makes the compiler merge the 112 accumulator registers with v_movs: 128 -> 175 us)
+        // FULLY unrolled: every operand address is a per-lane base + an immediate.  With a runtime pixel-pair index the
+        // compiler rebuilt the seven addresses of every pair with 12-14 vector adds — on the pipe the fp32 MFMAs execute
+        // on, ~4.8 cycles each: 16-23k of a job's 128k cycles (experiments/ablate_wgrad.hip, round 4)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
-                if (mine) acc[NQ] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[NQ] + poff], acc[NQ], 0, 0, 0);
+        for (int pp = 0; pp < 128; ++pp) {
+            const int p = 2 * pp;
+            const float a = ga[p];
+            const int poff = (p >> 4) * RF + (p & 15);
+            if (DBG & 2) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q][0] += a * img[bbase[q] + poff];
+                continue;
             }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, img[bbase[q] + poff], acc[q], 0, 0, 0);
         }
+        // my eighth of tile 48: pixel pairs 16w .. 16w+15 (one more chain of 16; all operands fetched up front)
+        if (last48 && !(DBG & 2)) {
+            float a48[16], b48[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int p = 2 * (16 * w + k);
+                a48[k] = ga[p];
+                b48[k] = img[bbase[NQ] + (p >> 4) * RF + (p & 15)];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[NQ] = __builtin_amdgcn_mfma_f32_32x32x2f32(a48[k], b48[k], acc[NQ], 0, 0, 0);
+        }
+        if (DBG & 1) asm volatile("" ::"v"(acc[0][0]), "v"(acc[NQ - 1][15]));
+        lap(tMfma);
+    }
+    if ((DBG & 4) && acc[0][0] != 12345.678f) {
+        if ((DBG & 1) && lane == 0) {
+            unsigned long long *dst = (unsigned long long *)(part + (long)gridDim.x * 32 * 1569) + ((long)blockIdx.x * 8 + w) * 6;
+            dst[0] = tStage; dst[1] = tBias; dst[2] = tMfma; dst[3] = 0; dst[4] = __builtin_amdgcn_s_memtime() - tEntry; dst[5] = tEntry;
+        }
+        return;
     }
     float *pw = part + (long)blockIdx.x * 32 * 1569;
 #pragma unroll
@@ -504,6 +545,12 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
     // bias partial: reduce the 16 lanes of each co group
     bsum += __shfl_xor(bsum, 1); bsum += __shfl_xor(bsum, 2); bsum += __shfl_xor(bsum, 4); bsum += __shfl_xor(bsum, 8);
     if ((lane & 15) == 0) pw[(long)(4 * w + (lane >> 4)) * 1569 + 1568] = bsum;
+    if ((DBG & 1) && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        lap(tEnd);
+        unsigned long long *dst = (unsigned long long *)(part + (long)gridDim.x * 32 * 1569) + ((long)blockIdx.x * 8 + w) * 6;
+        dst[0] = tStage; dst[1] = tBias; dst[2] = tMfma; dst[3] = tEnd; dst[4] = tA - tEntry; dst[5] = tEntry;
+    }
 }
 
 // Weight gradient of the FIRST layer (c_in = 1 -> 32 channels, 7x7, 16x16 plane) as fp32 MFMA, the one-channel sibling
@@ -2029,15 +2076,17 @@ extern "C" int dcll_readout_act(const float *pv, const float *Wt, const float *b
 // B fragments serves both tiles: 112 ds_read dwords per 98 MFMAs.  Input is the dense fp32 map x (any values, not
 // only {0,1}), outputs are the dense s / pv / v maps of dcll_conv_lif_step: no packing, no separate trace kernel.
 // ------------------------------------------------------------------------------------------------------------
-// floats per weight chunk (A fragments of one channel pair): 49 taps x 64 lanes, the taps STEP_WTS = 65 floats apart: a
-// wave of the copy-in writes one fragment lane of 64 consecutive TAPS (that is how the weights lie in global memory),
-// which at a stride of 64 floats would be 64 writes into one LDS bank — measured 1.4 us per chunk, during which the
-// operand reads of the MFMA stream wait (experiments/ablate_step.hip)
-constexpr int STEP_WTS = 65, STEP_WCH = 49 * STEP_WTS + 3;
-// Weight chunk cp (input-channel pair cp) of a 32 -> 32 7x7 layer as MFMA A fragments in LDS:
-// wch[tap*STEP_WTS + hh*32 + co] = W[co][2cp+hh][tap].  In global memory the 98 floats of (co, channel pair cp) are
+// Weight chunk (A fragments of one input-channel pair) in LDS, LANE-major (round 4): the 49 taps of fragment lane
+// l = hh*32 + co are consecutive, the lanes STEP_WLS = 49 floats apart (an odd stride: the 64 lanes of a fragment read hit
+// 64 different banks; the copy-in writes consecutive taps of one lane — consecutive addresses).  Every tap of a lane is
+// then within ds_read2_b32's 8-bit offset range of ONE per-lane base.  (Round 2-3 layout: tap-major, the taps 65 floats
+// apart — 49 taps span 3185 dwords, so the compiler rebuilt a base register for nearly every ds_read2: 56 v_add_u32 per
+// 98 MFMAs in the chunk loop, on the pipe the fp32 MFMAs execute on.)
+// wch[l * STEP_WLS + tap] = W[co][2cp + hh][tap].  In global memory the 98 floats of (co, channel pair cp) are
 // contiguous: thread t of the 256 moves elements t, t+256, ... of the 32 x 98 block through registers (fetched while the
 // MFMAs of the previous chunk run); the index arithmetic is done once per kernel.
+constexpr int STEP_WLS = 49, STEP_WCH = 64 * STEP_WLS + 4;
+typedef __attribute__((address_space(3))) const float lds_cfloat;
 struct step_wchunk {
     static constexpr int NW = 13;
     float reg[NW];
@@ -2048,7 +2097,7 @@ struct step_wchunk {
         for (int i = 0; i < NW; ++i) {
             const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
             goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
-            loff[i] = (r % 49) * STEP_WTS + (r / 49) * 32 + co;
+            loff[i] = ((r / 49) * 32 + co) * STEP_WLS + (r % 49);
         }
     }
     __device__ __forceinline__ void fetch(const dcll_wsrc &W, int cp)
@@ -2090,8 +2139,11 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     const long b = blockIdx.x;
     // DBG & 32 (experiments/ablate_step.hip): shader-clock stamps of every wave — kernel entry, first MFMA row, end of the
     // chunk loop, end of the epilogue — written behind the arp plane of the launch (timing only)
-    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
-    if (DBG & 32) stamp0 = __builtin_amdgcn_s_memtime();
+    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0, real0 = 0;
+    if (DBG & 32) {
+        stamp0 = __builtin_amdgcn_s_memtime();
+        real0 = __builtin_amdgcn_s_memrealtime();           // constant 100 MHz: the shader clock under THIS load
+    }
 
     for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
@@ -2139,6 +2191,17 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     };
     fetch_w(0);
     fetch_t(0);
+    // the refractory trace of my 2 x 16 outputs is requested NOW and lands under the chunk loop: the epilogue of a launch
+    // (all workgroups reach it together) is an HBM burst — arp in, s / pv / v / arp out, 160 KB per sample at ~5.6 TB/s —
+    // and these 32 KB per sample are the part of it that does not depend on the MFMAs
+    float arp_pre[2][16];
+    if (REFRACTORY && !(DBG & 2)) {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                arp_pre[tl][r] = arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 32 * (2 * w + tl) + j];
+    }
     __syncthreads();        // image zeroed
     finish_t(0);
     store_w(0);
@@ -2153,8 +2216,12 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             if (!(DBG & 8)) fetch_w(cp + 1);
             fetch_t(cp + 1);
         }
-        const float *wa = wch + (cp & 1) * STEP_WCH + lane;
-        const float *ib = img + bbase + cp * 2 * CHF;
+        // per-lane bases as opaque 32-bit LDS addresses: every operand read below is base + immediate (ds_read2's 8-bit
+        // dword offsets reach all 49 taps / all 9 rows).  Left visible, the arrays' static LDS offsets (the chunk buffers
+        // sit 47 KB into the allocation) do not fit the immediates and the compiler rebuilds a base per read.
+        lds_cfloat *wa = (lds_cfloat *)(wch + (cp & 1) * STEP_WCH + lane * STEP_WLS);
+        lds_cfloat *ib = (lds_cfloat *)(img + bbase + cp * 2 * CHF);
+        asm volatile("" : "+v"(wa), "+v"(ib));
         // LDS rows rho = 0..8 below the pair's first image row: row rho is tap row ky = rho of tile A (rho <= 6) and
         // tap row ky = rho - 2 of tile B (rho >= 2); the weight fragments of tap row ky are read once (at rho = ky)
         // and kept for tile B two rows later
@@ -2166,7 +2233,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             for (int kx = 0; kx < 7; ++kx) bq[kx] = ib[rho * ROWF + kx];
             if (rho <= 6) {
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[(rho * 7 + kx) * STEP_WTS];
+                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[rho * 7 + kx];
             }
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
@@ -2200,7 +2267,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             float v = pvm;
             bool s;
             if (REFRACTORY) {
-                float ar = (DBG & 2) ? 0.0f : arp_g[o];
+                float ar = (DBG & 2) ? 0.0f : arp_pre[tl][r];
                 v = refractory(pvm, ar, alpharp, wrp, s);
                 if (!(DBG & 2) || ar == 12345.678f) arp_g[o] = ar;
             } else {
@@ -2213,9 +2280,9 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         }
     if ((DBG & 32) && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
-        unsigned long long *dst = (unsigned long long *)(arp_g + (long)gridDim.x * 8192) + (b * 4 + w) * 4;
-        dst[0] = stamp0; dst[1] = stamp1; dst[2] = stamp2; dst[3] = stamp3;
+        const unsigned long long stamp3 = __builtin_amdgcn_s_memtime(), real3 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *dst = (unsigned long long *)(arp_g + (long)gridDim.x * 8192) + (b * 4 + w) * 6;
+        dst[0] = stamp0; dst[1] = stamp1; dst[2] = stamp2; dst[3] = stamp3; dst[4] = real0; dst[5] = real3;
     }
 }
 
@@ -2292,8 +2359,9 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const 
             fetch_w(cp + 1);
             fetch_t(cp + 1);
         }
-        const float *wa = wch + (cp & 1) * STEP_WCH + lane;
-        const float *ib = img + (cp & 1) * ST_PAIR + bbase;
+        lds_cfloat *wa = (lds_cfloat *)(wch + (cp & 1) * STEP_WCH + lane * STEP_WLS);      // opaque bases: see k_lif_step_c32
+        lds_cfloat *ib = (lds_cfloat *)(img + (cp & 1) * ST_PAIR + bbase);
+        asm volatile("" : "+v"(wa), "+v"(ib));
         float wr[3][7];
 #pragma unroll
         for (int rho = 0; rho < (TH == 16 ? 9 : 7); ++rho) {
@@ -2302,7 +2370,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const 
             for (int kx = 0; kx < 7; ++kx) bq[kx] = ib[rho * ST_RF + kx];
             if (rho <= 6) {
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[(rho * 7 + kx) * STEP_WTS];
+                for (int kx = 0; kx < 7; ++kx) wr[rho % 3][kx] = wa[rho * 7 + kx];
             }
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
