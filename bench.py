@@ -538,11 +538,11 @@ def main():
     flop_per_launch = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T_STEPS * B * 2 * a.steps / max(1, len(c32_ms))
     achieved = flop_per_launch / avg_c32_s / 1e12
     # HBM bytes of the dominant kernel: PMC counters cannot be read from inside this process; the committed summary of
-    # the separate `rocprofv3 --pmc` passes of this same command (profiles/r03_pmc_b4096.json; collect_r03.sh) is used
+    # the separate `rocprofv3 --pmc` passes of this same command (profiles/r04_pmc_b4096.json; collect_r04.sh) is used
     # when the batch matches, else null.
     traffic, traffic_src = None, None
-    for name in (["r%02d_pmc_b%d.json" % (r_, B) for r_ in (3, 2, 1)] if R == 16 else
-                 ["r%02d_pmc_plane%d_b%d.json" % (r_, R, B) for r_ in (3, 2, 1)]):
+    for name in (["r%02d_pmc_b%d.json" % (r_, B) for r_ in (4, 3, 2, 1)] if R == 16 else
+                 ["r%02d_pmc_plane%d_b%d.json" % (r_, R, B) for r_ in (4, 3, 2, 1)]):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)

@@ -1,4 +1,4 @@
-"""gpurun_out/<round>prof_* (profiles/collect_r03.sh) -> the committed summaries profiles/<round>_{bench,kernel_stats,pmc}_*.*
+"""gpurun_out/<round>prof_* (profiles/collect_%s.sh) -> the committed summaries profiles/<round>_{bench,kernel_stats,pmc}_*.*
     python experiments/profile_to_json.py r03 4096 | ref | plane128
 """
 import json, os, shutil, sys
