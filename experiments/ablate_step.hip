@@ -55,6 +55,10 @@ int main()
         float h = run<30>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         printf("%6d %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f\n", B, f, a, c, d, e, g, h, 2.0 * 32 * 1568 * 256 * (double)B / 157.3e12 * 1e6);
     }
+    for (int B : {512, 4096})
+        printf("B=%d: full %.1f  no weight streaming %.1f  fetch only (no LDS copy-in) %.1f  copy-in only (no fetch) %.1f us\n", B,
+               run<0>(B, x, W, bias, tau, e0, e1, arp, s, pv, v), run<8>(B, x, W, bias, tau, e0, e1, arp, s, pv, v),
+               run<64>(B, x, W, bias, tau, e0, e1, arp, s, pv, v), run<128>(B, x, W, bias, tau, e0, e1, arp, s, pv, v));
     for (int B : {256, 512}) {
         stamps<0>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);
         stamps<30>(B, x, W, bias, tau, e0, e1, arp, s, pv, v);

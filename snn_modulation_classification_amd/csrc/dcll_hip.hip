@@ -2213,7 +2213,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     if (DBG & 32) stamp1 = __builtin_amdgcn_s_memtime();
     for (int cp = 0; cp < 16; ++cp) {
         if (cp + 1 < 16) {                                 // land during the MFMAs below
-            if (!(DBG & 8)) fetch_w(cp + 1);
+            if (!(DBG & 8) && !(DBG & 128)) fetch_w(cp + 1);
             fetch_t(cp + 1);
         }
         // per-lane bases as opaque 32-bit LDS addresses: every operand read below is base + immediate (ds_read2's 8-bit
@@ -2247,7 +2247,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             }
         }
         if (cp + 1 < 16) {
-            if (!(DBG & 8)) store_w((cp + 1) & 1);         // the other buffer: nobody reads it in this iteration
+            if (!(DBG & 8) && !(DBG & 64)) store_w((cp + 1) & 1); // the other buffer: nobody reads it in this iteration
             finish_t(cp + 1);                              // image channels nobody reads in this iteration
         }
         if (!(DBG & 16)) __syncthreads();
