@@ -101,6 +101,24 @@ def test_bench_launches_its_own_ranks():
 
 
 @pytest.mark.timeout(900)
+def test_bench_strong_scaling_flag_fixes_the_global_batch():
+    """`bench.py --gpus 2 --global-batch 600` (north_star: "batch 4096 ... at 1/2/4/8 GPUs" read as a FIXED global batch): the
+    ranks run contiguous shards of 300 windows, the line says "scaling": "strong", value = global windows / time, and the
+    upload-inclusive value sits beside the device-resident one."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--global-batch", "600"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == 600 and out["config"]["batch_per_gpu"] == 300
+    assert abs(out["value"] - 600 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert 0 < out["value_incl_upload"] <= out["value"] * 1.2 and out["ms_per_step_incl_upload"] > 0
+
+
+@pytest.mark.timeout(900)
 def test_entry_points_shard_over_ranks(tmp_path):
     """`test_radio_ml.py --gpus 2` and `train.py --gpus 2` started plainly: each launches two ranks (sharing cuda:0 here,
     gloo), shards every batch and reduces — the per-SNR accuracies and confusion matrices equal the single-process

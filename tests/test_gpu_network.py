@@ -919,6 +919,60 @@ def test_graph_captured_learning_steps_equal_eager_steps():
             assert torch.equal(sta["exp_avg_sq"], stb["exp_avg_sq"]) and torch.equal(sta["exp_avg"], stb["exp_avg"])
 
 
+def test_graph_or_eager_is_decided_by_measurement_for_mid_size_batches(monkeypatch):
+    """Between the batches that always replay (<= 128 samples of a 16x16 plane) and those that never do, ConvNetwork times
+    the running job — six eager timesteps against six replays — and keeps the faster form (_graph_tuned; the round-3 driver
+    host launched a B = 512 timestep in 2 ms against 0.73 ms of device work, the builder's hosts are device-bound there).
+    Whatever it decides: the learning run is bit-identical to the one with the measurement switched off, the decision is
+    recorded with both timings, and it is taken once."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    B, R_, T, burnin = 160, 16, 36, 3
+
+    def make():
+        torch.manual_seed(1)
+        np.random.seed(1)
+        net = ConvNetwork(_args(), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                          opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0},
+                          learning_rates=[1e-6], burnin=burnin)
+        net.reset(True)
+        return net
+    rng = np.random.RandomState(5)
+    cells = torch.from_numpy(rng.randint(0, R_ * R_, size=(T, B)).astype(np.int32)).cuda()
+    y = torch.zeros(B, 24)
+    y[np.arange(B), rng.randint(0, 24, size=B)] = 1
+    y = y.cuda()
+    tuned = make()
+    assert tuned.graph_autotune and not tuned._graph_small(torch.empty(B, 1, R_, R_))
+    tuned.learn_sequence(cells, y)
+    monkeypatch.setenv("DCLL_GRAPH_AUTOTUNE", "0")
+    plain = make()
+    assert not plain.graph_autotune
+    plain.learn_sequence(cells, y)
+    dec = tuned.graph_decisions()["learn"]
+    assert len(dec) == 1
+    d = list(dec.values())[0]
+    assert d["eager_ms"] > 0 and d["graph_ms"] > 0 and d["use_graph"] in (True, False)
+    assert d["use_graph"] == (d["graph_ms"] < 0.97 * d["eager_ms"])
+    assert not plain.graph_decisions() and not plain._learn_graphs
+    sa, sb = tuned.state_dict(), plain.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for sl_a, sl_b in zip(tuned.dcll_slices, plain.dcll_slices):
+        assert sl_a.iter == sl_b.iter == T and np.array_equal(np.asarray(sl_a.clout), np.asarray(sl_b.clout))
+    # the inference step likewise
+    x = torch.zeros(T, B, R_ * R_, device='cuda').scatter_(2, cells.long().unsqueeze(-1), 1.0).reshape(T, B, 1, R_, R_)
+    for net in (tuned, plain):
+        net.reset()
+        for t in range(T):
+            net.test(x[t])
+    assert "test" in tuned.graph_decisions() and "test" not in plain.graph_decisions()
+    for sl_a, sl_b in zip(tuned.dcll_slices, plain.dcll_slices):
+        assert np.array_equal(np.asarray(sl_a.clout), np.asarray(sl_b.clout))
+        for ta, tb in zip(sl_a.dclllayer.i2h.state, sl_b.dclllayer.i2h.state):
+            assert torch.equal(ta, tb)
+
+
 def test_graph_captured_inference_steps_equal_eager_steps():
     """net.test(x[t]) replayed from its captured hipGraph (ConvNetwork._test_graphed; batches <= 256) == the eager step:
     clout, iteration count, pv statistics and the neuron state after 47 steps bit for bit, incl. a reset in between; the
