@@ -399,7 +399,6 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
     float *img = lds, *gl = lds + IMG;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < IMG; i += 512) img[i] = 0.0f;
     // 49 column tiles over 8 waves: wave w owns tiles w, w + 8, ..., w + 40 (six) and ONE EIGHTH of tile 48 — the pixel
     // pairs 16w .. 16w+15 of every sample, summed over the waves in wave order at the end.  (Tile 48 whole on wave 0 made
     // its SIMD carry 13 tiles against 12: the slowest SIMD sets the time, +6 %.)
@@ -451,6 +450,7 @@ __global__ __launch_bounds__(512) void k_bwd_wgrad_c32(const float *__restrict__
         }
     };
     if ((long)blockIdx.x < njob) fetch(blockIdx.x);
+    for (int i = tid; i < IMG; i += 512) img[i] = 0.0f;       // (under the first job's requests)
     for (long job = blockIdx.x; job < njob; job += gridDim.x) {
         __syncthreads();
         if (TILED) {
@@ -2145,7 +2145,6 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         real0 = __builtin_amdgcn_s_memrealtime();           // constant 100 MHz: the shader clock under THIS load
     }
 
-    for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
     if (tid < 32) sbias[tid] = bias[tid];
     step_wchunk wc;
     wc.init(tid);
@@ -2202,6 +2201,9 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             for (int r = 0; r < 16; ++r)
                 arp_pre[tl][r] = arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 32 * (2 * w + tl) + j];
     }
+    // (the image is zeroed while those requests are in flight: all workgroups of a launch start together, and the first
+    //  chunk cannot begin before the slowest of them has its first operands)
+    for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
     __syncthreads();        // image zeroed
     finish_t(0);
     store_w(0);
