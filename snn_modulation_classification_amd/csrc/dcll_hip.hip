@@ -2356,6 +2356,18 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
     const int bbase = h * ST_CF + ((j >> 4) + (TH / 4) * w) * ST_RF + (j & 15);
+    // the refractory trace of my outputs, requested now: it lands under the chunk loop instead of being waited for, load
+    // by load, in the epilogue (k_lif_step_c32: epilogue 37k -> 12k cycles)
+    float arp_pre[TH / 8][16];
+    if (REFRACTORY) {
+#pragma unroll
+        for (int tq = 0; tq < TH / 8; ++tq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * ((TH / 8) * w + tq) + j;
+                arp_pre[tq][r] = arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15)];
+            }
+    }
     for (int cp = 0; cp < 16; ++cp) {
         if (cp + 1 < 16) {                                 // land during the MFMAs below
             fetch_w(cp + 1);
@@ -2399,7 +2411,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const 
             float v = pvm;
             bool s;
             if (REFRACTORY) {
-                float ar = arp_g[o];
+                float ar = arp_pre[tq][r];
                 v = refractory(pvm, ar, alpharp, wrp, s);
                 arp_g[o] = ar;
             } else {
@@ -2478,6 +2490,18 @@ __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__r
     const int tile = blockIdx.x % tps, y0 = (tile / tpr) * 16, x0 = (tile % tpr) * 16;
     const long HW = TILED ? (long)H * Wd : 256;
     if (pix < 32) sbias[pix] = pix < c_out ? bias[pix] : 0.0f;
+    // the refractory trace of my 2 x 16 outputs, requested at kernel entry (not load by load in the epilogue)
+    float arp_pre[2][16];
+    if (REFRACTORY) {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h, p = 32 * (2 * w + tl) + j;
+                arp_pre[tl][r] = co < c_out ? arp_g[(b * c_out + co) * HW + (TILED ? (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15) : (long)p)]
+                                            : 0.0f;
+            }
+    }
     // weight fragments: pair p: lane (co = j, tap = 2p + h); the pad tap and channels >= c_out carry 0
     float wf[25];
 #pragma unroll
@@ -2527,7 +2551,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c1(int c_out, const float *__r
             float v = acc[r];
             bool s;
             if (REFRACTORY) {
-                float ar = arp_g[o];
+                float ar = arp_pre[tl][r];
                 v = refractory(acc[r], ar, alpharp, wrp, s);
                 arp_g[o] = ar;
             } else {
@@ -2806,16 +2830,37 @@ __global__ __launch_bounds__(256) void k_bwd_outgrad_mfma(const float *__restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     int b = b0;
-    for (; b + 16 <= b1; b += 16) {                            // eight sample pairs: all loads issued before the first MFMA
-        float av[8], bvv[8];
+    // sixteen sample pairs per group, register double buffer: the loads of group g + 1 are in flight under the MFMAs of
+    // group g (round 4: one group at a time meant eight exposed HBM round trips per wave at B = 512 — 21 us for a kernel
+    // whose traffic is 17 MB)
+    constexpr int GP = 16;
+    float av[2][GP], bvv[2][GP];
+    auto fetch = [&](int buf, int bs) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int bb = b + 2 * q + h;
-            av[q] = j < N ? g_o[(long)bb * N + j] : 0.0f;
-            bvv[q] = pvp[(long)bb * K + k0 + j];
+        for (int q = 0; q < GP; ++q) {
+            const int bb = bs + 2 * q + h;
+            av[buf][q] = j < N ? g_o[(long)bb * N + j] : 0.0f;
+            bvv[buf][q] = pvp[(long)bb * K + k0 + j];
         }
+    };
+    auto mfmas = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bvv[q], acc, 0, 0, 0);
+        for (int q = 0; q < GP; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][q], bvv[buf][q], acc, 0, 0, 0);
+    };
+    if (b + 2 * GP <= b1) fetch(0, b);
+    for (; b + 4 * GP <= b1; b += 4 * GP) {                    // two groups per trip: static buffer indices
+        fetch(1, b + 2 * GP);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 6 * GP <= b1) fetch(0, b + 4 * GP);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (b + 2 * GP <= b1) {                                    // a last single group (its loads were issued above)
+        mfmas(0);
+        b += 2 * GP;
     }
     for (; b < b1; b += 2) {
         const int bb = b + h;
