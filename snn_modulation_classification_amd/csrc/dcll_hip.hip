@@ -2252,7 +2252,9 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             if (!(DBG & 8) && !(DBG & 64)) store_w((cp + 1) & 1); // the other buffer: nobody reads it in this iteration
             finish_t(cp + 1);                              // image channels nobody reads in this iteration
         }
-        if (!(DBG & 16)) __syncthreads();
+        // LDS-only barrier: it orders the image / chunk writes above against the next chunk's reads; the state stores of
+        // finish_t need not have landed (__syncthreads() also waits for their acknowledgement: s_waitcnt vmcnt(0))
+        if (!(DBG & 16)) lds_barrier();
     }
     if (DBG & 32) {
         asm volatile("" ::"v"(accA[0]), "v"(accB[0]));

@@ -219,6 +219,42 @@ def test_layer_opts_validation(dev):
     torch.cuda.synchronize()
 
 
+def test_step_readouts_argument_checks(dev):
+    """dcll_step_readouts (ABI 4) refuses what it does not serve with a status and a message — nothing is launched, nothing
+    throws across the ABI: shapes outside the split-K form (callers then fall back to dcll_readout + dcll_argmax_vote),
+    null / inconsistent pointers, scratch that is too small, an unknown loss kind."""
+    from snn_modulation_classification_amd import _lib
+    lib = _lib.get()
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+    rows, K, N = 64, 8192, 24
+    pv, Wt, bias, p, o = z(rows, K), z(2 * N, K), z(2 * N), z(rows, N), z(rows, N)
+    need = lib.dcll_step_readouts_scratch(rows, K, N, N)
+    assert need == lib.dcll_readout_splitk_scratch(rows, K, 2 * N) > 0
+    assert lib.dcll_step_readouts_scratch(rows, 8192 + 32, N, 0) == 0          # K % 256 != 0
+    assert lib.dcll_step_readouts_scratch(rows, 131072, N, 0) == 0             # long rows: the 4096-column split form
+    assert lib.dcll_step_readouts_scratch(4096, K, N, 0) == 0                  # many rows: the plain GEMM
+    assert lib.dcll_step_readouts_scratch(rows, K, 40, 40) == 0                # more than 64 stacked rows
+    sc = z(need)
+    cl, tg, gp, go = z(rows, dt=torch.int32), z(rows, N), z(rows, N), z(rows, N)
+    P = _lib.ptr
+
+    def call(pv_=pv, K_=K, N2=N, o_=o, sc_=sc, need_=need, tg_=None, gp_=None, go_=None, kind=0):
+        return lib.dcll_step_readouts(P(pv_), P(Wt), P(bias), P(sc_), need_, rows, K_, N, N2, P(p), P(o_), P(cl), P(tg_), P(gp_),
+                                      P(go_), kind, None)
+    assert call() == _lib.DCLL_OK
+    assert call(tg_=tg, gp_=gp, go_=go, kind=1) == _lib.DCLL_OK
+    assert call(o_=None) == _lib.DCLL_ERR_INVALID                              # output layer without o
+    assert call(N2=7) == _lib.DCLL_ERR_INVALID                                 # output_ rows != i2o rows
+    assert call(tg_=tg) == _lib.DCLL_ERR_INVALID                               # loss gradients asked for, no place to put them
+    assert call(tg_=tg, gp_=gp, go_=go, kind=5) == _lib.DCLL_ERR_UNSUPPORTED and b"SmoothL1" in lib.dcll_last_error()
+    assert call(need_=need - 1) == _lib.DCLL_ERR_INVALID and b"scratch" in lib.dcll_last_error()
+    assert call(K_=8192 + 32) == _lib.DCLL_ERR_UNSUPPORTED
+    assert call(pv_=pv.reshape(-1)[1:1 + rows * (K - 1)]) == _lib.DCLL_ERR_UNSUPPORTED      # pv not 16-byte aligned
+    assert lib.dcll_step_readouts(P(pv), P(Wt), P(bias), P(sc), need, 0, K, N, N, P(p), P(o), None, None, None, None, 0,
+                                  None) == _lib.DCLL_OK                       # empty batch: nothing to do
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("case", [c for c in SEQ_CASES if c[0] in ("c32d", "c32", "c32t", "c1", "c1_narrow", "c1t",
                                                                       "w3_wide", "w3_mid", "w3_narrow", "w3_first")],
                          ids=lambda c: c[0])
