@@ -362,6 +362,15 @@ int dcll_argmax_vote(const float *logits, int32_t *clout, int32_t *vote, int32_t
                      int32_t t_begin, void *stream);
 
 /*
+ * The per-class tallies of an evaluated batch (accuracy_by_vote / confusion_matrix, dcll/pytorch_libdcll.py:44-61, :740-749, in
+ * the summable form the ranks all-reduce): out (n_layers, n_classes*n_classes + 2) int64 = per layer the confusion matrix
+ * [pred][label] flattened, the number of votes equal to their label, the number of votes.  votes: HOST array of n_layers
+ * device pointers to (B) int32 votes (dcll_argmax_vote); labels (B) int64.  Every element of `out` is written.
+ */
+int dcll_vote_tallies(const int32_t *const *votes, int32_t n_layers, const int64_t *labels, int64_t *out, int32_t B,
+                      int32_t n_classes, void *stream);
+
+/*
  * iq2spiketrain on device (data/utils.py:60-82) as a threshold search: cell = #{j : x >= thr[j]} for the
  * monotone map x -> int(clamp(gamma(x),0,1)*(R-1)); thr_i (w-1) and thr_q (h-1) are produced on the host from
  * the host encoder so that the result is bit-identical to it.

@@ -94,6 +94,7 @@ SIGNATURES = {
     "dcll_readout_mode": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "dcll_readout_splitk_scratch": (_I64, [_I64, _I32, _I32]),
     "dcll_readout_splitk": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    "dcll_vote_tallies": (_I32, [_P, _I32, _P, _P, _I32, _I32, _P]),
     "dcll_step_readouts_scratch": (_I64, [_I64, _I32, _I32, _I32]),
     "dcll_step_readouts": (_I32, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "dcll_argmax_vote": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),

@@ -295,3 +295,54 @@ extern "C" int dcll_cells_to_planes(const int32_t *cells, float *planes, int64_t
     HIP_CHECK_LAUNCH("k_cells_to_planes");
     return DCLL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// k_vote_tally — the per-class tallies of an evaluated batch on the device (what the reference computes on the host from
+// clout: accuracy_by_vote / confusion_matrix, dcll/pytorch_libdcll.py:44-61, :740-749; here the summable form the ranks
+// all-reduce, parallel.py): per layer the confusion matrix [pred][label] (n x n), the number of correct votes and the
+// number of votes.  One workgroup per layer: LDS histogram (integer atomics: the result does not depend on their order),
+// every output element written — no zero fill, no partial sums.  (Round 3 built this from nine torch kernels per layer.)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TALLY_MAXL = 16;
+struct tally_args { const int32_t *votes[TALLY_MAXL]; };
+
+__global__ __launch_bounds__(1024) void k_vote_tally(tally_args a, const int64_t *__restrict__ labels, int64_t *__restrict__ out,
+                                                      int B, int n)
+{
+    extern __shared__ unsigned hist[];                          // n * n bins + [correct]
+    const int nn = n * n;
+    for (int i = threadIdx.x; i <= nn; i += 1024) hist[i] = 0u;
+    __syncthreads();
+    const int32_t *v = a.votes[blockIdx.x];
+    unsigned ok = 0;
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const int pred = v[b];
+        const long lab = labels[b];
+        if ((unsigned)pred < (unsigned)n && (unsigned long)lab < (unsigned long)n) atomicAdd(&hist[pred * n + (int)lab], 1u);
+        ok += (long)pred == lab;
+    }
+    if (ok) atomicAdd(&hist[nn], ok);
+    __syncthreads();
+    int64_t *row = out + (long)blockIdx.x * (nn + 2);
+    for (int i = threadIdx.x; i <= nn; i += 1024) row[i] = (int64_t)hist[i];
+    if (threadIdx.x == 0) row[nn + 1] = B;
+}
+
+extern "C" int dcll_vote_tallies(const int32_t *const *votes, int32_t n_layers, const int64_t *labels, int64_t *out, int32_t B,
+                                 int32_t n_classes, void *stream)
+{
+    if (n_layers == 0) return DCLL_OK;
+    if (!votes || !labels || !out || n_layers < 0 || B < 0 || n_classes < 1)
+        return fail(DCLL_ERR_INVALID, "dcll_vote_tallies: bad argument");
+    if (n_layers > TALLY_MAXL || n_classes > 96)
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_vote_tallies: at most 16 layers and 96 classes");
+    tally_args a;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!votes[l]) return fail(DCLL_ERR_INVALID, "dcll_vote_tallies: null vote tensor");
+        a.votes[l] = votes[l];
+    }
+    const size_t lds = (size_t)(n_classes * n_classes + 1) * sizeof(unsigned);
+    hipLaunchKernelGGL(k_vote_tally, dim3(n_layers), dim3(1024), lds, (hipStream_t)stream, a, labels, out, B, n_classes);
+    HIP_CHECK_LAUNCH("k_vote_tally");
+    return DCLL_OK;
+}

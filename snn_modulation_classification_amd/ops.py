@@ -537,6 +537,20 @@ def readout_act(pv2d, Wt, bias, out=None, presigmoid=False, scratch=None):
     return out
 
 
+def vote_tallies(votes, labels, n_classes):
+    """dcll_vote_tallies: per layer the confusion matrix [pred][label], the correct count and the vote count of a batch as one
+    (L, n*n + 2) int64 tensor (the form parallel.py all-reduces) — one launch.  votes: list of (B) int32 device tensors;
+    labels (B) int64 on the same device."""
+    L, B = len(votes), labels.shape[0]
+    for v in votes:
+        _expect(v, "vote", torch.int32, (B,))
+    _expect(labels, "labels", torch.int64, (B,))
+    out = torch.empty((L, n_classes * n_classes + 2), device=labels.device, dtype=torch.int64)
+    arr = (ctypes.c_void_p * L)(*[v.data_ptr() for v in votes])
+    check(_lib.get().dcll_vote_tallies(arr, L, ptr(labels), ptr(out), B, n_classes, stream_ptr()), "dcll_vote_tallies")
+    return out
+
+
 def argmax_vote(logits, t_begin=0, want_vote=True):
     """logits (T,B,N) -> clout (T,B) int32, vote (B) int32."""
     T, B, N = logits.shape

@@ -144,6 +144,10 @@ def tallies(votes, labels, n_classes):
     """votes: list (per layer) of (B) int tensors; labels (B) int.  -> int64 tensor (L, n*n + 2):
     flattened confusion matrix [pred, label] followed by (correct, total)."""
     labels = labels.to(torch.int64)
+    if labels.is_cuda and len(votes) <= 16 and n_classes <= 96 and all(v.is_cuda and v.dtype == torch.int32 and
+                                                                      v.is_contiguous() for v in votes):
+        from . import ops                           # one HIP launch instead of nine torch kernels per layer
+        return ops.vote_tallies(list(votes), labels.contiguous(), n_classes)
     rows = []
     for v in votes:
         v = v.to(torch.int64)

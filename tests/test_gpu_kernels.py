@@ -1058,3 +1058,20 @@ def test_step_readouts_fused_tail_equals_the_separate_calls(dev, rows, K, N2, le
             assert torch.equal(fin['g_o'], g_o)
     else:
         assert fin['g_p'] is None
+
+
+@pytest.mark.parametrize("B,L,n", [(4096, 3, 24), (37, 1, 24), (1, 2, 10), (5000, 7, 24)])
+def test_vote_tallies_equal_the_torch_construction(dev, B, L, n):
+    """dcll_vote_tallies (one launch; parallel.tallies on device tensors) == the torch construction it replaced: per layer
+    the confusion matrix [pred][label] via bincount, the correct count, the vote count — the form the ranks all-reduce."""
+    from snn_modulation_classification_amd import ops, parallel
+    g = torch.Generator().manual_seed(B + L)
+    votes = [torch.randint(0, n, (B,), generator=g, dtype=torch.int32).to(dev) for _ in range(L)]
+    labels = torch.randint(0, n, (B,), generator=g).to(dev)
+    got = parallel.tallies(votes, labels, n)
+    assert got.dtype == torch.int64 and tuple(got.shape) == (L, n * n + 2)
+    want = parallel.tallies([v.cpu() for v in votes], labels.cpu(), n)           # CPU tensors: the torch construction
+    assert torch.equal(got.cpu(), want)
+    cm, acc = parallel.split_tallies(got, n)
+    assert int(cm.sum()) == L * B and all(int(got[l, -1]) == B for l in range(L))
+    assert torch.equal(ops.vote_tallies(votes, labels, n), got)
