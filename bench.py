@@ -590,6 +590,9 @@ def main():
                          # executed_frac): what the matrix pipe executes is less than the algorithmic count, so `frac`
                          # (algorithmic) may exceed what the pipe alone allows — the pipe's own busy fraction
                          # is frac * executed / algorithmic
+                         "frac_definition": "algorithmic FLOPs of SURVEY 8(d) per launch / HIP-event launch time / peak (the task's "
+                                            "definition of `achieved`); the kernel ISSUES executed_over_algorithmic_flop of them — "
+                                            "matrix_pipe_frac = frac * that ratio is how busy the matrix pipe really is",
                          "executed_over_algorithmic_flop": executed_frac(R),
                          "matrix_pipe_frac": achieved / PEAK_FP32_MFMA_TFLOPS * executed_frac(R),
                          "hbm": {"achieved_GBps": (traffic / avg_c32_s / 1e9) if traffic else None,
