@@ -75,8 +75,12 @@ def init_process_group(backend=None):
         kw = {}
         if backend == "nccl":
             # RCCL refuses two ranks on one device (and hangs the others in the rendezvous): say so before joining
+            # (a launcher that hands every rank its own GPU through *_VISIBLE_DEVICES is trusted: the ranks then see one
+            #  device each and do not share it)
             n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-            if torch.cuda.device_count() < n_local:
+            masked = any(os.environ.get(v) is not None for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
+                                                                 "CUDA_VISIBLE_DEVICES"))
+            if torch.cuda.device_count() < n_local and not masked:
                 sys.exit("rank %d: %d local rank(s) over RCCL but this process sees %d GPU(s) — use --gpus <= %d, or "
                          "DCLL_DIST_BACKEND=gloo for a rehearsal in which ranks share devices"
                          % (rank, n_local, torch.cuda.device_count(), max(torch.cuda.device_count(), 1)))
