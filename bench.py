@@ -12,7 +12,8 @@ That is the span of the reference's test_radio_ml.py:142-146 plus its input enco
 `--plane 128` runs the same path on the reference's argparse-default 128x128 I/Q plane (test_radio_ml.py:52; tiled
 kernels k_lif_seq_c1t / k_lif_seq_c32t, default batch 64) — a secondary configuration, not the headline number.
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` for the dominant kernel
-(k_lif_seq_c32d, fp32 MFMA bound) and `cpu_baseline` (the torch-CPU port of the reference timed on this host).
+(k_lif_seq_c32d, fp32 MFMA bound; `traffic` = its HBM bytes per launch measured in the run by two `rocprofv3 --pmc` child
+passes) and `cpu_baseline` (the torch-CPU port of the reference timed on this host).
 """
 import argparse
 import json
@@ -333,6 +334,54 @@ def trained_top1(dev, n_batches=4, batch=512, train_steps=25):
     return rep
 
 
+def live_hbm_traffic(extra_args, kernel_prefix, timeout=300):
+    """HBM bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two child passes of this very command (1 step) under
+    `rocprofv3 --pmc` — FETCH_SIZE and WRITE_SIZE in separate passes, no trace domain beside them, the program itself behind
+    `--` (MI355X_MICROARCH.md, HBM / rocprofv3 section) — and the guide's gfx950 correction: bytes = (2 * FETCH_SIZE +
+    WRITE_SIZE) KiB (wide coalesced reads are tallied at half).  The children are ordinary child processes (no exec from a
+    process that has touched the GPU).  -> (bytes per launch or None, how it was obtained)"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="dcll_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__)] + list(extra_args) + [
+                   "--steps", "1", "--warmup", "0", "--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--batch-sweep", "0",
+                   "--trained", "0", "--live-traffic", "0"]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                                                      "MASTER_ADDR", "MASTER_PORT", "DCLL_FORCE_DIST")}
+            env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (ctr, r.returncode, r.stderr.decode("utf-8", "replace")[-200:])
+            tot, disp = 0.0, set()
+            for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(fn)):
+                    if row["Counter_Name"] == ctr and row["Kernel_Name"].replace("void ", "").startswith(kernel_prefix):
+                        tot += float(row["Counter_Value"])
+                        disp.add(row["Dispatch_Id"])
+            if not disp:
+                return None, "no %s dispatch in the %s pass" % (kernel_prefix, ctr)
+            vals[ctr] = (tot / len(disp), len(disp))
+    except (OSError, subprocess.TimeoutExpired, KeyError, ValueError) as e:
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    byt = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return byt, ("measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE as two child passes of this command with --steps 1 "
+                 "(%d / %d %s launches averaged), HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB" %
+                 (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1], kernel_prefix))
+
+
 def log(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -420,6 +469,9 @@ def main():
     ap.add_argument("--batch-sweep", type=int, default=1,
                     help="1 (default, N=1 headline run only): also run BASELINE configs 2 and 3 (batch 512 and 8192, 3 steps "
                          "each) and report them as `batch_sweep`")
+    ap.add_argument("--live-traffic", type=int, default=1,
+                    help="1 (default, N=1 only): measure roofline.traffic in this run — two child passes of this command under "
+                         "rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; ~30 s); 0 or on failure: the committed builder-side summary")
     ap.add_argument("--trained", type=int, default=1,
                     help="1 (default, N=1 headline run only): also train the network on the synthetic modulation set (train.py, "
                          "25 batches of 512) and compare top-1 of the fused path with the CPU reference path on 2048 held-out "
@@ -556,6 +608,16 @@ def main():
             break
         except (OSError, ValueError, KeyError, IndexError):
             continue
+    if rank == 0 and world == 1 and a.live_traffic:
+        t_pm = time.perf_counter()
+        live, how = live_hbm_traffic(["--batch", str(B), "--plane", str(R)], hot_kernel)
+        log("live HBM traffic of %s: %s (%s; %.0f s)" % (hot_kernel, live, how[:60], time.perf_counter() - t_pm))
+        if live is not None:
+            if traffic is not None:
+                how += "; builder-side summary %s: %.4g" % (traffic_src.split(" ")[0], traffic)
+            traffic, traffic_src = live, how
+        elif traffic_src is not None:
+            traffic_src += " [live measurement unavailable: %s]" % how
     kernel_ms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in prof.items()}
     if len(c32_ms) >= 2:        # the two 32->32 layers of a step (the output layer carries a second readout)
         kernel_ms["lif_c32_layer1"] = float(np.mean(c32_ms[0::2]))
@@ -645,6 +707,13 @@ def main():
             except Exception as e:                  # noqa: BLE001
                 out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
+            roof5 = out["config5"].get("roofline") if isinstance(out["config5"], dict) else None
+            if roof5 and a.live_traffic:            # its HBM traffic measured in this run as well (children: 137 GB of pv each)
+                live, how = live_hbm_traffic(["--network", "ref", "--batch", "4096"], "k_lif_seq_w3<64")
+                log("live HBM traffic of the six k_lif_seq_w3<64> launches: %s (%s)" % (live, how[:50]))
+                if live is not None:
+                    roof5["traffic"] = live * roof5["launches_per_step"]
+                    roof5["traffic_source"] = how + "; x %g launches per step" % roof5["launches_per_step"]
         if world == 1 and R == 16 and a.trained and a.cpu_windows > 0 and B == 4096:
             try:
                 out["trained_top1"] = trained_top1(dev)

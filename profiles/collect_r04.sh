@@ -11,9 +11,9 @@ MODE=${1:-4096}
 if [ "$MODE" = "ref" ]; then
     OUT=$PWD/gpurun_out/r04prof_ref; ARGS="--network ref --batch 4096"; TSTEPS=2
 elif [ "$MODE" = "plane128" ]; then
-    OUT=$PWD/gpurun_out/r04prof_plane128; ARGS="--plane 128 --batch 64 --cpu-windows 0 --per-step 0 --config5 0 --batch-sweep 0 --trained 0"; TSTEPS=2
+    OUT=$PWD/gpurun_out/r04prof_plane128; ARGS="--plane 128 --batch 64 --cpu-windows 0 --per-step 0 --config5 0 --batch-sweep 0 --trained 0 --live-traffic 0"; TSTEPS=2
 else
-    OUT=$PWD/gpurun_out/r04prof_b$MODE; ARGS="--batch $MODE --cpu-windows 0 --per-step 0 --config5 0 --batch-sweep 0 --trained 0"; TSTEPS=4
+    OUT=$PWD/gpurun_out/r04prof_b$MODE; ARGS="--batch $MODE --cpu-windows 0 --per-step 0 --config5 0 --batch-sweep 0 --trained 0 --live-traffic 0"; TSTEPS=4
 fi
 mkdir -p "$OUT"
 python3 bench.py $ARGS --steps 5 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"

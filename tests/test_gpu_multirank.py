@@ -189,7 +189,7 @@ def test_rccl_code_path_on_a_one_rank_group_equals_the_plain_run(tmp_path):
     lines = {}
     for name, env in (("plain", base), ("rccl", dict(rccl, MASTER_PORT=str(_free_port())))):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                            "--batch", "256", "--cpu-windows", "0", "--per-step", "0", "--config5", "0"], env=env,
+                            "--batch", "256", "--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--live-traffic", "0"], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         out = [l for l in r.stdout.splitlines() if l.strip()]

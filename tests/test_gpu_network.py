@@ -1284,3 +1284,25 @@ def test_accuracy_after_sequence_run_uses_device_vote_and_equals_host_vote():
     assert net.accuracy(tg2) == [L.accuracy_by_vote(s_.clout, tg2) for s_ in net.dcll_slices]
     net.reset()
     assert all(s_._seq_vote is None for s_ in net.dcll_slices)
+
+
+@pytest.mark.timeout(900)
+def test_bench_measures_hbm_traffic_in_the_run():
+    """bench.py's roofline.traffic is measured in the run itself (two child passes of the same command under rocprofv3 --pmc:
+    FETCH_SIZE, WRITE_SIZE, the guide's gfx950 correction) — not read from a committed file: at batch 256 the dominant kernel
+    must show its design traffic (pv written once: T * B * 32 * 256 * 4 bytes, + packed spikes both ways + state) within 10 %."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "256",
+                        "--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--batch-sweep", "0", "--trained", "0"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    roof = json.loads(lines[0])["roofline"]
+    assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
+    T, B = 128, 256
+    design = T * B * (32 * 256 * 4 + 2 * 1024) + 3 * B * 32 * 256 * 4 * 2          # pv + spikes in / out + state in / out
+    assert 0.9 * design <= roof["traffic"] <= 1.1 * design, (roof["traffic"], design)
+    assert abs(roof["hbm"]["achieved_GBps"] - roof["traffic"] / (roof["avg_launch_ms"] * 1e6)) < 1e-6 * roof["hbm"]["achieved_GBps"]
