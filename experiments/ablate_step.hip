@@ -1,6 +1,7 @@
 // Where does k_lif_step_c32 spend its time?  (diagnostic, not product)   ./ablate_step
 #include "../snn_modulation_classification_amd/csrc/dcll_hip.hip"
 #include <vector>
+#include <algorithm>
 template <int DBG>
 static float run(int B, float *x, float *W, float *bias, float *tau, float *e0, float *e1, float *arp, float *s, float *pv, float *v)
 {
@@ -28,6 +29,16 @@ static void stamps(int B, float *x, float *W, float *bias, float *tau, float *e0
         clk += (double)(h[6 * i + 3] - h[6 * i]) / (double)(h[6 * i + 5] - h[6 * i + 4]) * 0.1;     // GHz
         if (h[6 * i + 4] < t0) t0 = h[6 * i + 4];
         if (h[6 * i + 5] > t1) t1 = h[6 * i + 5];
+    }
+    {   // spread over the launch: when do waves start / end, how long do they take (100 MHz constant clock)
+        std::vector<double> st, du, en;
+        for (int i = 0; i < B * 4; ++i) { st.push_back((h[6 * i + 4] - t0) * 0.01); du.push_back((h[6 * i + 5] - h[6 * i + 4]) * 0.01); en.push_back((h[6 * i + 5] - t0) * 0.01); }
+        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        printf("   wave start (us after the first): p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f | duration: p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f | end: p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f\n",
+               pct(st, 0), pct(st, .1), pct(st, .5), pct(st, .9), pct(st, 1), pct(du, 0), pct(du, .1), pct(du, .5), pct(du, .9), pct(du, 1), pct(en, 0), pct(en, .1), pct(en, .5), pct(en, .9), pct(en, 1));
+        double s_lo = 0, s_hi = 0, d_lo = 0, d_hi = 0;
+        for (int i = 0; i < B * 4; ++i) { if (i < B * 2) { s_lo += st[i]; d_lo += du[i]; } else { s_hi += st[i]; d_hi += du[i]; } }
+        printf("   workgroups 0..B/2-1: mean start %.1f duration %.1f | B/2..B-1: mean start %.1f duration %.1f\n", s_lo / (B * 2), d_lo / (B * 2), s_hi / (B * 2), d_hi / (B * 2));
     }
     printf("   stamps DBG=%d B=%d: prologue %.0f  chunk loop %.0f (MFMA time of a wave: %d, of a SIMD's %d waves: %d)  epilogue %.0f  shader clock %.3f GHz  first entry -> last exit %.1f us\n",
            DBG, B, pro / (B * 4), loop / (B * 4), 1568 * 64, B >= 512 ? 2 : 1, (B >= 512 ? 2 : 1) * 1568 * 64, epi / (B * 4), clk / (B * 4), (t1 - t0) * 0.01);

@@ -2087,42 +2087,66 @@ extern "C" int dcll_readout_act(const float *pv, const float *Wt, const float *b
 // MFMAs of the previous chunk run); the index arithmetic is done once per kernel.
 constexpr int STEP_WLS = 49, STEP_WCH = 64 * STEP_WLS + 4;
 typedef __attribute__((address_space(3))) const float lds_cfloat;
-struct step_wchunk {
+// Every global access of the per-step kernels is a BUFFER access (round 4): 128-bit descriptor of a wave-uniform base in
+// SGPRs + a loop-invariant 32-bit lane offset + a scalar / immediate offset that walks with the chunk — no 64-bit vector
+// address is formed inside the chunk loop (flat accesses: v_add_co / v_addc per load and a v_cndmask + exec-mask branch per
+// conditional one, 43 vector instructions and ~10 scalar branches per chunk on the pipe the fp32 MFMAs execute on).  The one
+// ragged element set (tid < 64 of i = 12: 3136 = 12 * 256 + 64) loads element 0 and parks it in the chunk's pad slot.
+__device__ __forceinline__ float buf_ldf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_stf(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+constexpr unsigned BUF_OOB = 0x80000000u;      // beyond tile_rsrc's 2^31 - 1 records: the load returns 0, no access is made
+template <bool Q8>             // int8 weights (dcll_layer_opts): a template parameter — as a runtime test the compiler
+struct step_wchunk {            // speculates the 26 conversion instructions of the int8 branch into the fp32 path's MFMA block
     static constexpr int NW = 13;
-    float reg[NW];
-    int goff[NW], loff[NW];
-    __device__ __forceinline__ void init(int tid)
+    int raw[NW];                // fetched weights: fp32 bit patterns, or sign-extended int8 values
+    float qs[NW];               // int8: the scale of my elements' output channels
+    unsigned goff[NW];          // offset of my element i inside a channel pair's slice: bytes (fp32) or elements (int8)
+    int loff[NW];
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ void init(int tid, const dcll_wsrc &W)
     {
+        constexpr bool q8 = Q8;
+        rs = q8 ? tile_rsrc(W.q) : tile_rsrc(W.f);
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int idx = tid + 256 * i, co = idx / 98, r = idx % 98;
-            goff[i] = idx < 32 * 98 ? co * 1568 + r : -1;
-            loff[i] = ((r / 49) * 32 + co) * STEP_WLS + (r % 49);
+            const bool valid = i < NW - 1 || tid < 32 * 98 - 256 * (NW - 1);
+            const int idx = valid ? tid + 256 * i : 0, co = idx / 98, r = idx % 98;
+            goff[i] = (unsigned)(co * 1568 + r) * (q8 ? 1u : 4u);
+            loff[i] = valid ? ((r / 49) * 32 + co) * STEP_WLS + (r % 49) : 64 * STEP_WLS;
+            qs[i] = q8 ? W.scale[co] : 0.0f;
         }
     }
-    __device__ __forceinline__ void fetch(const dcll_wsrc &W, int cp)
+    __device__ __forceinline__ void fetch(int cp)          // requests only: nothing here waits for the data
     {
-        if (W.q) {                              // int8 weights (dcll_layer_opts): one rounded multiply per weight, here
-            const int8_t *wc = W.q + cp * 98;
+        if (Q8) {
 #pragma unroll
-            for (int i = 0; i < NW; ++i) reg[i] = goff[i] >= 0 ? (float)wc[goff[i]] * W.scale[goff[i] / 1568] : 0.0f;
+            for (int i = 0; i < NW; ++i) raw[i] = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, goff[i], (unsigned)cp * 98u, 0);
             return;
         }
-        const float *wc = W.f + cp * 98;        // wave-uniform base of the chunk
 #pragma unroll
-        for (int i = 0; i < NW; ++i) reg[i] = goff[i] >= 0 ? wc[goff[i]] : 0.0f;
+        for (int i = 0; i < NW; ++i) raw[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs, goff[i], (unsigned)cp * 392u, 0);
     }
     __device__ __forceinline__ void store(float *wch, int buf) const
     {
+        if (Q8) {                               // int8 weights (dcll_layer_opts): one rounded multiply per weight, here
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-            if (goff[i] >= 0) wch[buf * STEP_WCH + loff[i]] = reg[i];
+            for (int i = 0; i < NW; ++i) wch[buf * STEP_WCH + loff[i]] = (float)raw[i] * qs[i];
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wch[buf * STEP_WCH + loff[i]] = __int_as_float(raw[i]);
     }
 };
 
 // DBG (experiments/ablate_step.hip only; 0 in the product): 1 no MFMAs, 2 no epilogue stores, 4 no state traffic,
 // 8 no weight streaming, 16 no barrier per chunk (8, 16: wrong results, timing only)
-template <bool REFRACTORY, int DBG = 0>
+template <bool REFRACTORY, int DBG = 0, bool Q8 = false>
 __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ x, const dcll_wsrc W,
                                                        const float *__restrict__ bias, const float *__restrict__ alpha,
                                                        const float *__restrict__ tau_m, const float *__restrict__ alphas,
@@ -2146,64 +2170,73 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     }
 
     if (tid < 32) sbias[tid] = bias[tid];
-    step_wchunk wc;
-    wc.init(tid);
-    auto fetch_w = [&](int cp) { wc.fetch(W, cp); };
+    step_wchunk<Q8> wc;
+    wc.init(tid, W);
+    auto fetch_w = [&](int cp) { wc.fetch(cp); };
     auto store_w = [&](int buf) { wc.store(wch, buf); };
     // traces of this step (dcll/pytorch_libdcll.py:493-494), state updated in HBM, eps1 -> image — one channel PAIR at a
     // time (thread t owns pixel t of both channels): pair cp + 1 is fetched while the MFMAs of pair cp run and finished
     // (trace arithmetic, state stores, image write) behind them, so that the 160 KB of state traffic per sample is spread
     // over the MFMA phase instead of sitting in front of it (all workgroups of a launch start together: a separate
-    // prologue is an HBM-bound phase during which no matrix core works)
+    // prologue is an HBM-bound phase during which no matrix core works).  Buffer accesses: descriptor of the sample's 32
+    // planes + lane offset 4 tid (+ 1 KB for the pair's second channel, an immediate) + scalar offset 2 KB x cp.
+    const auto xrs = tile_rsrc(x + b * 8192), e0rs = tile_rsrc(eps0_g + b * 8192), e1rs = tile_rsrc(eps1_g + b * 8192);
+    const auto ars = tile_rsrc(alpha), tmrs = tile_rsrc(tau_m), asrs = tile_rsrc(alphas), tsrs = tile_rsrc(tau_s);
+    const unsigned tvo = 4u * tid;
+    const unsigned tcv0 = tau_is_tensor ? tvo : 0u, tcv1 = tau_is_tensor ? tvo + 1024u : 0u;   // time constants: (C,H,W) or (1)
+    const unsigned tcs = tau_is_tensor ? 2048u : 0u;
     float tx[2], te0[2], te1[2], ta[2], ttm[2], tas[2], tts[2];
     auto fetch_t = [&](int cp) {
+        const unsigned so = 2048u * cp, tso = tcs * cp;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int e = (2 * cp + i) * 256 + tid;
-            const long gidx = b * 8192 + e;
-            const int ti = tau_is_tensor ? e : 0;
             if (DBG & 4) {
                 tx[i] = te0[i] = te1[i] = (float)tid;
             } else {
-                tx[i] = x[gidx];
-                te0[i] = eps0_g[gidx];
-                te1[i] = eps1_g[gidx];
+                tx[i] = buf_ldf(xrs, tvo + 1024u * i, so);
+                te0[i] = buf_ldf(e0rs, tvo + 1024u * i, so);
+                te1[i] = buf_ldf(e1rs, tvo + 1024u * i, so);
             }
-            ta[i] = alpha[ti];
-            ttm[i] = tau_m[ti];
-            tas[i] = alphas[ti];
-            tts[i] = tau_s[ti];
+            const unsigned tv = i ? tcv1 : tcv0;
+            ta[i] = buf_ldf(ars, tv, tso);
+            ttm[i] = buf_ldf(tmrs, tv, tso);
+            tas[i] = buf_ldf(asrs, tv, tso);
+            tts[i] = buf_ldf(tsrs, tv, tso);
         }
     };
+    const int ipix = ((tid >> 4) + 3) * ROWF + (tid & 15) + 3;
     auto finish_t = [&](int cp) {
+        const unsigned so = 2048u * cp;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int c = 2 * cp + i;
-            const long gidx = b * 8192 + c * 256 + tid;
             trace_update(tx[i], ta[i], ttm[i], tas[i], tts[i], te0[i], te1[i]);
             if (!(DBG & 4) || te0[i] == 12345.678f) {
-                eps0_g[gidx] = te0[i];
-                eps1_g[gidx] = te1[i];
+                buf_stf(te0[i], e0rs, tvo + 1024u * i, so);
+                buf_stf(te1[i], e1rs, tvo + 1024u * i, so);
             }
-            img[c * CHF + ((tid >> 4) + 3) * ROWF + (tid & 15) + 3] = te1[i];
+            img[(2 * cp + i) * CHF + ipix] = te1[i];
         }
     };
     fetch_w(0);
     fetch_t(0);
     // the refractory trace of my 2 x 16 outputs is requested NOW and lands under the chunk loop: the epilogue of a launch
     // (all workgroups reach it together) is an HBM burst — arp in, s / pv / v / arp out, 160 KB per sample at ~5.6 TB/s —
-    // and these 32 KB per sample are the part of it that does not depend on the MFMAs
+    // and these 32 KB per sample are the part of it that does not depend on the MFMAs.  Output addressing (also of the
+    // epilogue below): descriptor of the sample's 32 planes + lane offset (channel 4h, pixel j) + immediate (r & 3 channels,
+    // tile of the pair) + scalar offset (8 (r >> 2) channels, my tile pair)
+    const unsigned ovo = 4096u * h + 4u * j, oso = 256u * w;
+    const auto aprs = tile_rsrc(arp_g + b * 8192);
     float arp_pre[2][16];
     if (REFRACTORY && !(DBG & 2)) {
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                arp_pre[tl][r] = arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 32 * (2 * w + tl) + j];
+                arp_pre[tl][r] = buf_ldf(aprs, ovo + 1024u * (r & 3) + 128u * tl, oso + 8192u * (r >> 2));
     }
     // (the image is zeroed while those requests are in flight: all workgroups of a launch start together, and the first
     //  chunk cannot begin before the slowest of them has its first operands)
-    for (int i = tid; i < IMG_FLOATS; i += 256) img[i] = 0.0f;
+    for (int i = tid; i < IMG_FLOATS / 4; i += 256) ((f32x4 *)img)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();        // image zeroed
     finish_t(0);
     store_w(0);
@@ -2213,7 +2246,10 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
     for (int r = 0; r < 16; ++r) accA[r] = accB[r] = sbias[(r & 3) + 8 * (r >> 2) + 4 * h];
     const int bbase = h * CHF + ((j >> 4) + 4 * w) * ROWF + (j & 15);
     if (DBG & 32) stamp1 = __builtin_amdgcn_s_memtime();
-    for (int cp = 0; cp < 16; ++cp) {
+    // one chunk = one input-channel pair; the loop runs two chunks per iteration so that the chunk buffer (cp & 1) is a
+    // compile-time constant: its LDS offset folds into the immediates of the 13 copy-in writes (13 v_add_u32 per chunk else)
+    auto chunk = [&](int cp, auto parity) {
+        constexpr int par = decltype(parity)::value;
         if (cp + 1 < 16) {                                 // land during the MFMAs below
             if (!(DBG & 8) && !(DBG & 128)) fetch_w(cp + 1);
             fetch_t(cp + 1);
@@ -2221,7 +2257,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         // per-lane bases as opaque 32-bit LDS addresses: every operand read below is base + immediate (ds_read2's 8-bit
         // dword offsets reach all 49 taps / all 9 rows).  Left visible, the arrays' static LDS offsets (the chunk buffers
         // sit 47 KB into the allocation) do not fit the immediates and the compiler rebuilds a base per read.
-        lds_cfloat *wa = (lds_cfloat *)(wch + (cp & 1) * STEP_WCH + lane * STEP_WLS);
+        lds_cfloat *wa = (lds_cfloat *)(wch + par * STEP_WCH + lane * STEP_WLS);
         lds_cfloat *ib = (lds_cfloat *)(img + bbase + cp * 2 * CHF);
         asm volatile("" : "+v"(wa), "+v"(ib));
         // LDS rows rho = 0..8 below the pair's first image row: row rho is tap row ky = rho of tile A (rho <= 6) and
@@ -2249,39 +2285,48 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             }
         }
         if (cp + 1 < 16) {
-            if (!(DBG & 8) && !(DBG & 64)) store_w((cp + 1) & 1); // the other buffer: nobody reads it in this iteration
+            if (!(DBG & 8) && !(DBG & 64)) store_w(par ^ 1);      // the other buffer: nobody reads it in this iteration
             finish_t(cp + 1);                              // image channels nobody reads in this iteration
         }
         // LDS-only barrier: it orders the image / chunk writes above against the next chunk's reads; the state stores of
         // finish_t need not have landed (__syncthreads() also waits for their acknowledgement: s_waitcnt vmcnt(0))
         if (!(DBG & 16)) lds_barrier();
+    };
+    for (int cp = 0; cp < 16; cp += 2) {
+        chunk(cp, std::integral_constant<int, 0>{});
+        chunk(cp + 1, std::integral_constant<int, 1>{});
     }
     if (DBG & 32) {
         asm volatile("" ::"v"(accA[0]), "v"(accB[0]));
         stamp2 = __builtin_amdgcn_s_memtime();
     }
     // epilogue of my two tiles: channel (r&3) + 8(r>>2) + 4h, pixel 32(2w + tl) + j
+    const auto srs = tile_rsrc(out_s + b * 8192), pvrs = tile_rsrc(out_pv + b * 8192);
+    const auto vrs = tile_rsrc((out_v ? out_v : out_pv) + b * 8192);
+    auto epilogue = [&](auto want_v) {          // (one wave-uniform test of out_v, not one per value)
 #pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
+        for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const long o = (b * 32 + co) * 256 + 32 * (2 * w + tl) + j;
-            const float pvm = tl ? accB[r] : accA[r];
-            float v = pvm;
-            bool s;
-            if (REFRACTORY) {
-                float ar = (DBG & 2) ? 0.0f : arp_pre[tl][r];
-                v = refractory(pvm, ar, alpharp, wrp, s);
-                if (!(DBG & 2) || ar == 12345.678f) arp_g[o] = ar;
-            } else {
-                s = v > 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                const unsigned vo = ovo + 1024u * (r & 3) + 128u * tl, so = oso + 8192u * (r >> 2);
+                const float pvm = tl ? accB[r] : accA[r];
+                float v = pvm;
+                bool s;
+                if (REFRACTORY) {
+                    float ar = (DBG & 2) ? 0.0f : arp_pre[tl][r];
+                    v = refractory(pvm, ar, alpharp, wrp, s);
+                    if (!(DBG & 2) || ar == 12345.678f) buf_stf(ar, aprs, vo, so);
+                } else {
+                    s = v > 0.0f;
+                }
+                if ((DBG & 2) && v != 12345.678f) continue;
+                buf_stf(s ? 1.0f : 0.0f, srs, vo, so);
+                buf_stf(sigmoidf_dev(v), pvrs, vo, so);
+                if (decltype(want_v)::value) buf_stf(v, vrs, vo, so);
             }
-            if ((DBG & 2) && v != 12345.678f) continue;
-            out_s[o] = s ? 1.0f : 0.0f;
-            out_pv[o] = sigmoidf_dev(v);
-            if (out_v) out_v[o] = v;
-        }
+    };
+    if (out_v) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if ((DBG & 32) && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long stamp3 = __builtin_amdgcn_s_memtime(), real3 = __builtin_amdgcn_s_memrealtime();
@@ -2305,7 +2350,7 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 // the CUs (one workgroup per sample runs 69 us however small the batch is).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int ST_RF = 22;                                          // region row stride
-template <bool REFRACTORY, int TH>
+template <bool REFRACTORY, int TH, bool Q8 = false>
 __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const float *__restrict__ bias,
                                                         const float *__restrict__ eps1_g, float *__restrict__ arp_g,
                                                         float *__restrict__ out_s, float *__restrict__ out_pv,
@@ -2321,30 +2366,31 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const 
     const int tile = blockIdx.x % tps, y0 = (tile / tpr) * TH, x0 = (tile % tpr) * 16;
     const long HW = (long)H * Wd;
     if (tid < 32) sbias[tid] = bias[tid];
-    step_wchunk wc;                                              // weight chunks exactly as in k_lif_step_c32
-    wc.init(tid);
-    auto fetch_w = [&](int cp) { wc.fetch(W, cp); };
+    step_wchunk<Q8> wc;                                          // weight chunks exactly as in k_lif_step_c32
+    wc.init(tid, W);
+    auto fetch_w = [&](int cp) { wc.fetch(cp); };
     auto store_w = [&](int buf) { wc.store(wch, buf); };
     // eps1 of one channel pair over the tile's (TH+6) x 22 region: element e = tid + 256 i of the 2 x ST_CF; addresses:
     // wave-uniform base of the sample + a 32-bit offset inside its 32 planes
     constexpr int NT = (ST_PAIR + 255) / 256;
-    int toff[NT];               // offset inside the channel pair's two planes, -1: outside the plane (zero) or no element
+    unsigned toff[NT];          // byte offset inside the channel pair's two planes; outside the plane (zero) or no element:
+                                // BUF_OOB — the buffer load returns 0 without a branch or an access
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int e = tid + 256 * i, r = e % ST_CF, ry = r / ST_RF, rx = r % ST_RF;
         const int gy = y0 + ry - 3, gx = x0 + rx - 3;
         const bool in = e < ST_PAIR && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)Wd;
-        toff[i] = in ? (e >= ST_CF ? (int)HW : 0) + gy * Wd + gx : -1;
+        toff[i] = in ? 4u * (unsigned)((e >= ST_CF ? (int)HW : 0) + gy * Wd + gx) : BUF_OOB;
     }
-    const float *e1b = eps1_g + b * 32 * HW;
-    const unsigned pair32 = 2u * (unsigned)HW;
+    const auto e1rs = tile_rsrc(eps1_g + b * 32 * HW);
+    const unsigned pair32 = 8u * (unsigned)HW;         // bytes per channel pair
     float te1[NT];
     auto fetch_t = [&](int cp) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) te1[i] = toff[i] >= 0 ? e1b[(unsigned)cp * pair32 + (unsigned)toff[i]] : 0.0f;
+        for (int i = 0; i < NT; ++i) te1[i] = buf_ldf(e1rs, toff[i], (unsigned)cp * pair32);
     };
-    auto store_t = [&](int cp) {
-        float *dst = img + (cp & 1) * ST_PAIR;
+    auto store_t = [&](int buf) {
+        float *dst = img + buf * ST_PAIR;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
             if (tid + 256 * i < ST_PAIR) dst[tid + 256 * i] = te1[i];
@@ -2360,23 +2406,31 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const 
     const int bbase = h * ST_CF + ((j >> 4) + (TH / 4) * w) * ST_RF + (j & 15);
     // the refractory trace of my outputs, requested now: it lands under the chunk loop instead of being waited for, load
     // by load, in the epilogue (k_lif_step_c32: epilogue 37k -> 12k cycles)
+    // output addressing (here and in the epilogue): descriptor of the sample's 32 planes + lane offset (channel 4h, my
+    // pixel of MFMA tile tq) + scalar offset (channel (r & 3) + 8 (r >> 2)): no 64-bit address per value
+    const auto aprs = tile_rsrc(arp_g + b * 32 * HW);
+    unsigned ovo[TH / 8];
+#pragma unroll
+    for (int tq = 0; tq < TH / 8; ++tq) {
+        const int p = 32 * ((TH / 8) * w + tq) + j;
+        ovo[tq] = 4u * (unsigned)(4 * h * (int)HW + (y0 + (p >> 4)) * Wd + x0 + (p & 15));
+    }
+    const unsigned plane4 = 4u * (unsigned)HW;
     float arp_pre[TH / 8][16];
     if (REFRACTORY) {
 #pragma unroll
         for (int tq = 0; tq < TH / 8; ++tq)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = 32 * ((TH / 8) * w + tq) + j;
-                arp_pre[tq][r] = arp_g[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15)];
-            }
+            for (int r = 0; r < 16; ++r) arp_pre[tq][r] = buf_ldf(aprs, ovo[tq], plane4 * ((r & 3) + 8 * (r >> 2)));
     }
-    for (int cp = 0; cp < 16; ++cp) {
+    auto chunk = [&](int cp, auto parity) {     // two chunks per loop iteration: the buffer index is a constant (k_lif_step_c32)
+        constexpr int par = decltype(parity)::value;
         if (cp + 1 < 16) {                                 // land during the MFMAs below
             fetch_w(cp + 1);
             fetch_t(cp + 1);
         }
-        lds_cfloat *wa = (lds_cfloat *)(wch + (cp & 1) * STEP_WCH + lane * STEP_WLS);      // opaque bases: see k_lif_step_c32
-        lds_cfloat *ib = (lds_cfloat *)(img + (cp & 1) * ST_PAIR + bbase);
+        lds_cfloat *wa = (lds_cfloat *)(wch + par * STEP_WCH + lane * STEP_WLS);      // opaque bases: see k_lif_step_c32
+        lds_cfloat *ib = (lds_cfloat *)(img + par * ST_PAIR + bbase);
         asm volatile("" : "+v"(wa), "+v"(ib));
         float wr[3][7];
 #pragma unroll
@@ -2396,33 +2450,41 @@ __global__ __launch_bounds__(256) void k_lif_step_c32t(const dcll_wsrc W, const 
             }
         }
         if (cp + 1 < 16) {
-            store_w((cp + 1) & 1);                         // the other buffers: nobody reads them in this iteration
-            store_t(cp + 1);
+            store_w(par ^ 1);                              // the other buffers: nobody reads them in this iteration
+            store_t(par ^ 1);
         }
         __syncthreads();
+    };
+    for (int cp = 0; cp < 16; cp += 2) {
+        chunk(cp, std::integral_constant<int, 0>{});
+        chunk(cp + 1, std::integral_constant<int, 1>{});
     }
     // epilogue of my MFMA tile(s): channel (r&3) + 8(r>>2) + 4h, tile pixel 32((TH/8) w + tq) + j
+    const auto srs = tile_rsrc(out_s + b * 32 * HW), pvrs = tile_rsrc(out_pv + b * 32 * HW);
+    const auto vrs = tile_rsrc((out_v ? out_v : out_pv) + b * 32 * HW);
+    auto epilogue = [&](auto want_v) {
 #pragma unroll
-    for (int tq = 0; tq < TH / 8; ++tq)
+        for (int tq = 0; tq < TH / 8; ++tq)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int p = 32 * ((TH / 8) * w + tq) + j;
-            const long o = (b * 32 + co) * HW + (long)(y0 + (p >> 4)) * Wd + x0 + (p & 15);
-            const float pvm = tq ? accB[r] : accA[r];
-            float v = pvm;
-            bool s;
-            if (REFRACTORY) {
-                float ar = arp_pre[tq][r];
-                v = refractory(pvm, ar, alpharp, wrp, s);
-                arp_g[o] = ar;
-            } else {
-                s = v > 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                const unsigned vo = ovo[tq], so = plane4 * ((r & 3) + 8 * (r >> 2));
+                const float pvm = tq ? accB[r] : accA[r];
+                float v = pvm;
+                bool s;
+                if (REFRACTORY) {
+                    float ar = arp_pre[tq][r];
+                    v = refractory(pvm, ar, alpharp, wrp, s);
+                    buf_stf(ar, aprs, vo, so);
+                } else {
+                    s = v > 0.0f;
+                }
+                buf_stf(s ? 1.0f : 0.0f, srs, vo, so);
+                buf_stf(sigmoidf_dev(v), pvrs, vo, so);
+                if (decltype(want_v)::value) buf_stf(v, vrs, vo, so);
             }
-            out_s[o] = s ? 1.0f : 0.0f;
-            out_pv[o] = sigmoidf_dev(v);
-            if (out_v) out_v[o] = v;
-        }
+    };
+    if (out_v) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // The trace update of a whole state tensor, four elements per thread (n % 4 == 0, per_sample % 4 == 0): the pass in
@@ -2605,8 +2667,9 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
         HIP_CHECK_LAUNCH("k_trace4");
         const long njob = (long)B * (d->h / (split16 ? 8 : 16)) * (d->w / 16);
         if (njob > 0x7fffffffL) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_step: more than 2^31 tiles");
-#define DCLL_STEP_T(R_, TH_) hipLaunchKernelGGL((k_lif_step_c32t<R_, TH_>), dim3((unsigned)njob), dim3(256), 0, st, W, b, eps1,  \
-                                                arp, out_s, out_pv, out_v, d->h, d->w, d->alpharp, d->wrp)
+#define DCLL_STEP_TQ(R_, TH_, Q_) hipLaunchKernelGGL((k_lif_step_c32t<R_, TH_, Q_>), dim3((unsigned)njob), dim3(256), 0, st, W, b, \
+                                                     eps1, arp, out_s, out_pv, out_v, d->h, d->w, d->alpharp, d->wrp)
+#define DCLL_STEP_T(R_, TH_) do { if (W.q) DCLL_STEP_TQ(R_, TH_, true); else DCLL_STEP_TQ(R_, TH_, false); } while (0)
         if (c1t) {
             if (d->refractory)
                 hipLaunchKernelGGL((k_lif_step_c1<true, true>), dim3((unsigned)njob), dim3(256), 0, st, d->c_out, x, W, b, alpha,
@@ -2622,6 +2685,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
             if (d->refractory) DCLL_STEP_T(true, 16); else DCLL_STEP_T(false, 16);
         }
 #undef DCLL_STEP_T
+#undef DCLL_STEP_TQ
         HIP_CHECK_LAUNCH("k_lif_step_c32t / k_lif_step_c1 (tiled)");
         if (i2o_W && out_p) {
             rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
@@ -2645,12 +2709,13 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
                 hipLaunchKernelGGL((k_lif_step_c1<false, false>), dim3(B), dim3(256), 0, st, d->c_out, x, W, b, alpha, tau_m,
                                    alphas, tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp,
                                    16, 16);
-        } else if (d->refractory)
-            hipLaunchKernelGGL(k_lif_step_c32<true>, dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
-                               d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
-        else
-            hipLaunchKernelGGL(k_lif_step_c32<false>, dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, tau_s,
-                               d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp);
+        } else {
+#define DCLL_STEP_16(R_, Q_) hipLaunchKernelGGL((k_lif_step_c32<R_, 0, Q_>), dim3(B), dim3(256), 0, st, x, W, b, alpha, tau_m, alphas, \
+                                                tau_s, d->tau_is_tensor, eps0, eps1, arp, out_s, out_pv, out_v, d->alpharp, d->wrp)
+            if (d->refractory) { if (W.q) DCLL_STEP_16(true, true); else DCLL_STEP_16(true, false); }
+            else { if (W.q) DCLL_STEP_16(false, true); else DCLL_STEP_16(false, false); }
+#undef DCLL_STEP_16
+        }
         HIP_CHECK_LAUNCH("k_lif_step_c32 / k_lif_step_c1");
         if (i2o_W && out_p) {
             rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
