@@ -1909,7 +1909,8 @@ static int launch_readout(const float *pv, const float *Wt, const float *bias, f
                           hipStream_t st, int mode = DCLL_READOUT_AUTO)
 {
     if (rows == 0 || N == 0) return DCLL_OK;
-    const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0;
+    const bool fast = (K % RO_KC == 0) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0 &&
+                      K < (1 << 22);     // (32-bit buffer offsets inside a workgroup's 128 rows)
     const bool direct_ok = fast && K % 64 == 0 && N <= 48 && K <= 16384 && mode != DCLL_READOUT_LDS;
     // (standalone the LDS-free kernel is slower than the LDS-staged ones — 4.6 vs 3.5 ms for 24 rows, 6.9 vs 5.3 ms for 48
     //  at B = 4096: its fragment-layout loads give the texture addresser one 16-byte piece per lane — so it only serves

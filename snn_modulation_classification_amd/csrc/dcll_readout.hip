@@ -144,31 +144,36 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
                                                       const float *__restrict__ bias, float *__restrict__ out,
                                                       long rows, int K, int N, int kslice)
 {
+    constexpr int NBF = (NT * 16 * 8 + 255) / 256;          // float4 loads of the weight chunk per thread
     __shared__ __attribute__((aligned(16))) float sA[T16_ROWS * T16_LD];
-    __shared__ __attribute__((aligned(16))) float sB[NT * 16 * T16_LD];
+    __shared__ __attribute__((aligned(16))) float sB[NBF * 32 * T16_LD];     // (rows >= NT * 16: staged zeros nobody reads)
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long row0 = (long)blockIdx.x * T16_ROWS;
     const int kc = (tid & 7) * 4, rsub = tid >> 3;          // 8 threads x float4 = one 32-float K-chunk of a row
-    constexpr int NBF = (NT * 16 * 8 + 255) / 256;          // float4 loads of the weight chunk per thread
     f32x4 acc[2][NT];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Operand fetch as BUFFER loads (round 4): descriptor = this workgroup's 128 rows of pv (resp. the readout matrix), its
+    // record count = the rows that exist, lane offset = (row, 4 floats of the chunk), scalar offset = the chunk — a row past
+    // the end is out of range and reads as zeros.  (Flat loads: a 64-bit address and an exec-mask branch per load — 21
+    // vector instructions + 6 branches per 32-float chunk on the pipe the fp32 MFMAs of the chunk execute on.)
+    const long nra = rows - row0 < T16_ROWS ? rows - row0 : T16_ROWS;
+    const auto ars = __builtin_amdgcn_make_buffer_rsrc((void *)(pv + row0 * K), 0, (int)(nra * K * 4), 0x00020000);
+    const auto brs = __builtin_amdgcn_make_buffer_rsrc((void *)Wt, 0, (N < NT * 16 ? N : NT * 16) * K * 4, 0x00020000);
+    unsigned avo[4], bvo[NBF];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) avo[q] = 4u * (unsigned)((rsub + 32 * q) * K + kc);
+#pragma unroll
+    for (int q = 0; q < NBF; ++q) bvo[q] = 4u * (unsigned)((rsub + 32 * q) * K + kc);
     f32x4 ra[4], rb[NBF];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long gr = row0 + rsub + 32 * q;
-            ra[q] = gr < rows ? __builtin_nontemporal_load((const f32x4 *)(pv + gr * K + k0 + kc))
-                              : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int q = 0; q < 4; ++q) ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avo[q], 4u * k0, 2));
 #pragma unroll
-        for (int q = 0; q < NBF; ++q) {
-            const int nn = rsub + 32 * q;
-            rb[q] = (nn < N && nn < NT * 16) ? *(const f32x4 *)(Wt + (long)nn * K + k0 + kc) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int q = 0; q < NBF; ++q) rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, bvo[q], 4u * k0, 0));
     };
     const int kbeg = kslice > 0 ? blockIdx.y * kslice : 0, kend = kslice > 0 ? kbeg + kslice : K;
     if (kslice > 0) { out += (long)blockIdx.y * rows * N; bias = nullptr; }
@@ -183,8 +188,7 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
             *(f32x4 *)(sA + (rsub + 32 * q) * T16_LD + kc) = ra[q];
         }
 #pragma unroll
-        for (int q = 0; q < NBF; ++q)
-            if (rsub + 32 * q < NT * 16) *(f32x4 *)(sB + (rsub + 32 * q) * T16_LD + kc) = rb[q];
+        for (int q = 0; q < NBF; ++q) *(f32x4 *)(sB + (rsub + 32 * q) * T16_LD + kc) = rb[q];
         __syncthreads();
         if (k0 + T16_KC < kend) fetch(k0 + T16_KC);
 #pragma unroll
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
 int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
                             int kslice, hipStream_t st, int act)
 {
+    if (K >= (1 << 22)) return fail(DCLL_ERR_UNSUPPORTED, "readout GEMM: K above 4 M features per row");
     const dim3 g((unsigned)((rows + T16_ROWS - 1) / T16_ROWS), kslice > 0 ? K / kslice : 1);
 #define DCLL_T16(NT_)                                                                                                   \
     do {                                                                                                                \
