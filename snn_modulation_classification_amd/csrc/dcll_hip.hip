@@ -1742,10 +1742,16 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
         // B's ky = 5, 6 (rho = 7, 8): 168 instead of 196 MFMAs for those two of the four pairs
         const bool skip = !(DBG & 4);
         const int rl = (skip && p == 0) ? 2 : 0;        // first LDS row of my chains
+        // B-fragment bases of my two channel pairs as opaque 32-bit LDS addresses: every read of the chains is base +
+        // immediate (9 rows x 19 floats + 7 taps = 158 dwords, inside ds_read2_b32's 8-bit offsets).  Left visible, the
+        // pair stride (722 dwords) does not fit and the compiler rebuilds a base for 27 of the reads — vector instructions
+        // on the pipe the MFMAs execute on (experiments/isa_blocks.py)
+        lds_cfloat *ib0 = (lds_cfloat *)(lds + i0), *ib1 = (lds_cfloat *)(lds + i0 + 2 * CHF);
+        asm volatile("" : "+v"(ib0), "+v"(ib1));
         float bq[2][7];
         if (active) {
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = lds[i0 + rl * ROWF + kx];
+            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = ib0[rl * ROWF + kx];
         }
         // ---- (2) trace share (dcll/pytorch_libdcll.py:493-494, every op rounded separately) ----
         if (tr) {
@@ -1806,7 +1812,7 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32d(const uint32_t *__restrict
                     if (r + 1 < NR) {
                         const int cpn = (r + 1) / NRH, rhon = RL + (r + 1) % NRH;
 #pragma unroll
-                        for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = lds[i0 + cpn * 2 * CHF + rhon * ROWF + kx];
+                        for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = (cpn ? ib1 : ib0)[rhon * ROWF + kx];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2087,7 +2093,6 @@ extern "C" int dcll_readout_act(const float *pv, const float *Wt, const float *b
 // contiguous: thread t of the 256 moves elements t, t+256, ... of the 32 x 98 block through registers (fetched while the
 // MFMAs of the previous chunk run); the index arithmetic is done once per kernel.
 constexpr int STEP_WLS = 49, STEP_WCH = 64 * STEP_WLS + 4;
-typedef __attribute__((address_space(3))) const float lds_cfloat;
 // Every global access of the per-step kernels is a BUFFER access (round 4): 128-bit descriptor of a wave-uniform base in
 // SGPRs + a loop-invariant 32-bit lane offset + a scalar / immediate offset that walks with the chunk — no 64-bit vector
 // address is formed inside the chunk loop (flat accesses: v_add_co / v_addc per load and a v_cndmask + exec-mask branch per

@@ -185,6 +185,10 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+// A 32-bit LDS address the compiler cannot fold into static offsets (after `asm volatile("" : "+v"(p))`): reads through it are
+// base + immediate, where a visible static offset beyond the instruction's range makes the compiler rebuild a base per read.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+
 // Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS (and scalar) operations, then
 // s_barrier — without the s_waitcnt vmcnt(0) that __syncthreads() adds for its global-memory fence, so a wave does not
 // stall on its own pv / spike stores.  The builtin keeps the barrier convergent for the compiler.
