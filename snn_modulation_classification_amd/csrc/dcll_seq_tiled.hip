@@ -267,16 +267,22 @@ __global__ __launch_bounds__(512) void k_lif_seq_c32t(const uint32_t *__restrict
             // LDS rows 0..7 below the pair's first image row, per channel pair: row rho is tap row ky = rho of tile A
             // (rho <= 6) and tap row ky = rho - 1 of tile B (rho >= 1); next row fetched before the MFMAs of this one.
             const int i0 = bbase + 2 * p * TRW;
+            // opaque 32-bit LDS bases — per channel pair one for rows 0..3 and one for rows 4..7 (8 rows x 38 floats do not
+            // fit ds_read2_b32's 255-dword reach from one): every read of the chains is base + immediate (k_lif_seq_c32d:
+            // left to the compiler, 28 address instructions per 196 MFMAs, on the pipe the MFMAs execute on)
+            lds_cfloat *ib[2][2] = {{(lds_cfloat *)(lds + i0), (lds_cfloat *)(lds + i0 + 4 * TRW)},
+                                    {(lds_cfloat *)(lds + i0 + 2 * TCH), (lds_cfloat *)(lds + i0 + 2 * TCH + 4 * TRW)}};
+            asm volatile("" : "+v"(ib[0][0]), "+v"(ib[0][1]), "+v"(ib[1][0]), "+v"(ib[1][1]));
             float bq[2][7];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = lds[i0 + kx];
+            for (int kx = 0; kx < 7; ++kx) bq[0][kx] = ib[0][0][kx];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cp = r / 8, rho = r % 8;
                 if (r + 1 < 16) {
                     const int cpn = (r + 1) / 8, rhon = (r + 1) % 8;
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = lds[i0 + cpn * 2 * TCH + rhon * TRW + kx];
+                    for (int kx = 0; kx < 7; ++kx) bq[(r + 1) & 1][kx] = ib[cpn][rhon >> 2][(rhon & 3) * TRW + kx];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
