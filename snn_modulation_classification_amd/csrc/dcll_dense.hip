@@ -20,7 +20,7 @@
 //   dcll_hip.hip decides) — at in_features = 8192 a single sample's traces are 64 KB: they cannot stay on chip.
 #include "dcll_internal.h"
 
-constexpr int DN_BT = 128, DN_OT = 64, DN_KC = 32, DN_LD = 34;
+constexpr int DN_BT = 128, DN_KC = 32, DN_LD = 34;
 
 // 4 consecutive floats of row `row` (nrows rows of n floats) from column k0, zeros outside; float4 when it is aligned
 __device__ __forceinline__ f32x4 dn_load4(const float *__restrict__ m, long row, long nrows, int n, int k0, bool vec)
@@ -39,62 +39,130 @@ __device__ __forceinline__ f32x4 dn_load4(const float *__restrict__ m, long row,
     return v;
 }
 
-template <bool REFRACTORY>
+// NTW = neuron tiles per wave: 2 (one A fragment feeds two MFMAs; workgroup = 128 samples x 64 neurons) or 1 (128 x 32: twice
+// the workgroups — chosen when the launch would otherwise put fewer than two workgroups = two waves per SIMD on a CU: with one
+// wave per SIMD nothing covers its barrier and its LDS round trip, 58 % of the MFMA peak at in = 8192, out = 512, B = 4096)
+template <bool REFRACTORY, int NTW>
 __global__ __launch_bounds__(256) void k_dense_lif_mfma(int in, int out, const float *__restrict__ eps1,
                                                          const float *__restrict__ W, const float *__restrict__ bias,
                                                          float *__restrict__ arp, float *__restrict__ s_out,
                                                          float *__restrict__ pv_out, float *__restrict__ v_out, int B,
                                                          float alpharp, float wrp)
 {
-    __shared__ __attribute__((aligned(16))) float sE[DN_BT * DN_LD];
-    __shared__ __attribute__((aligned(16))) float sW[DN_OT * DN_LD];
+    // two LDS buffers and two register sets (round 4): chunk c is computed from buffer c & 1 while chunk c + 1 is written into
+    // the other buffer and chunk c + 3 is requested — one barrier per chunk, and a request has two chunks of MFMAs (4k cycles)
+    // to land.  (At in = 8192, out = 512, B = 4096 the launch is ONE workgroup per CU: no other workgroup hides the latency.)
+    constexpr int DN_OT = 32 * NTW;
+    __shared__ __attribute__((aligned(16))) float sE[2][DN_BT * DN_LD];
+    __shared__ __attribute__((aligned(16))) float sW[2][DN_OT * DN_LD];
     const int tid = threadIdx.x, lane = tid & 63, jj = lane & 31, kk = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long b0 = (long)blockIdx.y * DN_BT;
-    const int o0 = blockIdx.x * DN_OT;
+    // XCD-aware tile order (round 4).  Workgroup L of a launch goes to XCD L % 8 (each XCD has its own 4 MB L2).  With the
+    // plain order (neuron tile fastest) an XCD gets ONE neuron tile of every sample block: every block of eps1 (the large
+    // operand: 128 x in floats) is fetched by all eight XCDs — 8 x the state through the fabric, 1.2 GB per step at in = 8192,
+    // B = 4096.  Here the workgroups of one XCD walk ALL neuron tiles of a sample block before the next block: eps1 crosses
+    // once (its other seven readers hit that XCD's L2), only W (small) is read by every XCD.
+    const int gx = (out + DN_OT - 1) / DN_OT, gy = (B + DN_BT - 1) / DN_BT;
+    const int L = blockIdx.x;
+    int tx, ty;
+    if (gy % 8 == 0) {
+        const int xcd = L & 7, slot = L >> 3;
+        tx = slot % gx;
+        ty = (slot / gx) * 8 + xcd;
+    } else {
+        tx = L % gx;
+        ty = L / gx;
+    }
+    const long b0 = (long)ty * DN_BT;
+    const int o0 = tx * DN_OT;
     const int r = tid >> 3, c4 = (tid & 7) * 4;             // staging: 8 threads x float4 = one 32-float chunk of a row
     const bool vec = (in % 4 == 0) && ((((uintptr_t)eps1 | (uintptr_t)W) & 15) == 0);
-    f32x4 re[4], rw[2];
-    auto fetch = [&](int k0) {
+    f32x4 re[2][4], rw[2][NTW];
+    // Whole 32-feature chunks of 16-byte aligned rows are fetched with BUFFER loads (round 4): descriptor = this workgroup's
+    // 128 samples of eps1 (resp. its 64 rows of W), record count = the rows that exist (a row past the end reads as zeros),
+    // lane offset = (row, 4 floats), scalar offset = the chunk — no vector instruction, no branch.  (The general fetch
+    // below it is three exec-mask branches and ~20 address / select instructions per float4: ~120 vector instructions and
+    // ~40 branches per chunk of 32 MFMAs, on the pipe the MFMAs execute on — it now serves only a ragged last chunk and
+    // unaligned operands.)
+    const int kfast = (vec && in < (1 << 22)) ? (in & ~(DN_KC - 1)) : 0;
+    const long nb = B - b0 < DN_BT ? B - b0 : DN_BT;
+    const int no = out - o0 < DN_OT ? out - o0 : DN_OT;
+    const auto ers = __builtin_amdgcn_make_buffer_rsrc((void *)(eps1 + b0 * in), 0, (int)(nb * in * 4), 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(W + (long)o0 * in), 0, no * in * 4, 0x00020000);
+    unsigned evo[4], wvo[NTW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) re[q] = dn_load4(eps1, b0 + r + 32 * q, B, in, k0 + c4, vec);
+    for (int q = 0; q < 4; ++q) evo[q] = 4u * (unsigned)((r + 32 * q) * in + c4);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) rw[q] = dn_load4(W, o0 + r + 32 * q, out, in, k0 + c4, vec);
+    for (int q = 0; q < NTW; ++q) wvo[q] = 4u * (unsigned)((r + 32 * q) * in + c4);
+    auto fetch = [&](auto setc, int k0) {
+        constexpr int S = decltype(setc)::value;
+        if (k0 >= in) return;
+        if (k0 < kfast) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) re[S][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ers, evo[q], 4u * k0, 0));
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) rw[S][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[q], 4u * k0, 0));
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) re[S][q] = dn_load4(eps1, b0 + r + 32 * q, B, in, k0 + c4, vec);
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) rw[S][q] = dn_load4(W, o0 + r + 32 * q, out, in, k0 + c4, vec);
+    };
+    auto store = [&](auto setc) {                           // register set S -> LDS buffer S
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float *dst = sE[S] + (r + 32 * q) * DN_LD + c4;
+            *(f32x2 *)dst = f32x2{re[S][q][0], re[S][q][1]};
+            *(f32x2 *)(dst + 2) = f32x2{re[S][q][2], re[S][q][3]};
+        }
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            float *dst = sW[S] + (r + 32 * q) * DN_LD + c4;
+            *(f32x2 *)dst = f32x2{rw[S][q][0], rw[S][q][1]};
+            *(f32x2 *)(dst + 2) = f32x2{rw[S][q][2], rw[S][q][3]};
+        }
     };
     f32x16 acc0, acc1;                                      // chains start from the bias (lane = output neuron)
     {
-        const float bz0 = (bias && o0 + jj < out) ? bias[o0 + jj] : 0.0f, bz1 = (bias && o0 + 32 + jj < out) ? bias[o0 + 32 + jj] : 0.0f;
+        const float bz0 = (bias && o0 + jj < out) ? bias[o0 + jj] : 0.0f;
+        const float bz1 = (NTW == 2 && bias && o0 + 32 + jj < out) ? bias[o0 + 32 + jj] : 0.0f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc0[q] = bz0; acc1[q] = bz1; }
     }
-    fetch(0);
-    for (int k0 = 0; k0 < in; k0 += DN_KC) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float *dst = sE + (r + 32 * q) * DN_LD + c4;
-            *(f32x2 *)dst = f32x2{re[q][0], re[q][1]};
-            *(f32x2 *)(dst + 2) = f32x2{re[q][2], re[q][3]};
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float *dst = sW + (r + 32 * q) * DN_LD + c4;
-            *(f32x2 *)dst = f32x2{rw[q][0], rw[q][1]};
-            *(f32x2 *)(dst + 2) = f32x2{rw[q][2], rw[q][3]};
-        }
-        __syncthreads();
-        if (k0 + DN_KC < in) fetch(k0 + DN_KC);
-        const float *ea = sE + (32 * w + jj) * DN_LD + kk, *wb0 = sW + jj * DN_LD + kk, *wb1 = sW + (32 + jj) * DN_LD + kk;
+    auto compute = [&](auto bufc) {
+        constexpr int S = decltype(bufc)::value;
+        const float *ea = sE[S] + (32 * w + jj) * DN_LD + kk, *wb0 = sW[S] + jj * DN_LD + kk, *wb1 = sW[S] + (32 * (NTW - 1) + jj) * DN_LD + kk;
 #pragma unroll
         for (int s = 0; s < DN_KC / 2; ++s) {
             const float a = ea[2 * s];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb0[2 * s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb1[2 * s], acc1, 0, 0, 0);
+            if (NTW == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb1[2 * s], acc1, 0, 0, 0);
         }
+    };
+    const std::integral_constant<int, 0> S0;
+    const std::integral_constant<int, 1> S1;
+    fetch(S0, 0);
+    fetch(S1, DN_KC);
+    store(S0);
+    fetch(S0, 2 * DN_KC);
+    __syncthreads();
+    for (int k0 = 0; k0 < in; k0 += 2 * DN_KC) {
+        // chunk k0 from buffer 0; chunk k0 + 32 (register set 1, requested two chunks ago) -> buffer 1; request chunk k0 + 96
+        if (k0 + DN_KC < in) store(S1);
+        fetch(S1, k0 + 3 * DN_KC);
+        compute(S0);
+        __syncthreads();
+        if (k0 + DN_KC >= in) break;
+        if (k0 + 2 * DN_KC < in) store(S0);
+        fetch(S0, k0 + 4 * DN_KC);
+        compute(S1);
         __syncthreads();
     }
     // D layout: register q of lane (jj, kk) = sample (q & 3) + 8 (q >> 2) + 4 kk of the wave's 32, neuron jj of the tile
 #pragma unroll
-    for (int tl = 0; tl < 2; ++tl) {
+    for (int tl = 0; tl < NTW; ++tl) {
         const int o = o0 + 32 * tl + jj;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -122,14 +190,16 @@ __global__ __launch_bounds__(256) void k_dense_lif_mfma(int in, int out, const f
 int dcll_launch_dense_mfma(const dcll_dense_desc *d, const float *eps1, const float *W, const float *b, float *arp,
                            float *out_s, float *out_pv, float *out_v, int32_t B, hipStream_t st)
 {
-    const dim3 g((unsigned)((d->out_features + DN_OT - 1) / DN_OT), (unsigned)((B + DN_BT - 1) / DN_BT));
-    if (g.y > 65535) return fail(DCLL_ERR_UNSUPPORTED, "dense layer: batch above 8 M samples per call");
-    if (d->refractory)
-        hipLaunchKernelGGL(k_dense_lif_mfma<true>, g, dim3(256), 0, st, d->in_features, d->out_features, eps1, W, b, arp, out_s,
-                           out_pv, out_v, B, d->alpharp, d->wrp);
-    else
-        hipLaunchKernelGGL(k_dense_lif_mfma<false>, g, dim3(256), 0, st, d->in_features, d->out_features, eps1, W, b, arp, out_s,
-                           out_pv, out_v, B, d->alpharp, d->wrp);
+    const long gy = (B + DN_BT - 1) / DN_BT;
+    const bool narrow = ((d->out_features + 63) / 64) * gy < 512;       // fewer than two 128 x 64 workgroups per CU
+    const long ntile = (long)((d->out_features + (narrow ? 31 : 63)) / (narrow ? 32 : 64)) * gy;
+    if (ntile > 0x7fffffffL) return fail(DCLL_ERR_UNSUPPORTED, "dense layer: more than 2^31 output tiles per call");
+    const dim3 g((unsigned)ntile);
+#define DCLL_DENSE(R_, N_) hipLaunchKernelGGL((k_dense_lif_mfma<R_, N_>), g, dim3(256), 0, st, d->in_features, d->out_features, eps1, W,  \
+                                              b, arp, out_s, out_pv, out_v, B, d->alpharp, d->wrp)
+    if (d->refractory) { if (narrow) DCLL_DENSE(true, 1); else DCLL_DENSE(true, 2); }
+    else { if (narrow) DCLL_DENSE(false, 1); else DCLL_DENSE(false, 2); }
+#undef DCLL_DENSE
     HIP_CHECK_LAUNCH("k_dense_lif_mfma");
     return DCLL_OK;
 }
