@@ -217,17 +217,20 @@ def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
     if roof:
         # HBM traffic of the six launches: PMC counters cannot be read from inside this process — the summary of the separate
         # `rocprofv3 --pmc` passes of this command (profiles/collect_r03.sh ref) is used when it is for this batch
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_ref_b%d.json" % B)) as f:
-                ker = json.load(f)["kernels"]
-            w3 = {k: v for k, v in ker.items() if k.startswith("k_lif_seq_w3<64")}
-            if sum(v["launches"] for v in w3.values()) == 6:
-                roof["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in w3.values())
-                roof["traffic_unit"] = "HBM bytes per step over the six launches (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)"
-                roof["traffic_source"] = ("profiles/r03_pmc_ref_b%d.json (builder-side rocprofv3 --pmc passes of this command; "
-                                          "not measured in this run)" % B)
-        except (OSError, KeyError, ValueError):
-            pass
+        for rnd in (4, 3):
+            name = "r%02d_pmc_ref_b%d.json" % (rnd, B)
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)) as f:
+                    ker = json.load(f)["kernels"]
+                w3 = {k: v for k, v in ker.items() if k.startswith("k_lif_seq_w3<64")}
+                if sum(v["launches"] for v in w3.values()) == 6:
+                    roof["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in w3.values())
+                    roof["traffic_unit"] = "HBM bytes per step over the six launches (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC)"
+                    roof["traffic_source"] = ("profiles/%s (builder-side rocprofv3 --pmc passes of this command; not measured "
+                                              "in this run)" % name)
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
     kernel_ms = {k: float(np.sum([s_.elapsed_time(e_) for s_, e_ in v])) / steps for k, v in prof.items()}
     hbm = {}
     if kernel_ms.get("lif_c1"):
