@@ -2056,8 +2056,8 @@ extern "C" int dcll_readout_act(const float *pv, const float *Wt, const float *b
     if (rows == 0 || N == 0) return DCLL_OK;
     if (!pv || !Wt || !out || rows < 0 || K < 1 || N < 1 || (act != DCLL_ACT_NONE && act != DCLL_ACT_SIGMOID))
         return fail(DCLL_ERR_INVALID, "dcll_readout_act: bad argument");
-    if (!(K % RO_KC == 0 && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0))
-        return fail(DCLL_ERR_UNSUPPORTED, "dcll_readout_act: needs K % 32 == 0, N <= 64, 16-byte aligned pv / Wt");
+    if (!(K % RO_KC == 0 && K < (1 << 22) && N <= 64 && (((uintptr_t)pv | (uintptr_t)Wt) & 15) == 0))
+        return fail(DCLL_ERR_UNSUPPORTED, "dcll_readout_act: needs K % 32 == 0, K < 2^22, N <= 64, 16-byte aligned pv / Wt");
     hipStream_t st = (hipStream_t)stream;
     const int64_t need = dcll_readout_act_scratch(rows, K, N);
     if (need == 0) return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, 0, st, act);
