@@ -2119,13 +2119,19 @@ struct step_wchunk {            // speculates the 26 conversion instructions of 
     {
         constexpr bool q8 = Q8;
         rs = q8 ? tile_rsrc(W.q) : tile_rsrc(W.f);
+        // (co, r) of element tid + 256 i, stepped from i to i + 1 (256 = 2 * 98 + 60) instead of thirteen divisions by 98
+        // and 49: the index arithmetic sits in front of the kernel's first weight request
+        int co = tid >= 196 ? 2 : tid >= 98 ? 1 : 0, r = tid - 98 * co;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const bool valid = i < NW - 1 || tid < 32 * 98 - 256 * (NW - 1);
-            const int idx = valid ? tid + 256 * i : 0, co = idx / 98, r = idx % 98;
-            goff[i] = (unsigned)(co * 1568 + r) * (q8 ? 1u : 4u);
-            loff[i] = valid ? ((r / 49) * 32 + co) * STEP_WLS + (r % 49) : 64 * STEP_WLS;
-            qs[i] = q8 ? W.scale[co] : 0.0f;
+            const int cv = valid ? co : 0, rv = valid ? r : 0, hh = rv >= 49 ? 1 : 0;
+            goff[i] = (unsigned)(cv * 1568 + rv) * (q8 ? 1u : 4u);
+            loff[i] = valid ? (hh * 32 + cv) * STEP_WLS + (rv - 49 * hh) : 64 * STEP_WLS;
+            qs[i] = q8 ? W.scale[cv] : 0.0f;
+            r += 60;
+            co += 2;
+            if (r >= 98) { r -= 98; co += 1; }
         }
     }
     __device__ __forceinline__ void fetch(int cp)          // requests only: nothing here waits for the data
@@ -2177,7 +2183,6 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 
     if (tid < 32) sbias[tid] = bias[tid];
     step_wchunk<Q8> wc;
-    wc.init(tid, W);
     auto fetch_w = [&](int cp) { wc.fetch(cp); };
     auto store_w = [&](int buf) { wc.store(wch, buf); };
     // traces of this step (dcll/pytorch_libdcll.py:493-494), state updated in HBM, eps1 -> image — one channel PAIR at a
@@ -2223,8 +2228,8 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             img[(2 * cp + i) * CHF + ipix] = te1[i];
         }
     };
-    fetch_w(0);
-    fetch_t(0);
+    fetch_t(0);             // (state and refractory-trace requests first: they need no index arithmetic — the weight chunk's
+                            //  does, wc.init below, and runs while they are in flight)
     // the refractory trace of my 2 x 16 outputs is requested NOW and lands under the chunk loop: the epilogue of a launch
     // (all workgroups reach it together) is an HBM burst — arp in, s / pv / v / arp out, 160 KB per sample at ~5.6 TB/s —
     // and these 32 KB per sample are the part of it that does not depend on the MFMAs.  Output addressing (also of the
@@ -2240,9 +2245,17 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             for (int r = 0; r < 16; ++r)
                 arp_pre[tl][r] = buf_ldf(aprs, ovo + 1024u * (r & 3) + 128u * tl, oso + 8192u * (r >> 2));
     }
+    wc.init(tid, W);
+    fetch_w(0);
     // (the image is zeroed while those requests are in flight: all workgroups of a launch start together, and the first
     //  chunk cannot begin before the slowest of them has its first operands)
-    for (int i = tid; i < IMG_FLOATS / 4; i += 256) ((f32x4 *)img)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        constexpr int NZ4 = IMG_FLOATS / 4, NZF = NZ4 / 256;      // float4 stores: NZF per thread + a ragged one (immediates)
+        f32x4 *z = (f32x4 *)img + tid;
+#pragma unroll
+        for (int k = 0; k < NZF; ++k) z[256 * k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (tid < NZ4 - 256 * NZF) z[256 * NZF] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
     __syncthreads();        // image zeroed
     finish_t(0);
     store_w(0);
