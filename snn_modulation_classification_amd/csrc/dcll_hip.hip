@@ -2228,8 +2228,9 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             img[(2 * cp + i) * CHF + ipix] = te1[i];
         }
     };
-    fetch_t(0);             // (state and refractory-trace requests first: they need no index arithmetic — the weight chunk's
-                            //  does, wc.init below, and runs while they are in flight)
+    fetch_t(0);             // (the state request first: it needs no index arithmetic — the weight chunk's does, wc.init, and
+    wc.init(tid, W);        //  runs while it is in flight; the refractory trace, 32 KB per sample that nothing needs before the
+    fetch_w(0);             //  epilogue, is requested BEHIND the first chunk's operands)
     // the refractory trace of my 2 x 16 outputs is requested NOW and lands under the chunk loop: the epilogue of a launch
     // (all workgroups reach it together) is an HBM burst — arp in, s / pv / v / arp out, 160 KB per sample at ~5.6 TB/s —
     // and these 32 KB per sample are the part of it that does not depend on the MFMAs.  Output addressing (also of the
@@ -2245,8 +2246,6 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
             for (int r = 0; r < 16; ++r)
                 arp_pre[tl][r] = buf_ldf(aprs, ovo + 1024u * (r & 3) + 128u * tl, oso + 8192u * (r >> 2));
     }
-    wc.init(tid, W);
-    fetch_w(0);
     // (the image is zeroed while those requests are in flight: all workgroups of a launch start together, and the first
     //  chunk cannot begin before the slowest of them has its first operands)
     {
