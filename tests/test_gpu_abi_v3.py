@@ -471,7 +471,11 @@ def test_native_learning_step_drops_int8_form_and_readout_caches(dev, graph, mon
 
 # (in_features, out_features, B, T, tensor tau, wrp)
 DENSE_CASES = [(40, 24, 5, 4, False, 1.0), (40, 24, 5, 4, True, 0.0), (257, 130, 133, 3, True, 1.0), (1024, 128, 70, 6, True, 1.0),
-               (1000, 96, 33, 5, False, 0.0), (7, 3, 1, 5, True, 1.0), (2050, 64, 40, 3, True, 1.0), (96, 200, 64, 4, False, 1.0)]
+               (1000, 96, 33, 5, False, 0.0), (7, 3, 1, 5, True, 1.0), (2050, 64, 40, 3, True, 1.0), (96, 200, 64, 4, False, 1.0),
+               # launches large enough for the 128 x 64 workgroups of k_dense_lif_mfma (>= 512 of them; smaller launches take the
+               # 128 x 32 form): ragged in both directions with the plain tile order, and a multiple of eight sample blocks =
+               # the XCD-aware tile order; the same order on the 128 x 32 form
+               (36, 520, 7300, 2, True, 1.0), (64, 512, 8192, 2, False, 0.0), (48, 96, 1024, 2, True, 1.0)]
 
 
 @pytest.mark.parametrize("cin,cout,B,T,ttau,wrp", DENSE_CASES)
