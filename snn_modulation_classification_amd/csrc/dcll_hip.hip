@@ -21,9 +21,10 @@
 //                      so the result is ONE fmaf chain in the pinned order of include/dcll_hip.h; waves run
 //                      skewed by one tile (a systolic chain), one s_barrier per tile-stage.
 //   k_lif_seq_c1       first layer (c_in = 1, one input spike per step as a cell index or raw IQ): fp32 MFMA with the
-//                      49 taps padded to 28 k-pairs by zero weights, weight-stationary, one sample per workgroup.
+//                      49 taps in 25 k-pairs (only tap 49 is a zero-weight pad), weight-stationary, one sample per workgroup.
 //   k_lif_step_c32     ONE step of a 32->32 7x7 layer on the 16x16 plane (per-step drop-in, learning forward): no
-//                      systolic hand-off, every wave runs two whole chains, weights stream through LDS.
+//                      systolic hand-off, every wave runs two whole chains, weights stream through LDS; every global
+//                      access a buffer access (descriptor + lane offset + scalar / immediate offset).
 //   k_trace / k_conv_lif_tiled / k_conv_lif / k_pool   generic per-step path (any geometry, state in HBM) — the exact
 //                      drop-in for `.forward`; same pinned order.
 //   (dense twins: k_dense_lif_mfma / k_dense_lif_seq in dcll_dense.hip.)
