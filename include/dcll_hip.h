@@ -299,7 +299,8 @@ int dcll_readout(const float *pv, const float *Wt, const float *bias, float *out
  *     out[r, n] = sum_k act(pv[r,k])*Wt[n,k] + bias[n]
  * act = DCLL_ACT_SIGMOID applies the layer kernels' sigmoid (v_exp_f32 + v_rcp_f32) to every staged value: the logits equal
  * those of the pv = sigmoid(v) form up to the readout's summation order.  Always the LDS-staged 16x16x4 kernel: whole for
- * K < 65536, in eight K-slices (partials in caller scratch, summed in slice order) for longer rows — chosen by K alone, so
+ * K < 65536, in 8 ... 64 K-slices of >= 8192 columns (partials in caller scratch, summed in slice order) for longer rows —
+ * chosen by K alone, so
  * a row's logits do not depend on the row count, i.e. on how the caller chunks a batch (dcll_readout / dcll_readout_splitk
  * choose by row count: they serve the per-step calls).  Needs K % 32 == 0 (K % 256 == 0 when split), K < 2^22 (32-bit
  * offsets inside a workgroup's 128 rows), N <= 64, 16-byte aligned pv / Wt — else DCLL_ERR_UNSUPPORTED (the caller keeps pv = sigmoid(v) and dcll_readout for such shapes);

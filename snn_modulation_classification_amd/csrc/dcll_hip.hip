@@ -2043,12 +2043,22 @@ extern "C" int dcll_readout_splitk(const float *pv, const float *Wt, const float
 }
 
 // The readout of the whole-sequence path (rows = T x chunk of the batch): the LDS-staged 16x16x4 kernel, whole for K < 65536,
-// in EIGHT K-slices + k_readout_sum for longer rows (large planes) — chosen by K alone, never by the row count, so a row's
+// in 8 ... 64 K-slices + k_readout_sum for longer rows (large planes) — chosen by K alone, never by the row count, so a row's
 // logits do not depend on how a batch is chunked (dcll_readout / dcll_readout_splitk pick by row count: per-step calls).
 // act = DCLL_ACT_SIGMOID: pv holds v (dcll_layer_opts pv_presigmoid), the sigmoid is applied to the staged values.
+// K-slices of dcll_readout_act: 0 (unsplit) below 65536 columns, else 8 ... 64 slices of >= 8192 columns — by K alone.  (Round
+// 4: always eight left the 128x128 plane, K = 524288 and rows = T x 64, with 512 workgroups of 65536 columns each — two per
+// CU, 3.9 TB/s; 64 slices are 4096 workgroups.)
+static int act_nslice(int32_t K)
+{
+    if (K < 65536 || K % 256 != 0) return 0;
+    int n = 8;
+    while (n < 64 && K / (2 * n) >= 8192 && K % (2 * n * RO_KC) == 0) n *= 2;
+    return n;
+}
 extern "C" int64_t dcll_readout_act_scratch(int64_t rows, int32_t K, int32_t N)
 {
-    return (rows > 0 && N > 0 && K >= 65536 && K % 256 == 0) ? 8 * rows * N : 0;
+    return (rows > 0 && N > 0) ? (int64_t)act_nslice(K) * rows * N : 0;
 }
 
 extern "C" int dcll_readout_act(const float *pv, const float *Wt, const float *bias, float *out, float *scratch,
@@ -2064,9 +2074,10 @@ extern "C" int dcll_readout_act(const float *pv, const float *Wt, const float *b
     if (need == 0) return dcll_launch_readout_t16(pv, Wt, bias, out, rows, K, N, 0, st, act);
     if (!scratch || scratch_floats < need)
         return fail(DCLL_ERR_INVALID, "dcll_readout_act: K >= 65536 is split over K and needs scratch (dcll_readout_act_scratch)");
-    int rc = dcll_launch_readout_t16(pv, Wt, nullptr, scratch, rows, K, N, K / 8, st, act);
+    const int ns = act_nslice(K);
+    int rc = dcll_launch_readout_t16(pv, Wt, nullptr, scratch, rows, K, N, K / ns, st, act);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_readout_sum, dim3(nblk(rows * N, 64)), dim3(256), 0, st, scratch, bias, out, rows * N, N, 8);
+    hipLaunchKernelGGL(k_readout_sum, dim3(nblk(rows * N, 64)), dim3(256), 0, st, scratch, bias, out, rows * N, N, ns);
     HIP_CHECK_LAUNCH("k_readout_sum");
     return DCLL_OK;
 }
