@@ -1011,9 +1011,20 @@ __global__ void k_argmax(const float *__restrict__ logits, int32_t *__restrict__
     const float *l = logits + i * N;
     int best = 0;
     float bv = l[0];
-    for (int n = 1; n < N; ++n) {
-        float v = l[n];
-        if (v > bv) { bv = v; best = n; }
+    if (N % 4 == 0 && ((uintptr_t)logits & 15) == 0) {
+        // rows of 16-byte multiples (N = 24): N / 4 loads of 16 bytes per thread instead of N of 4 — a wave's rows are 4 N
+        // bytes apart, so every scalar load touched every cache line of the wave's block (68 us for 50 MB at T x B = 524 288)
+        for (int n4 = 0; n4 < N; n4 += 4) {
+            const f32x4 q = *(const f32x4 *)(l + n4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (q[e] > bv) { bv = q[e]; best = n4 + e; }
+        }
+    } else {
+        for (int n = 1; n < N; ++n) {
+            float v = l[n];
+            if (v > bv) { bv = v; best = n; }
+        }
     }
     clout[i] = best;
 }
@@ -1027,9 +1038,13 @@ __global__ __launch_bounds__(64) void k_vote(const int32_t *__restrict__ clout, 
     const int b = blockIdx.x * 64 + threadIdx.x;
     for (int n = 0; n < N; ++n) { cnt[n * 64 + threadIdx.x] = 0; first[n * 64 + threadIdx.x] = T; }
     if (b >= B) return;
-    for (int t = t_begin; t < T; ++t) {
-        int c = clout[(long)t * B + b];
-        if (cnt[c * 64 + threadIdx.x]++ == 0) first[c * 64 + threadIdx.x] = t;
+    for (int t0 = t_begin; t0 < T; t0 += 16) {        // sixteen recorded steps requested at once: the loop is one thread per
+        int c[16];                                    // sample, 64 workgroups of one wave — nothing else hides a round trip
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = t0 + k < T ? clout[(long)(t0 + k) * B + b] : -1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (c[k] >= 0 && cnt[c[k] * 64 + threadIdx.x]++ == 0) first[c[k] * 64 + threadIdx.x] = t0 + k;
     }
     int best = -1, bc = 0, bf = 0;
     for (int n = 0; n < N; ++n) {
