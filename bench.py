@@ -138,6 +138,29 @@ def per_step_paths(dev, batch=512, steps=48, reps=3):
         out[name + "_wall_over_device"] = 1e3 * dt / max(min(devs), 1e-9)
         out[name + "_windows_per_s_at_T128"] = batch / (dt * T_STEPS)
     out["graph_decision"] = net.graph_decisions()
+    # the MFMA kernel the per-step forward spends its time in, alone: `.forward` of a 32 -> 32 layer without its readouts =
+    # one k_lif_step_c32 launch per call, launched back to back (106 us of device work per launch against ~10 us of host
+    # work: the HIP events bracket device time); frac = algorithmic FLOPs of the layer step / time / fp32-MFMA peak
+    i2h = net.dcll_slices[1].dclllayer.i2h
+    spikes = (torch.rand(batch, 32, R, R, device=dev) < 0.05).float()
+    obuf = {}                                   # reusable output maps: no allocation per call
+    best = float("inf")
+    for rep in range(4):                        # (the first repetitions also bring the clocks up: best of four)
+        for _ in range(20):
+            i2h._step(spikes, want_v=False, out=obuf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(60):
+            i2h._step(spikes, want_v=False, out=obuf)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = min(best, 1e3 * e0.elapsed_time(e1) / 60)
+    us = best
+    flop = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * batch
+    out["k_lif_step_c32"] = {"us_per_launch": us, "batch": batch, "TFLOPs": flop / us / 1e6,
+                             "frac_of_fp32_mfma_peak": flop / us / 1e6 / PEAK_FP32_MFMA_TFLOPS,
+                             "what": "one layer step of a 32->32 7x7 layer on the 16x16 plane (dcll_conv_lif_step without "
+                                     "readouts, s and pv written, state in HBM), 60 launches back to back, HIP events, best of 4"}
     return out
 
 
