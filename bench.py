@@ -62,17 +62,28 @@ def build_net(batch, device):
     return net, convs
 
 
-def _spin_calibration(dev):
-    """torch.cuda._sleep cycles per millisecond on this device (its clock is not the shader clock everywhere)."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda._sleep(1000)
-    torch.cuda.synchronize(dev)
-    n = 20_000_000
-    e0.record()
-    torch.cuda._sleep(n)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return n / max(e0.elapsed_time(e1), 1e-3)
+class _BusyBlocker:
+    """Keeps the stream busy for a given time with matrix products (so that the host can enqueue a whole loop behind it).
+    Not torch.cuda._sleep: while the device idles in a spin kernel its clocks come down, and the launches timed right
+    behind it read 10-15 % slow (experiments/step_data_dependence.py)."""
+
+    def __init__(self, dev):
+        self.a = torch.randn(4096, 4096, device=dev)
+        self.b = torch.randn(4096, 4096, device=dev)
+        self.c = torch.empty(4096, 4096, device=dev)
+        for _ in range(3):
+            torch.mm(self.a, self.b, out=self.c)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            torch.mm(self.a, self.b, out=self.c)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        self.ms_per_mm = max(e0.elapsed_time(e1) / 10, 1e-3)
+
+    def block(self, ms):
+        for _ in range(int(ms / self.ms_per_mm) + 1):
+            torch.mm(self.a, self.b, out=self.c)
 
 
 def per_step_paths(dev, batch=512, steps=48, reps=3):
@@ -82,9 +93,9 @@ def per_step_paths(dev, batch=512, steps=48, reps=3):
     burn-in / warm-up, best of `reps` repetitions.  Two clocks per path, so that the record can tell a slow HOST from a
     slow DEVICE:
       wall_ms    host wall clock around the loop (+ a final synchronize): what a user of the loop sees;
-      device_ms  HIP-event time of the same launches executing BACK TO BACK: the stream is first blocked by a spin kernel
-                 for about the wall time of the loop, the host enqueues all `steps` timesteps behind it, and the events
-                 around them then bracket pure device work (no launch gaps).
+      device_ms  HIP-event time of the same launches executing BACK TO BACK: the stream is first kept busy (matrix products,
+                 _BusyBlocker) for about the wall time of the loop, the host enqueues all `steps` timesteps behind them, and
+                 the events around them then bracket pure device work (no launch gaps).
     wall_ms / device_ms ~ 1: the device sets the pace; >> 1: the host's launch path does (then hipGraph replays help —
     ConvNetwork decides that by measurement per geometry, `graph_decision`)."""
     convs = load_network_spec(os.path.join(ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
@@ -102,7 +113,7 @@ def per_step_paths(dev, batch=512, steps=48, reps=3):
     x = x.reshape(n, batch, 1, R, R)
     y = torch.zeros(batch, N_CLASSES, device=dev)
     y[torch.arange(batch), torch.randint(0, N_CLASSES, (batch,))] = 1
-    cyc_per_ms = _spin_calibration(dev)
+    blocker = _BusyBlocker(dev)
     out = {"batch": batch, "timesteps_timed": steps, "repetitions": reps}
     # A full pass of CPython's cyclic collector over this process's heap (~265 k tracked objects, most of them torch's
     # import-time ones) takes ~100 ms: landing in a 48-timestep window it reads as +2 ms per timestep (round-3 driver run:
@@ -123,7 +134,7 @@ def per_step_paths(dev, batch=512, steps=48, reps=3):
             walls.append((time.perf_counter() - t0) / steps)
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda._sleep(int(1.15 * min(walls) * steps * 1e3 * cyc_per_ms))     # the host gets ahead of the device
+            blocker.block(1.15 * min(walls) * steps * 1e3)                  # the host gets ahead of the device
             e0.record()
             for t in range(warm, n):
                 fn(t)
