@@ -731,7 +731,7 @@ def main():
             try:
                 net._seq_buffers.clear()
                 torch.cuda.empty_cache()
-                out["batch_sweep"] = [sweep_point(dev, b_) for b_ in (512, 8192)]
+                out["batch_sweep"] = [sweep_point(dev, b_, steps=8 if b_ <= 512 else 3, warmup=4 if b_ <= 512 else 1) for b_ in (512, 8192)]
                 log("batch sweep done: %s" % [(r_["batch"], round(r_["value"])) for r_ in out["batch_sweep"]])
             except Exception as e:                  # noqa: BLE001
                 out["batch_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
