@@ -147,7 +147,7 @@ def per_step_paths(dev, batch=512, steps=48, reps=3):
         out[name + "_device_ms_per_timestep"] = min(devs)
         out[name + "_device_ms_per_timestep_all"] = devs
         out[name + "_wall_over_device"] = 1e3 * dt / max(min(devs), 1e-9)
-        out[name + "_windows_per_s_at_T128"] = batch / (dt * T_STEPS)
+        out[name + "_windows_per_s_at_T128"] = batch / (dt * 128)
     out["graph_decision"] = net.graph_decisions()
     # the MFMA kernel the per-step forward spends its time in, alone: `.forward` of a 32 -> 32 layer without its readouts =
     # one k_lif_step_c32 launch per call, launched back to back (106 us of device work per launch against ~10 us of host
@@ -313,21 +313,25 @@ def bench_ref_network(a):
         dist.destroy_process_group()
 
 
-def sweep_point(dev, B, steps=3, warmup=1):
-    """One more batch size of the headline workload (BASELINE configs 2 and 3: batch 512 / 8192 on one MI355X): the same
-    step as main()'s on a network of its own — value, ms per step and the roofline fraction of the hot kernel from the
-    HIP events of its launches.  A batch above the pv budget runs in chunks (8192 = 6144 + 2048)."""
+def sweep_point(dev, B, steps=3, warmup=1, T=None):
+    """One more batch size of the headline workload (BASELINE configs 2 and 3: batch 512 / 8192 on one MI355X) — or, with
+    T, another sequence length (T = 1024 = the reference's n_iters default and script setting, train.py:63-66,
+    scripts/test_radio_ml.sh:17-18; windows of max(128, T) samples): the same step as main()'s on a network of its own —
+    value, ms per step and the roofline fraction of the hot kernel from the HIP events of its launches.  A batch above
+    the pv budget runs in chunks (8192 = 6144 + 2048)."""
+    T = T_STEPS if T is None else T
+    L = max(L_IQ, T)
     net, _ = build_net(B, dev)
     enc = IQEncoder(R, R, device=dev)
     g = torch.Generator().manual_seed(11)
-    iq = (0.4 * torch.randn(B, 2, L_IQ, generator=g)).to(dev)
+    iq = (0.4 * torch.randn(B, 2, L, generator=g)).to(dev)
     labels = torch.randint(0, N_CLASSES, (B,), generator=g).to(dev)
     prof = {}
 
     def step(profile=None):
         net.zero_states()
         net.reset()
-        res = net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False, profile=profile)
+        res = net.test_sequence(iq=iq, encoder=enc, T=T, t0=0, collect=False, profile=profile)
         return parallel.tallies(res["vote"], labels, N_CLASSES)
 
     for _ in range(warmup):
@@ -339,10 +343,10 @@ def sweep_point(dev, B, steps=3, warmup=1):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     c32_ms = [s_.elapsed_time(e_) for s_, e_ in prof.get("lif_c32", [])]
-    flop = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T_STEPS * B * 2 * steps          # both 32->32 layers, all steps
+    flop = FLOP_C32_PER_SAMPLE_STEP_PIXEL * R * R * T * B * 2 * steps          # both 32->32 layers, all steps
     ach = flop / (sum(c32_ms) / 1e3) / 1e12 if c32_ms else float("nan")
-    rec = {"batch": B, "value": B * steps / dt, "unit": "IQ windows/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": 1e3 * dt / steps,
+    rec = {"batch": B, "T": T, "value": B * steps / dt, "unit": "IQ windows/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps, "timesteps_per_s": B * T * steps / dt,
            "roofline": {"kernel": "k_lif_seq_c32d" if R == 16 else "k_lif_seq_c32t", "bound": "mfma", "achieved": ach,
                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                         "launches": len(c32_ms), "launch_ms_total_per_step": sum(c32_ms) / steps},
@@ -393,7 +397,7 @@ def live_hbm_traffic(extra_args, kernel_prefix, timeout=300):
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__)] + list(extra_args) + [
                    "--steps", "1", "--warmup", "0", "--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--batch-sweep", "0",
-                   "--trained", "0", "--live-traffic", "0"]
+                   "--trained", "0", "--live-traffic", "0", "--t1024", "0"]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
                                                                       "MASTER_ADDR", "MASTER_PORT", "DCLL_FORCE_DIST")}
             env["TMPDIR"] = "/tmp"
@@ -503,6 +507,11 @@ def main():
                          "every rank runs its contiguous shard of G / N windows and the JSON line says \"scaling\": "
                          "\"strong\".  Default: weak scaling with --batch windows per GPU")
     ap.add_argument("--plane", type=int, default=16, help="I/Q plane resolution R (R x R cells): 16 or a multiple of 32")
+    ap.add_argument("--steps-T", type=int, default=128, dest="steps_T",
+                    help="timesteps per window T (IQ windows of max(128, T) samples).  128 = BASELINE's metric; 1024 = the "
+                         "reference's n_iters default and script setting (train.py:63-66, scripts/test_radio_ml.sh:17-18)")
+    ap.add_argument("--t1024", type=int, default=1,
+                    help="1 (default, N=1 headline run only): also run T = 1024 at batch 512 (2 steps) and report it as `t1024`")
     ap.add_argument("--batch-sweep", type=int, default=1,
                     help="1 (default, N=1 headline run only): also run BASELINE configs 2 and 3 (batch 512 and 8192, 3 steps "
                          "each) and report them as `batch_sweep`")
@@ -538,8 +547,9 @@ def main():
         sys.exit(parallel.spawn_local_ranks(a.gpus))
     if a.network == "ref":
         return bench_ref_network(a)
-    global R
+    global R, T_STEPS, L_IQ
     R = a.plane
+    T_STEPS, L_IQ = a.steps_T, max(128, a.steps_T)
     if a.batch is None:
         a.batch = 4096 if R == 16 else 64
     if a.cpu_windows is None:
@@ -561,9 +571,20 @@ def main():
 
     net, convs = build_net(B, dev)
     enc = IQEncoder(R, R, device=dev)
-    g = torch.Generator().manual_seed(1 + rank)          # every rank its own shard of the synthetic batch
-    iq = (0.4 * torch.randn(B, 2, L_IQ, generator=g)).to(dev)
-    labels = torch.randint(0, N_CLASSES, (B,), generator=g).to(dev)
+    shard = None
+    if strong:
+        # a FIXED global batch: the same windows whatever the rank count, every rank takes its contiguous slice — the
+        # all-reduced tallies of an N-rank run then equal the single-process run's (tests/test_gpu_multirank.py)
+        g = torch.Generator().manual_seed(1)
+        iq_all = 0.4 * torch.randn(a.global_batch, 2, L_IQ, generator=g)
+        labels_all = torch.randint(0, N_CLASSES, (a.global_batch,), generator=g)
+        iq, labels = iq_all[lo:hi].contiguous().to(dev), labels_all[lo:hi].contiguous().to(dev)
+        shard = (lo, a.global_batch)        # (the quantiser treats a sample as the reference would at ITS batch position)
+        del iq_all, labels_all
+    else:
+        g = torch.Generator().manual_seed(1 + rank)          # weak scaling: every rank its own synthetic batch
+        iq = (0.4 * torch.randn(B, 2, L_IQ, generator=g)).to(dev)
+        labels = torch.randint(0, N_CLASSES, (B,), generator=g).to(dev)
     prof = {}
 
     def step(profile=None):
@@ -572,9 +593,19 @@ def main():
         net.reset()
         res = net.test_sequence(iq=iq, encoder=enc, T=T_STEPS, t0=0, collect=False, profile=profile,
                                 fuse_readout=bool(a.fuse_readout), output_only=bool(a.output_only),
-                                overlap_readout=None if a.overlap_readout is None else bool(a.overlap_readout))
+                                overlap_readout=None if a.overlap_readout is None else bool(a.overlap_readout), shard=shard)
         votes = [v if v is not None else res["vote"][-1] for v in res["vote"]]      # output_only: hidden layers have none
-        tal = parallel.allreduce_tallies(parallel.tallies(votes, labels, N_CLASSES))
+        tal = parallel.tallies(votes, labels, N_CLASSES)
+        if profile is not None and parallel.is_distributed():
+            # the step's only collective, bracketed by events on the launch stream (the backend's own stream is joined to it
+            # before the call returns): a sub-6x scaling result can then name the collective — or rule it out
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tal = parallel.allreduce_tallies(tal)
+            e1.record()
+            profile.setdefault("allreduce", []).append((e0, e1))
+        else:
+            tal = parallel.allreduce_tallies(tal)
         return res, tal
 
     def fence():
@@ -614,10 +645,30 @@ def main():
         step_upload()
     fence()
     dt_up = time.perf_counter() - t0
+    multi = None
     if parallel.is_distributed():
-        tmax = torch.tensor([dt, dt_up], device=dev, dtype=torch.float64)
+        # max over ranks = the job's time (contract); min / max of the ranks' own clocks, of the device time of their layer
+        # kernels and of the collective say WHERE a scaling loss comes from: a straggler rank (per_rank spread), the
+        # collective (allreduce_ms_per_step), or the host (wall >> device_busy on every rank)
+        ar_ms = float(np.sum([s_.elapsed_time(e_) for s_, e_ in prof.get("allreduce", [])])) / max(1, a.steps)
+        busy_ms = float(np.sum([s_.elapsed_time(e_) for k_, v_ in prof.items() if k_ != "allreduce" for s_, e_ in v_])) / max(1, a.steps)
+        own = 1e3 * dt / a.steps
+        tmax = torch.tensor([dt, dt_up, -own, own, -ar_ms, ar_ms, -busy_ms, busy_ms], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
         dt, dt_up = float(tmax[0].item()), float(tmax[1].item())
+        multi = {"per_rank_ms_per_step": {"min": -float(tmax[2]), "max": float(tmax[3]), "this_rank0": own},
+                 "allreduce_ms_per_step": {"min": -float(tmax[4]), "max": float(tmax[5]),
+                                           "what": "HIP events around the tally all-reduce (the step's only collective), per step"},
+                 "device_busy_ms_per_step": {"min": -float(tmax[6]), "max": float(tmax[7]),
+                                             "what": "sum of the HIP-event times of a rank's layer kernels, readouts and votes per step"},
+                 "ranks_seen": dist.get_world_size(), "backend": dist.get_backend()}
+        try:
+            ids = [None] * dist.get_world_size()
+            dist.all_gather_object(ids, "%s/cuda:%d/%s" % (os.uname().nodename, dev.index, parallel.device_identity(dev.index)))
+            multi["rank_devices"] = ids
+            multi["distinct_devices"] = len(set(ids))
+        except Exception as e:                      # noqa: BLE001  (diagnostics must never cost the line)
+            multi["rank_devices"] = "%s: %s" % (type(e).__name__, e)
     log("upload-inclusive region done: %.3f s for %d steps" % (dt_up, a.steps))
 
     # dominant kernel: HIP-event time of every k_lif_seq_c32d launch of the timed region (same stream as the launch)
@@ -630,8 +681,8 @@ def main():
     # the separate `rocprofv3 --pmc` passes of this same command (profiles/r04_pmc_b4096.json; collect_r04.sh) is used
     # when the batch matches, else null.
     traffic, traffic_src = None, None
-    for name in (["r%02d_pmc_b%d.json" % (r_, B) for r_ in (4, 3, 2, 1)] if R == 16 else
-                 ["r%02d_pmc_plane%d_b%d.json" % (r_, R, B) for r_ in (4, 3, 2, 1)]):
+    for name in ([] if T_STEPS != 128 else ["r%02d_pmc_b%d.json" % (r_, B) for r_ in (5, 4, 3, 2, 1)] if R == 16 else
+                 ["r%02d_pmc_plane%d_b%d.json" % (r_, R, B) for r_ in (5, 4, 3, 2, 1)]):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
@@ -647,7 +698,7 @@ def main():
             continue
     if rank == 0 and world == 1 and a.live_traffic:
         t_pm = time.perf_counter()
-        live, how = live_hbm_traffic(["--batch", str(B), "--plane", str(R)], hot_kernel)
+        live, how = live_hbm_traffic(["--batch", str(B), "--plane", str(R), "--steps-T", str(T_STEPS)], hot_kernel)
         log("live HBM traffic of %s: %s (%s; %.0f s)" % (hot_kernel, live, how[:60], time.perf_counter() - t_pm))
         if live is not None:
             if traffic is not None:
@@ -663,18 +714,18 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "IQ windows/sec (RadioML 2x128, T=128)", "value": total_windows * a.steps / dt,
+            "metric": "IQ windows/sec (RadioML 2x%d, T=%d)" % (L_IQ, T_STEPS), "value": total_windows * a.steps / dt,
             "unit": "IQ windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "radio_ml_conv.yaml, %dx%d I/Q plane, T=128, arp=1.0, random_tau, %s%s, "
-                                   "synthetic IQ 0.4*randn(B,2,128), seeded init" %
-                                   (R, R, ("global batch %d sharded over %d GPU(s) (strong scaling)" % (total_windows, world))
+            "config": {"workload": "radio_ml_conv.yaml, %dx%d I/Q plane, T=%d, arp=1.0, random_tau, %s%s, "
+                                   "synthetic IQ 0.4*randn(B,2,%d), seeded init" %
+                                   (R, R, T_STEPS, ("global batch %d sharded over %d GPU(s) (strong scaling)" % (total_windows, world))
                                     if strong else ("batch %d per GPU" % B),
                                     (" (north_star headline batch)" if ((total_windows if strong else B) == 4096 and R == 16)
                                      else "") +
-                                    (", OUTPUT-ONLY serving mode (hidden-layer readouts skipped)" if a.output_only else "")),
+                                    (", OUTPUT-ONLY serving mode (hidden-layer readouts skipped)" if a.output_only else ""), L_IQ),
                        "batch_per_gpu": B, "global_batch": total_windows, "T": T_STEPS, "plane": [R, R],
                        "parallelism": "batch shards, %d rank(s) on %d GPU(s)%s, tally all-reduce only (backend %s)" %
                                       (world, min(world, torch.cuda.device_count()),
@@ -699,10 +750,13 @@ def main():
                                  "frac": (traffic / avg_c32_s / 1e9 / PEAK_HBM_GBS) if traffic else None}},
             "kernel_ms_per_launch": kernel_ms,
             "vote_accuracy_vs_random_labels": [float(x) for x in acc.cpu()],
+            # the all-reduced tallies of the last step: (correct, total) per layer and a digest of the confusion matrices
+            "tallies": {"correct_total": [[int(v) for v in row] for row in tal[:, -2:].cpu()],
+                        "confusion_sha1": __import__("hashlib").sha1(cm.cpu().numpy().astype(np.int64).tobytes()).hexdigest()},
             "value_incl_upload": total_windows * a.steps / dt_up,
             "ms_per_step_incl_upload": 1e3 * dt_up / a.steps,
-            "upload": "raw IQ (B,2,128) fp32 = %d bytes per step per GPU, pinned host memory -> HBM on the launch stream, in "
-                      "front of every step; `value` is the device-resident form" % (B * 2 * L_IQ * 4),
+            "upload": "raw IQ (B,2,%d) fp32 = %d bytes per step per GPU, pinned host memory -> HBM on the launch stream, in "
+                      "front of every step; `value` is the device-resident form" % (L_IQ, B * 2 * L_IQ * 4),
         }
         # the HBM-bound kernels around the hot one (north_star: achieved HBM GB/s of the LIF-update kernel against the
         # roofline): bytes they must move by this design (pv written once by the first layer's kernel, read once by a
@@ -721,12 +775,24 @@ def main():
                 "bytes_per_launch": pv_bytes, "ms": kernel_ms["readout"], "GBps": pv_bytes / kernel_ms["readout"] / 1e6,
                 "frac_of_peak": pv_bytes / kernel_ms["readout"] / 1e6 / PEAK_HBM_GBS}
         out["hbm_bound_kernels"] = hb
-        if world == 1 and R == 16 and a.per_step:
+        if multi is not None:
+            out["multi_gpu"] = multi
+        if world == 1 and R == 16 and a.per_step and T_STEPS == 128:
             try:                                    # an extra, never at the price of the headline line
                 out["per_step_paths"] = per_step_paths(dev)
             except Exception as e:                  # noqa: BLE001
                 out["per_step_paths"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and R == 16 and a.batch_sweep and B == 4096:
+        head = world == 1 and R == 16 and B == 4096 and T_STEPS == 128        # the headline run: extras beside it
+        if head and a.t1024:
+            # the reference's own sequence length (n_iters = n_iters_test = 1024) at its scripts' batch 512
+            try:
+                net._seq_buffers.clear()
+                torch.cuda.empty_cache()
+                out["t1024"] = sweep_point(dev, 512, steps=2, warmup=1, T=1024)
+                log("T = 1024 at batch 512: %.0f windows/s, frac %.3f" % (out["t1024"]["value"], out["t1024"]["roofline"]["frac"]))
+            except Exception as e:                  # noqa: BLE001
+                out["t1024"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if head and a.batch_sweep:
             # BASELINE configs 2 and 3 beside the headline (never at its price)
             try:
                 net._seq_buffers.clear()
@@ -735,7 +801,7 @@ def main():
                 log("batch sweep done: %s" % [(r_["batch"], round(r_["value"])) for r_ in out["batch_sweep"]])
             except Exception as e:                  # noqa: BLE001
                 out["batch_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and R == 16 and a.config5 and B == 4096:
+        if head and a.config5:
             # BASELINE config 5 beside the headline (never at its price): its own network, 3 steps at batch 4096
             try:
                 net._seq_buffers.clear()            # the headline's pv / spike buffers: config 5 needs 137 GB of pv
@@ -751,7 +817,7 @@ def main():
                 if live is not None:
                     roof5["traffic"] = live * roof5["launches_per_step"]
                     roof5["traffic_source"] = how + "; x %g launches per step" % roof5["launches_per_step"]
-        if world == 1 and R == 16 and a.trained and a.cpu_windows > 0 and B == 4096:
+        if head and a.trained and a.cpu_windows > 0:
             try:
                 out["trained_top1"] = trained_top1(dev)
             except Exception as e:                  # noqa: BLE001

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCLL_ABI_VERSION 4
+#define DCLL_ABI_VERSION 5
 
 enum {
     DCLL_OK = 0,
@@ -113,6 +113,17 @@ typedef struct dcll_layer_opts {
 
 int dcll_version(void);                 /* DCLL_ABI_VERSION of the loaded library                        */
 const char *dcll_last_error(void);      /* thread-local message of the last failing call ("" if none)    */
+
+/*
+ * Which kernels did a call dispatch?  (ABI 5; diagnostics, host-side only.)  The reference has one code path per layer
+ * (F.conv2d, dcll/pytorch_libdcll.py:417,495); this library picks a kernel by geometry and batch, and a parity test is
+ * only worth its name if it ran the kernel it claims to cover.  dcll_kernel_trace(1) clears the calling thread's log
+ * and starts recording one line per kernel launch of that thread's calls; dcll_kernel_trace(0) stops.
+ * dcll_kernel_trace_read copies the log (newline-separated kernel names, NUL-terminated, truncated to cap) and returns
+ * the bytes needed for all of it; the log itself stops growing at 64 KiB (last line "...").
+ */
+int dcll_kernel_trace(int32_t enable);
+int64_t dcll_kernel_trace_read(char *buf, int64_t cap);
 
 /* Output spatial sizes of the conv and of the pooled map (get_output_shape :368-375, :593-597). */
 int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *conv_h, int32_t *conv_w, int32_t *pool_h, int32_t *pool_w);

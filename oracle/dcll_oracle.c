@@ -69,36 +69,45 @@ int dcll_oracle_conv_lif_step(const dcll_conv_desc *d, const float *x, const flo
     const int HP = H + 2 * d->pad_h, WP = Wd + 2 * d->pad_w;
     const int plane = H * Wd, cplane = ch * cw, pplane = ph * pw;
     const int pool_ph = (d->pool_h - 1) / 2, pool_pw = (d->pool_w - 1) / 2;
-    int rc = 0;
-#pragma omp parallel for schedule(static)
-    for (int bi = 0; bi < B; ++bi) {
-        float *pad = (float *)calloc((size_t)C * HP * WP, sizeof(float));
-        float *sfull = (float *)malloc((size_t)O * cplane * sizeof(float));
-        float *pvfull = (float *)malloc((size_t)O * cplane * sizeof(float));
-        float *pvp = (float *)malloc((size_t)O * pplane * sizeof(float));
-        if (!pad || !sfull || !pvfull || !pvp) { rc = DCLL_ERR_INVALID; goto done; }
-        /* traces (elementwise on the layer INPUT) */
+    /* Three phases, each parallel over independent work items (the arithmetic of every output is the chain above, in the
+     * order above, whatever the loop schedule): (1) traces per sample, (2) the conv chains per (sample, output channel)
+     * with the chains of one output ROW advanced together — `omp simd` over x: a lane is one output pixel's own chain, every
+     * step an exactly rounded fmaf, so vector and scalar execution give the same bits —, (3) pooling + readouts per sample. */
+    float *pad = (float *)calloc((size_t)B * C * HP * WP, sizeof(float));
+    float *sfull = (float *)malloc((size_t)B * O * cplane * sizeof(float));
+    float *pvfull = (float *)malloc((size_t)B * O * cplane * sizeof(float));
+    if (!pad || !sfull || !pvfull) { free(pad); free(sfull); free(pvfull); return DCLL_ERR_INVALID; }
+    /* (1) traces (elementwise on the layer INPUT) */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < B; ++bi)
         for (int ci = 0; ci < C; ++ci)
             for (int i = 0; i < plane; ++i) {
                 size_t g = ((size_t)bi * C + ci) * plane + i;
                 size_t tq = d->tau_is_tensor ? (size_t)ci * plane + i : 0;
                 trace_update(x[g], alpha[tq], tau_m[tq], alphas[tq], tau_s[tq], &eps0[g], &eps1[g]);
-                pad[((size_t)ci * HP + (i / Wd + d->pad_h)) * WP + (i % Wd + d->pad_w)] = eps1[g];
+                pad[(((size_t)bi * C + ci) * HP + (i / Wd + d->pad_h)) * WP + (i % Wd + d->pad_w)] = eps1[g];
             }
-        /* conv as the pinned fmaf chain + refractory + threshold */
-        for (int co = 0; co < O; ++co)
-            for (int y = 0; y < ch; ++y)
+    /* (2) conv as the pinned fmaf chain + refractory + threshold */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < B; ++bi)
+        for (int co = 0; co < O; ++co) {
+            float accrow[cw];
+            const float *padb = pad + (size_t)bi * C * HP * WP;
+            for (int y = 0; y < ch; ++y) {
+                for (int xx = 0; xx < cw; ++xx) accrow[xx] = b ? b[co] : 0.0f;
+                for (int cp = 0; cp < (C + 1) / 2; ++cp)
+                    for (int ky = 0; ky < KH; ++ky)
+                        for (int kx = 0; kx < KW; ++kx)
+                            for (int hh = 0; hh < 2; ++hh) {
+                                int ci = 2 * cp + hh;
+                                if (ci >= C) continue;
+                                const float *row = padb + ((size_t)ci * HP + (y + ky)) * WP + kx;
+                                const float w = W[(((size_t)co * C + ci) * KH + ky) * KW + kx];
+#pragma omp simd
+                                for (int xx = 0; xx < cw; ++xx) accrow[xx] = fmaf(row[xx], w, accrow[xx]);
+                            }
                 for (int xx = 0; xx < cw; ++xx) {
-                    float acc = b ? b[co] : 0.0f;
-                    for (int cp = 0; cp < (C + 1) / 2; ++cp)
-                        for (int ky = 0; ky < KH; ++ky)
-                            for (int kx = 0; kx < KW; ++kx)
-                                for (int hh = 0; hh < 2; ++hh) {
-                                    int ci = 2 * cp + hh;
-                                    if (ci >= C) continue;
-                                    acc = fmaf(pad[((size_t)ci * HP + (y + ky)) * WP + (xx + kx)],
-                                               W[(((size_t)co * C + ci) * KH + ky) * KW + kx], acc);
-                                }
+                    const float acc = accrow[xx];
                     size_t og = ((size_t)bi * O + co) * cplane + (size_t)y * cw + xx;
                     float v = acc, s;
                     if (d->refractory) {
@@ -111,9 +120,18 @@ int dcll_oracle_conv_lif_step(const dcll_conv_desc *d, const float *x, const flo
                         s = v > 0.0f ? 1.0f : 0.0f;                   /* :420 */
                     }
                     if (out_v) out_v[og] = v;
-                    sfull[(size_t)co * cplane + y * cw + xx] = s;
-                    pvfull[(size_t)co * cplane + y * cw + xx] = sigmoidf_(v);   /* :500 / :419 */
+                    sfull[og] = s;
+                    pvfull[og] = sigmoidf_(v);                        /* :500 / :419 */
                 }
+            }
+        }
+    int rc = 0;
+    /* (3) max-pool + readouts */
+#pragma omp parallel for schedule(static)
+    for (int bi = 0; bi < B; ++bi) {
+        float *pvp = (float *)malloc((size_t)O * pplane * sizeof(float));
+        if (!pvp) { rc = DCLL_ERR_INVALID; continue; }
+        const float *sfb = sfull + (size_t)bi * O * cplane, *pvb = pvfull + (size_t)bi * O * cplane;
         /* max-pool (kernel=stride=pool, pad (pool-1)/2 with -inf) :601 */
         for (int co = 0; co < O; ++co)
             for (int py = 0; py < ph; ++py)
@@ -123,8 +141,8 @@ int dcll_oracle_conv_lif_step(const dcll_conv_desc *d, const float *x, const flo
                         for (int dx = 0; dx < d->pool_w; ++dx) {
                             int yy = py * d->pool_h - pool_ph + dy, xq = px * d->pool_w - pool_pw + dx;
                             if (yy < 0 || yy >= ch || xq < 0 || xq >= cw) continue;
-                            float a = sfull[(size_t)co * cplane + yy * cw + xq];
-                            float q = pvfull[(size_t)co * cplane + yy * cw + xq];
+                            float a = sfb[(size_t)co * cplane + yy * cw + xq];
+                            float q = pvb[(size_t)co * cplane + yy * cw + xq];
                             if (a > ms) ms = a;
                             if (q > mp) mp = q;
                         }
@@ -147,9 +165,9 @@ int dcll_oracle_conv_lif_step(const dcll_conv_desc *d, const float *x, const flo
                 }
             }
         }
-    done:
-        free(pad); free(sfull); free(pvfull); free(pvp);
+        free(pvp);
     }
+    free(pad); free(sfull); free(pvfull);
     return rc;
 }
 

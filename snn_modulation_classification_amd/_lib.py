@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_PKG, "libdcll_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class DCLLHipError(RuntimeError):
@@ -72,6 +72,8 @@ _OP = ctypes.POINTER(LayerOpts)
 SIGNATURES = {
     "dcll_version": (_I32, []),
     "dcll_last_error": (ctypes.c_char_p, []),
+    "dcll_kernel_trace": (_I32, [_I32]),
+    "dcll_kernel_trace_read": (_I64, [ctypes.c_char_p, _I64]),
     "dcll_conv_out_shape": (_I32, [_DP, _IP, _IP, _IP, _IP]),
     "dcll_conv_lif_step": (_I32, [_DP] + [_P] * 20 + [_OP, _I32, _P]),
     "dcll_conv_lif_backward": (_I32, [_DP] + [_P] * 13 + [_I64, _I32, _P]),

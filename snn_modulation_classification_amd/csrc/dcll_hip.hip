@@ -43,6 +43,55 @@ char *dcll_err_buf(void) { return g_err; }
 extern "C" int dcll_version(void) { return DCLL_ABI_VERSION; }
 extern "C" const char *dcll_last_error(void) { return g_err; }
 
+// dcll_kernel_trace: which kernels did this thread's calls dispatch?  Host-side bookkeeping only (a name per launch
+// check, newline separated, while recording); the log stops growing at DCLL_TRACE_LEN and says so ("...").
+constexpr size_t DCLL_TRACE_LEN = 1 << 16;
+static thread_local bool g_trace_on = false;
+static thread_local size_t g_trace_len = 0;
+static thread_local char *g_trace = nullptr;
+void dcll_trace_note(const char *name)
+{
+    if (!g_trace_on || !g_trace) return;
+    const size_t n = strlen(name);
+    if (g_trace_len + n + 5 >= DCLL_TRACE_LEN) {
+        if (g_trace_len + 4 < DCLL_TRACE_LEN && (g_trace_len < 4 || memcmp(g_trace + g_trace_len - 4, "...\n", 4) != 0)) {
+            memcpy(g_trace + g_trace_len, "...\n", 4);
+            g_trace_len += 4;
+        }
+        return;
+    }
+    memcpy(g_trace + g_trace_len, name, n);
+    g_trace[g_trace_len + n] = '\n';
+    g_trace_len += n + 1;
+}
+extern "C" int dcll_kernel_trace(int32_t enable)
+{
+    if (enable) {
+        if (!g_trace) g_trace = (char *)malloc(DCLL_TRACE_LEN);
+        if (!g_trace) return fail(DCLL_ERR_INVALID, "dcll_kernel_trace: out of host memory");
+        g_trace_len = 0;
+    }
+    g_trace_on = enable != 0;
+    return DCLL_OK;
+}
+extern "C" int64_t dcll_kernel_trace_read(char *buf, int64_t cap)
+{
+    if (buf && cap > 0) {
+        const size_t n = g_trace_len < (size_t)(cap - 1) ? g_trace_len : (size_t)(cap - 1);
+        if (n) memcpy(buf, g_trace, n);
+        buf[n] = 0;
+    }
+    return (int64_t)g_trace_len + 1;
+}
+
+// dcll_conv_lif_step on the 16x16 plane: batches up to this many samples run two workgroups per sample (8-row tiles of
+// k_lif_step_c32t), larger ones k_lif_step_c32.  DCLL_SPLIT16_MAX_BATCH moves the switch (tests: both forms on one batch).
+static inline int split16_max_batch(void)
+{
+    const char *e = getenv("DCLL_SPLIT16_MAX_BATCH");
+    return e && *e ? atoi(e) : 256;
+}
+
 static inline void conv_shape(const dcll_conv_desc *d, int *ch, int *cw, int *ph, int *pw)
 {
     *ch = d->h + 2 * d->pad_h - d->kh + 1;
@@ -2700,7 +2749,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const bool k7 = d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b;
     const bool plane16 = d->h == 16 && d->w == 16 && k7;
     // (16x16 plane: two workgroups per sample — 8-row tiles — when the batch alone would leave half the CUs idle)
-    const bool split16 = plane16 && B <= 256;
+    const bool split16 = plane16 && B <= split16_max_batch();
     const bool ptr16 = ((((uintptr_t)x | (uintptr_t)eps0 | (uintptr_t)eps1) & 15) == 0) &&
                        (!d->tau_is_tensor || (((uintptr_t)alpha | (uintptr_t)tau_m | (uintptr_t)alphas | (uintptr_t)tau_s) & 15) == 0);
     const bool c1t = d->c_in == 1 && d->c_out <= 32 && k7 && !plane16;
@@ -2731,7 +2780,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
         }
 #undef DCLL_STEP_T
 #undef DCLL_STEP_TQ
-        HIP_CHECK_LAUNCH("k_lif_step_c32t / k_lif_step_c1 (tiled)");
+        HIP_CHECK_LAUNCH(c1t ? "k_lif_step_c1 (tiled)" : split16 ? "k_lif_step_c32t (8-row tiles)" : "k_lif_step_c32t");
         if (i2o_W && out_p) {
             rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
             if (rc) return rc;
@@ -2761,7 +2810,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
             else { if (W.q) DCLL_STEP_16(false, true); else DCLL_STEP_16(false, false); }
 #undef DCLL_STEP_16
         }
-        HIP_CHECK_LAUNCH("k_lif_step_c32 / k_lif_step_c1");
+        HIP_CHECK_LAUNCH(d->c_in == 1 ? "k_lif_step_c1" : "k_lif_step_c32");
         if (i2o_W && out_p) {
             rc = launch_readout(out_pv, i2o_W, i2o_b, out_p, B, K, d->target, st);
             if (rc) return rc;

@@ -6,6 +6,7 @@
 #include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/dcll_hip.h"
@@ -32,8 +33,12 @@ static inline int fail(int code, const char *msg, const char *who = nullptr)
     return code;
 }
 
+// dcll_kernel_trace (ABI 5): while a thread records, every launch check notes the kernel's name (dcll_hip.hip)
+__attribute__((visibility("hidden"))) void dcll_trace_note(const char *name);
+
 #define HIP_CHECK_LAUNCH(name)                                                              \
     do {                                                                                    \
+        dcll_trace_note(name);                                                              \
         hipError_t e_ = hipGetLastError();                                                  \
         if (e_ != hipSuccess) {                                                             \
             snprintf(dcll_err_buf(), DCLL_ERR_LEN, "%s: %s", name, hipGetErrorString(e_));  \

@@ -686,3 +686,27 @@ def cells_to_planes(cells, hw):
     check(_lib.get().dcll_cells_to_planes(ptr(cells), ptr(planes), cells.numel(), int(hw), stream_ptr()),
           "dcll_cells_to_planes")
     return planes
+
+
+class kernel_trace:
+    """`with ops.kernel_trace() as tr: ...; tr.names` — the kernels the calls inside dispatched, in launch order
+    (dcll_kernel_trace, ABI 5; this thread's calls only).  Diagnostics for tests and profiles: the library picks a kernel
+    by geometry and batch, and this says which one a call took."""
+
+    def __enter__(self):
+        self.names = []
+        _lib.check(_lib.get().dcll_kernel_trace(1), "dcll_kernel_trace")
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        lib = _lib.get()
+        lib.dcll_kernel_trace(0)
+        need = int(lib.dcll_kernel_trace_read(None, 0))
+        buf = ctypes.create_string_buffer(need)
+        lib.dcll_kernel_trace_read(buf, need)
+        self.names = [n for n in buf.value.decode("ascii", "replace").split("\n") if n]
+        return False
+
+    def count(self, name):
+        return sum(1 for n in self.names if n == name)

@@ -43,6 +43,50 @@ def local_device(local_rank):
     return local_rank % n if n > 0 else 0
 
 
+def device_identity(index):
+    """Something that names the PHYSICAL device behind cuda:<index> of this process (two processes that see the same GPU
+    through different *_VISIBLE_DEVICES masks get the same string): the device's uuid, else its PCI address, else None."""
+    if os.environ.get("DCLL_FAKE_DEVICE_ID"):          # (tests of the shared-device refusal on a box without GPUs)
+        return os.environ["DCLL_FAKE_DEVICE_ID"]
+    try:
+        p = torch.cuda.get_device_properties(index)
+    except Exception:                                   # noqa: BLE001
+        return None
+    u = getattr(p, "uuid", None)
+    if u is not None:
+        return str(u)
+    pci = tuple(getattr(p, n, None) for n in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return None if any(v is None for v in pci) else "pci-%04x:%02x:%02x" % pci
+
+
+def ranks_sharing_a_device(identities):
+    """identities: per rank (hostname, device identity or None).  -> sorted ranks that share a physical device with another
+    rank (identities of None are unknown and never counted)."""
+    seen = {}
+    for r, ident in enumerate(identities):
+        if ident is not None and ident[1] is not None:
+            seen.setdefault(tuple(ident), []).append(r)
+    return sorted(r for rs in seen.values() if len(rs) > 1 for r in rs)
+
+
+def _refuse_shared_devices(rank, world, device_index):
+    """RCCL hangs in its rendezvous when two ranks sit on one physical device.  A *_VISIBLE_DEVICES mask hides that from
+    device_count(): a per-rank mask (every rank sees ONE device, each a different one) is fine, a job-wide mask such as
+    HIP_VISIBLE_DEVICES=0 under torchrun maps every rank to the same GPU.  The ranks therefore compare what is behind
+    their device in a short gloo pre-rendezvous (host name + device uuid / PCI address) before RCCL is touched; any two
+    ranks on one device end the job with a message instead of a hang."""
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        ids = [None] * world
+        dist.all_gather_object(ids, (socket.gethostname(), device_identity(device_index)))
+    finally:
+        dist.destroy_process_group()
+    shared = ranks_sharing_a_device(ids)
+    if shared:
+        sys.exit("rank %d: ranks %s share a physical GPU (%s) — RCCL cannot run several ranks on one device; give every "
+                 "rank its own GPU, or set DCLL_DIST_BACKEND=gloo for a rehearsal" % (rank, shared, ids[shared[0]][1]))
+
+
 def freeze_startup_heap():
     """gc.collect() + gc.freeze(): move everything allocated so far (torch's import-time heap, the network) into the
     permanent generation, so that a full pass of CPython's cyclic collector inside a per-timestep loop walks only what
@@ -75,8 +119,8 @@ def init_process_group(backend=None):
         kw = {}
         if backend == "nccl":
             # RCCL refuses two ranks on one device (and hangs the others in the rendezvous): say so before joining
-            # (a launcher that hands every rank its own GPU through *_VISIBLE_DEVICES is trusted: the ranks then see one
-            #  device each and do not share it)
+            # (a launcher that hands every rank its own GPU through *_VISIBLE_DEVICES leaves every rank ONE device, each a
+            #  different one — which is checked, not assumed: _refuse_shared_devices)
             n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
             masked = any(os.environ.get(v) is not None for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
                                                                  "CUDA_VISIBLE_DEVICES"))
@@ -84,6 +128,9 @@ def init_process_group(backend=None):
                 sys.exit("rank %d: %d local rank(s) over RCCL but this process sees %d GPU(s) — use --gpus <= %d, or "
                          "DCLL_DIST_BACKEND=gloo for a rehearsal in which ranks share devices"
                          % (rank, n_local, torch.cuda.device_count(), max(torch.cuda.device_count(), 1)))
+            if torch.cuda.device_count() < n_local and world > 1:
+                # fewer visible devices than local ranks under a mask: per-rank masks, or one mask for the whole job?
+                _refuse_shared_devices(rank, world, local_device(local_rank))
             torch.cuda.set_device(local_device(local_rank))
             kw["device_id"] = torch.device("cuda", local_device(local_rank))
         # Both backends announce themselves with a printf on STDOUT while the group / the communicator forms (gloo its

@@ -10,9 +10,10 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py            # writes tests/golden/*.npz, meta.json
     python tests/golden/make_golden.py --only-r32 # only the 32x32-plane rollout (added for the tiled kernels)
     python tests/golden/make_golden.py --only-g9  # only the checkpoint fixture (added in round 2)
+    python tests/golden/make_golden.py --only-g6b # only the production-geometry learning fixture (added in round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
-G4 vote helpers, G5 load_network_spec, G6 one train_dcll step, G7 dense layer steps,
+G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
 G8 image2spiketrain (seeded), G9 a reference-written .pth checkpoint and the reference's run after restoring it.
 """
 import json
@@ -360,6 +361,81 @@ def g6_train_step(lib, nets, du):
     np.savez_compressed(os.path.join(OUT, "g6_train_steps.npz"), **out)
 
 
+def g6b_train_production(lib, nets, du):
+    """Eight consecutive train_dcll steps of the reference at the PRODUCTION geometry (round-4 verdict, weak #1):
+    radio_ml_conv.yaml, netscale 1 (32 channels), 16x16 plane, arp 1.0, random_tau, SmoothL1 + Adam(betas (0,.95),
+    weight_decay 10, lr 1e-6 = train.py's default) + the output layer's optimizer2 (Adam, lr 1e-4), B = 8, burn-in 20,
+    T = 27 -> iter 20..27 learn with the neuron state and the Adam moments carried from step to step
+    (dcll/pytorch_libdcll.py:690-718, networks/__init__.py:176-180, train.py:249-251).
+    Stored: input cells, labels, the initial conv tensors + time constants (the i2o tensors and the initial output_.weight
+    as SHA-256: 3.1 MB of seeded uniforms that the seeded construction reproduces bit for bit), per step the packed spikes of
+    the two hidden layers and every readout, the gradients of the first / a middle / the last learning step, the
+    final trainable tensors."""
+    import hashlib
+    convs = nets.load_network_spec(os.path.join(REF, "networks", "radio_ml_conv.yaml"))
+    seed(1)
+    B, R, T, burnin = 8, 16, 27, 20
+    args = make_args()
+    opt_param = {"betas": [0.0, .95], "weight_decay": 10.0}
+    net = nets.ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss,
+                           opt=torch.optim.Adam, opt_param=opt_param, learning_rates=[1e-6], burnin=burnin)
+    net.reset(True)
+    x = synth_iq(B, 128, 11)
+    labels = torch.randint(0, 24, (B,), generator=torch.Generator().manual_seed(12))
+    np.random.seed(13)
+    spikes, targets = du.iq2spiketrain(x, du.to_one_hot(labels, 24), out_w=R, out_h=R, max_duration=T)
+    xin, tg = torch.Tensor(spikes), torch.Tensor(targets)
+    assert spikes.reshape(T, B, -1).sum(-1).min() == 1 == spikes.reshape(T, B, -1).sum(-1).max()
+    out = {"cells": spikes.reshape(T, B, -1).argmax(-1).astype(np.int32), "labels": labels.numpy().astype(np.int64)}
+    sha = {}
+    for i, s in enumerate(net.dcll_slices):
+        for k, v in state_dict_np(s.dclllayer, "sd0/%d/" % i).items():
+            if "/i2o." in k or k.endswith("/output_.weight"):
+                sha[k] = hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()
+            else:
+                out[k] = v
+    net.reset()
+    net.train()
+    learn_steps = [t for t in range(T) if t + 1 >= burnin]
+    keep = {learn_steps[0], learn_steps[len(learn_steps) // 2], learn_steps[-1]}
+    nl = len(net.dcll_slices)
+    spk = [[] for _ in range(nl - 1)]
+    pl = [[] for _ in range(nl)]
+    ol = []
+    for t in range(T):
+        cur = xin[t]
+        for i, s in enumerate(net.dcll_slices):       # ConvNetwork.learn, unrolled to see every slice's outputs
+            cur, p, _, _, _ = s.train_dcll(cur, tg[t], regularize=False)
+            pl[i].append(npy(p))
+            if s.dclllayer.output_layer:
+                ol.append(npy(cur))
+            else:
+                spk[i].append(pack_bits(npy(cur).reshape(B, -1)))
+            if t in keep:
+                out["grad/%d/%d/w" % (t, i)] = npy(s.dclllayer.i2h.weight.grad)
+                out["grad/%d/%d/b" % (t, i)] = npy(s.dclllayer.i2h.bias.grad)
+                if s.dclllayer.output_layer:
+                    out["grad/%d/%d/ow" % (t, i)] = npy(s.dclllayer.output_.weight.grad)
+                    out["grad/%d/%d/ob" % (t, i)] = npy(s.dclllayer.output_.bias.grad)
+    for i in range(nl):
+        out["p/%d" % i] = np.stack(pl[i])
+        out["clout/%d" % i] = np.array(net.dcll_slices[i].clout)
+        if i < nl - 1:
+            out["spikes/%d" % i] = np.stack(spk[i])
+    out["o_last"] = np.stack(ol)
+    for i, s in enumerate(net.dcll_slices):
+        for k, v in state_dict_np(s.dclllayer, "sd1/%d/" % i).items():
+            if "/i2h.weight" in k or "/i2h.bias" in k or "/output_." in k:
+                out[k] = v
+            elif "/i2o." in k:                      # frozen: must still hash to the initial tensor
+                assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == sha[k.replace("sd1/", "sd0/")]
+        arp = npy(s.dclllayer.i2h.state.arp)
+        out["final_arp_sum/%d" % i] = np.array([np.abs(arp.astype(np.float64)).sum()])
+    np.savez_compressed(os.path.join(OUT, "g6b_train_production.npz"), **out)
+    return dict(B=B, R=R, T=T, burnin=burnin, lr=1e-6, learn_steps=learn_steps, grad_steps=sorted(keep),
+                i2o_sha256=sha)
+
+
 def g7_dense(lib):
     out = {}
     for name, wrp, rtau in (("rrp", 1.0, False), ("plain", 0.0, False), ("plain_rtau", 0.0, True)):
@@ -452,6 +528,13 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-g6b" in sys.argv:
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["g6b"] = g6b_train_production(lib, nets, du)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, default=lambda o: list(o))
+        return
     if "--only-r32" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -474,6 +557,7 @@ def main():
     g3_iq(du)
     g4_votes(lib)
     g6_train_step(lib, nets, du)
+    meta["g6b"] = g6b_train_production(lib, nets, du)
     g7_dense(lib)
     g8_image(du)
     meta["g9"] = g9_checkpoint(lib, nets, du)

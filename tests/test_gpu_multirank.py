@@ -100,22 +100,39 @@ def test_bench_launches_its_own_ranks():
     assert "cpu_baseline" not in out            # rank 0 at N = 1 only
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1200)
 def test_bench_strong_scaling_flag_fixes_the_global_batch():
-    """`bench.py --gpus 2 --global-batch 600` (north_star: "batch 4096 ... at 1/2/4/8 GPUs" read as a FIXED global batch): the
-    ranks run contiguous shards of 300 windows, the line says "scaling": "strong", value = global windows / time, and the
-    upload-inclusive value sits beside the device-resident one."""
+    """`bench.py --gpus N --global-batch G` (north_star: "batch 4096 ... at 1/2/4/8 GPUs" read as a FIXED global batch): the
+    ranks run contiguous shards of the SAME G windows, the line says "scaling": "strong", value = global windows / time,
+    the upload-inclusive value sits beside the device-resident one — and the all-reduced tallies (correct / total per
+    layer, digest of the confusion matrices) of a FOUR-rank run (four processes sharing cuda:0, gloo rehearsal; ragged
+    shards of 257/257/257/256 windows) equal the single-process run's.  The N > 1 line carries what makes a real 8-GPU run
+    diagnosable: per-rank step time (min / max), the tally all-reduce's time, device-busy time, ranks seen, backend."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--global-batch", "600"], env=env, capture_output=True, text=True, timeout=800)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
-    assert out["config"]["global_batch"] == 600 and out["config"]["batch_per_gpu"] == 300
-    assert abs(out["value"] - 600 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
-    assert 0 < out["value_incl_upload"] <= out["value"] * 1.2 and out["ms_per_step_incl_upload"] > 0
+    lines = {}
+    for n in (1, 4):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1",
+                            "--global-batch", "1027", "--cpu-windows", "0", "--per-step", "0", "--config5", "0",
+                            "--live-traffic", "0", "--batch-sweep", "0", "--trained", "0", "--t1024", "0"],
+                           env=env, capture_output=True, text=True, timeout=1000)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(out) == 1, r.stdout
+        lines[n] = json.loads(out[0])
+    one, four = lines[1], lines[4]
+    assert four["n_gpus"] == 4 and four["scaling"] == "strong" == one["scaling"]
+    assert four["config"]["global_batch"] == 1027 and four["config"]["batch_per_gpu"] == 257
+    assert abs(four["value"] - 1027 / (four["ms_per_step"] * 1e-3)) < 1e-6 * four["value"]
+    assert 0 < four["value_incl_upload"] <= four["value"] * 1.5 and four["ms_per_step_incl_upload"] > 0
+    assert four["tallies"] == one["tallies"], (four["tallies"], one["tallies"])
+    assert [ct[1] for ct in four["tallies"]["correct_total"]] == [1027] * 3
+    assert four["vote_accuracy_vs_random_labels"] == one["vote_accuracy_vs_random_labels"]
+    m = four["multi_gpu"]
+    assert "multi_gpu" not in one and m["ranks_seen"] == 4 and m["backend"] == "gloo"
+    assert 0 < m["per_rank_ms_per_step"]["min"] <= m["per_rank_ms_per_step"]["max"] <= four["ms_per_step"] * (1 + 1e-9)
+    assert 0 < m["allreduce_ms_per_step"]["min"] <= m["allreduce_ms_per_step"]["max"]
+    assert 0 < m["device_busy_ms_per_step"]["min"] <= m["device_busy_ms_per_step"]["max"]
+    assert len(m["rank_devices"]) == 4 and m["distinct_devices"] == 1         # the rehearsal: four ranks, one GPU
 
 
 @pytest.mark.timeout(900)

@@ -8,11 +8,18 @@ per-step call (dcll_conv_lif_step: the state is caller-owned, include/dcll_hip.h
 spikes of that layer.  Every (t, window, layer) pair is therefore verified on identical inputs:
 
   * traces eps0', eps1' bit-equal (elementwise fp32 ops in the reference's order, dcll/pytorch_libdcll.py:493-494);
-  * membrane v = pvmem + arp of the two summation orders (:495-498) compared at EVERY output, not only at flips, against
-    SURVEY 8(c)'s band 8*eps*sum|w*eps1| (+ one rounding of v).  That band is a statistical yardstick, not a worst-case
-    bound — two fp32 sums of n = 1569 terms may differ by up to 2*n*(eps/2)*sum|w*eps1| = 196 bands/8 —, so over the 1.3e10
-    values of a 512-window batch the largest deviation can graze it (seen: 1.01 x on trained weights, 0.9 x on the
-    seeded init): the worst ratio is REPORTED and must stay below DV_BANDS = 2;
+  * membrane v = pvmem + arp of the two summation orders (:495-498): on every 8th step BOTH are measured against a float64
+    evaluation of the same sum (the reference's eps1 and weights in float64: unfold + matmul on the GPU, plus the fp32
+    alpharp*arp both paths add), at EVERY output of the step.  Two gates (round-4 verdict, weak #3 — the earlier gate,
+    |v_hip - v_ref| <= 2 bands of 8*eps*sum|w*eps1|, had been widened until it constrained nothing):
+      (a) the pinned chain's own a-priori bound: |v_hip - v64| <= gamma_(n+1) * (|b| + sum|w*eps1|) + u*|v|, u = eps/2,
+          gamma_k = k*u / (1 - k*u), n = c_in*49 — what n+1 exactly rounded fmaf steps can accumulate (Higham, Accuracy
+          and Stability of Numerical Algorithms, eq. 3.4) — a missing, duplicated or mis-weighted term is ~ sum/n, seven
+          times the bound at n = 1568;
+      (b) "the pinned chain is as accurate as oneDNN's order": per layer, max |v_hip - v64| <= ACC_RATIO * max |v_ref -
+          v64| (both in units of u * (|b| + sum|w*eps1|)); both error distributions (max, rms, 99.9th percentile) are
+          reported.  |v_hip - v_ref| at every output of EVERY step is still reported in units of SURVEY 8(c)'s band
+          (worst_dv_over_band), without a gate of its own;
   * EVERY spike mismatch has |v_ref| inside the band itself (1 x; a legitimate tie-break of v > 0, :499), and the count
     is reported;
   * arp' bit-equal wherever the spikes agree (:497, :503);
@@ -32,7 +39,8 @@ pytestmark = pytest.mark.gpu
 PKG = os.path.join(ROOT, "snn_modulation_classification_amd")
 EPS = float(np.finfo(np.float32).eps)
 LOGIT_TOL = 1e-4
-DV_BANDS = 2.0
+ACC_RATIO = 1.5          # gate (b): worst error of the pinned chain <= ACC_RATIO x worst error of the reference's order
+F64_EVERY = 8            # steps between float64 evaluations
 
 
 def _seeded_net(B):
@@ -68,6 +76,7 @@ def teacher_forced_run(net, ref, x, report):
                 st = Lh.i2h.state
                 for dst, src in zip(st, pre[i]):
                     dst.copy_(src)
+                pre_arp = pre[i][2]
                 s_h, p_h, o_h, pv_h, v_h = Lh.i2h._step(cur.to(dev), Lh.pooling, Lh.i2o,
                                                         Lh.output_ if Lh.output_layer else None)
                 pre[i] = e0, e1, arp = tuple(t_.to(dev) for t_ in lay.state)
@@ -81,7 +90,8 @@ def teacher_forced_run(net, ref, x, report):
                 dv = (v_h - v_r).abs()
                 worst = float((dv / band).max())
                 report["worst_dv_over_band"] = max(report["worst_dv_over_band"], worst)
-                assert worst <= DV_BANDS, ("v outside %g rounding bands" % DV_BANDS, t, i, worst)
+                if t % F64_EVERY == F64_EVERY - 1:
+                    _f64_accuracy(report["f64"][i], e1, arp_pre=pre_arp, lay=lay, v_h=v_h, v_r=v_r, where=(t, i))
                 mism = (s_h > 0.5) != s_r
                 n_m = int(mism.sum())
                 report["spikes_compared"][i] += int(mism.numel())
@@ -107,18 +117,63 @@ def teacher_forced_run(net, ref, x, report):
     return report
 
 
+def _f64_accuracy(acc, eps1, arp_pre, lay, v_h, v_r, where):
+    """Both membrane values of one layer step against float64 (module docstring, gates (a) and (b)); eps1 = the
+    reference's post-step trace (bit-equal to the HIP one), arp_pre = the injected refractory trace."""
+    B, C, H, W = eps1.shape
+    w = lay.w.to(eps1.device)
+    b = lay.b.to(eps1.device)
+    n = C * w.shape[2] * w.shape[3]
+    u = EPS / 2
+    cols = F.unfold(eps1.double(), kernel_size=tuple(w.shape[2:]), padding=lay.padding)              # (B, n, H*W)
+    w2 = w.double().reshape(w.shape[0], n)
+    s64 = torch.matmul(w2, cols) + b.double()[None, :, None]
+    mag = torch.matmul(w2.abs(), cols.abs()) + b.double().abs()[None, :, None]                     # |b| + sum |w * eps1|
+    a32 = (lay.alpharp * arp_pre).double().reshape(B, w.shape[0], -1)                               # fp32 product, as both paths form it
+    v64 = s64 + a32
+    gamma = (n + 1) * u / (1 - (n + 1) * u)
+    e_h = (v_h.double().reshape(v64.shape) - v64).abs()
+    e_r = (v_r.double().reshape(v64.shape) - v64).abs()
+    bound = gamma * mag + u * v64.abs() + 1e-45
+    ratio = float((e_h / bound).max())
+    acc["worst_hip_over_apriori_bound"] = max(acc["worst_hip_over_apriori_bound"], ratio)
+    assert ratio <= 1.0, ("pinned fmaf chain outside its a-priori error bound", where, ratio)
+    unit = u * mag + 1e-45
+    for key, e in (("hip", e_h), ("ref", e_r)):
+        x = (e / unit).reshape(-1)
+        acc[key + "_max"] = max(acc[key + "_max"], float(x.max()))
+        acc[key + "_sumsq"] += float((x * x).sum())
+        acc[key + "_p999"] = max(acc[key + "_p999"], float(torch.quantile(x[::max(1, x.numel() // 1000000)].float(), 0.999)))
+    acc["n"] += int(e_h.numel())
+    acc["terms"] = n + 1
+
+
 def _new_report(L=3):
+    f64 = [dict(n=0, terms=0, worst_hip_over_apriori_bound=0.0, hip_max=0.0, ref_max=0.0, hip_sumsq=0.0, ref_sumsq=0.0,
+                hip_p999=0.0, ref_p999=0.0) for _ in range(L)]
     return dict(windows=0, steps=0, spikes_compared=[0] * L, mismatches=[0] * L, worst_dv_over_band=0.0,
                 worst_mismatch_v_over_band=0.0, worst_logit_diff=0.0, argmax_agree=0, argmax_total=0,
-                windows_with_mismatch=[set() for _ in range(L)])
+                windows_with_mismatch=[set() for _ in range(L)], f64=f64)
 
 
 def _finish(report, label, capsys):
     out = dict(report)
     out["windows_with_mismatch"] = [len(s_) for s_ in report["windows_with_mismatch"]]
     out["output_argmax_agreement"] = report["argmax_agree"] / max(1, report["argmax_total"])
+    out["f64"] = []
+    for a in report["f64"]:
+        n = max(1, a["n"])
+        out["f64"].append({"outputs_checked": a["n"], "chain_terms": a["terms"],
+                           "unit": "u * (|b| + sum|w*eps1|), u = 2^-24",
+                           "hip": {"max": a["hip_max"], "rms": (a["hip_sumsq"] / n) ** 0.5, "p99.9": a["hip_p999"]},
+                           "reference": {"max": a["ref_max"], "rms": (a["ref_sumsq"] / n) ** 0.5, "p99.9": a["ref_p999"]},
+                           "worst_hip_over_apriori_bound": a["worst_hip_over_apriori_bound"]})
     with capsys.disabled():
         print("\n[teacher-forced HIP step vs reference CPU path, %s] %s" % (label, json.dumps(out)))
+    for i, a in enumerate(out["f64"]):
+        assert a["outputs_checked"] > 0
+        assert a["hip"]["max"] <= ACC_RATIO * a["reference"]["max"], \
+            ("layer %d: the pinned chain's worst error against float64 exceeds %g x the reference order's" % (i, ACC_RATIO), a)
     return out
 
 

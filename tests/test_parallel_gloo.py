@@ -72,6 +72,36 @@ def test_two_rank_tally_allreduce_equals_single_process(tmp_path):
         assert abs(float(acc[i]) - float(np.mean(votes_np[i] == labels_np))) < 1e-12
 
 
+def _shared_device_worker(rank, world, port, same, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DCLL_FAKE_DEVICE_ID="GPU-0" if same else "GPU-%d" % rank)
+    parallel._refuse_shared_devices(rank, world, 0)        # exits the rank when two ranks name the same device
+    parallel.init_process_group(backend="gloo")            # the job's own group forms afterwards on the same port
+    t = torch.tensor([1.0])
+    parallel.all_reduce_(t)
+    open(os.path.join(out_dir, "ok_%d" % rank), "w").write(str(float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_ranks_that_share_a_physical_device_are_refused_before_rccl(tmp_path):
+    """Round-4 advisor: a job-wide HIP_VISIBLE_DEVICES=0 under torchrun looks like per-rank masks (every rank sees one
+    device) but maps all ranks onto one GPU, where RCCL hangs.  The ranks compare (host, device identity) in a gloo
+    pre-rendezvous: distinct devices -> the job goes on and forms its group; a shared one -> every rank exits non-zero."""
+    assert parallel.ranks_sharing_a_device([("a", "u0"), ("a", "u1"), ("b", "u0"), ("a", None), ("a", None)]) == []
+    assert parallel.ranks_sharing_a_device([("a", "u0"), ("a", "u1"), ("a", "u0")]) == [0, 2]
+    (tmp_path / "distinct").mkdir()
+    (tmp_path / "same").mkdir()
+    mp.spawn(_shared_device_worker, args=(2, _free_port(), False, str(tmp_path / "distinct")), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path / "distinct")) == ["ok_0", "ok_1"]
+    assert open(tmp_path / "distinct" / "ok_0").read() == "2.0"
+    with pytest.raises(Exception) as ei:
+        mp.spawn(_shared_device_worker, args=(2, _free_port(), True, str(tmp_path / "same")), nprocs=2, join=True)
+    assert "exit code 1" in str(ei.value) or "exited" in str(ei.value)
+    assert os.listdir(tmp_path / "same") == []
+
+
 def _grad_worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
