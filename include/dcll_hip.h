@@ -203,6 +203,31 @@ int dcll_adam_step(const dcll_adam_tensor *tensors, int32_t n_tensors, void *str
  * stream-ordered copy before each replay). */
 int dcll_adam_step_dyn(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream);
 
+/*
+ * The end of a learning timestep in one launch (ABI 5).  dcll_conv_lif_backward_open is dcll_conv_lif_backward with the last
+ * step of the weight gradient left open: the partial rows stay in `scratch` — *part points at *nchunk rows of
+ * c_out * (c_in*kh*kw + 1) floats, valid until the next call that uses this scratch — and dW / db are not written.
+ * dcll_grad_reduce_adam then finishes up to DCLL_REDUCE_MAX_LAYERS layers at once: the rows are added in dcll_conv_lif_backward's
+ * own fixed order (bit-identical gradients), written to dW / db, and the Adam update of `tensors[adam_w]` / `tensors[adam_b]`
+ * (index, or -1: no update) is applied by the thread that holds the finished gradient element; the tensors no layer refers
+ * to get dcll_adam_step's elementwise update in the same launch.  dyn: NULL, or as dcll_adam_step_dyn (n_tensors x 3).
+ * Replaces, per timestep of train_dcll (:690-718), one reduce launch per layer + the optimizer launch.
+ */
+#define DCLL_REDUCE_MAX_LAYERS 4
+typedef struct dcll_grad_parts {
+    const float *part;          /* nchunk partial rows (dcll_conv_lif_backward_open)                       */
+    float *dW, *db;             /* (c_out, c_in*kh*kw) and (c_out): the reduced gradients; db may be NULL  */
+    int64_t rowlen;             /* c_in*kh*kw + 1                                                          */
+    int32_t nchunk, c_out;
+    int32_t adam_w, adam_b;     /* entries of `tensors` to update with dW / db, or -1                      */
+} dcll_grad_parts;
+int dcll_conv_lif_backward_open(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
+                                const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
+                                const float *i2o_W, float *d_outW, float *d_outb, float *scratch, int64_t scratch_floats,
+                                int32_t B, const float **part, int32_t *nchunk, void *stream);
+int dcll_grad_reduce_adam(const dcll_grad_parts *layers, int32_t n_layers, const dcll_adam_tensor *tensors,
+                          int32_t n_tensors, const float *dyn, void *stream);
+
 int dcll_cells_to_planes(const int32_t *cells, float *planes, int64_t n_samples, int32_t hw, void *stream);
 
 /* One timestep of DenseDCLLlayer.forward — drop-in for dcll/pytorch_libdcll.py:250-255 (dropout = identity). */

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_PKG, "libdcll_hip.so")
+# (DCLL_HIP_SO: another build of the same sources, for A/B measurements of compile-time switches — experiments/)
+SO_PATH = os.environ.get("DCLL_HIP_SO") or os.path.join(_PKG, "libdcll_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
@@ -46,6 +47,12 @@ class AdamTensor(ctypes.Structure):
                 ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
+class GradParts(ctypes.Structure):
+    """dcll_grad_parts"""
+    _fields_ = [("part", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("rowlen", ctypes.c_int64),
+                ("nchunk", ctypes.c_int32), ("c_out", ctypes.c_int32), ("adam_w", ctypes.c_int32), ("adam_b", ctypes.c_int32)]
+
+
 class LayerOpts(ctypes.Structure):
     """dcll_layer_opts (ABI v3): int8 conv weights + per-output-channel scale, pv written before the sigmoid"""
     _fields_ = [("w_q8", ctypes.c_void_p), ("w_scale", ctypes.c_void_p), ("pv_presigmoid", ctypes.c_int32),
@@ -59,6 +66,7 @@ class IQTail(ctypes.Structure):
 
 ACT_NONE, ACT_SIGMOID = 0, 1
 ADAM_MAX_TENSORS = 8
+REDUCE_MAX_LAYERS = 4
 LOSS_SMOOTH_L1, LOSS_MSE = 0, 1
 
 _P, _I32, _I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
@@ -80,6 +88,8 @@ SIGNATURES = {
     "dcll_local_loss_grad": (_I32, [_P] * 7 + [_I32, _I32, _I32, _P]),
     "dcll_adam_step": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P]),
     "dcll_adam_step_dyn": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P, _P]),
+    "dcll_conv_lif_backward_open": (_I32, [_DP] + [_P] * 11 + [_I64, _I32, ctypes.POINTER(ctypes.c_void_p), _IP, _P]),
+    "dcll_grad_reduce_adam": (_I32, [ctypes.POINTER(GradParts), _I32, ctypes.POINTER(AdamTensor), _I32, _P, _P]),
     "dcll_cells_to_planes": (_I32, [_P, _P, _I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
     "dcll_dense_lif_sequence": (_I32, [_DDP] + [_P] * 16 + [_I32, _I32, _P]),

@@ -3056,14 +3056,17 @@ __global__ __launch_bounds__(256) void k_bwd_outgrad_mfma(const float *__restric
     }
 }
 
-extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
-                                      const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
-                                      const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
-                                      float *scratch, int64_t scratch_floats, int32_t B, void *stream)
+// open_part != nullptr: the weight gradient's partial rows are left in scratch (*open_part, *open_nchunk) for
+// dcll_grad_reduce_adam; dW / db are not written
+static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
+                                  const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
+                                  const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
+                                  float *scratch, int64_t scratch_floats, int32_t B, void *stream,
+                                  const float **open_part, int32_t *open_nchunk)
 {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!eps1 || !v || !dW || !scratch) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: null pointer");
+    if (!eps1 || !v || (!dW && !open_part) || !scratch) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: null pointer");
     if (g_p && !i2o_W) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: g_p needs i2o_W");
     if (g_o && (!pv_pooled || !d_outW || !d_outb)) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: g_o needs pv_pooled, d_outW, d_outb");
     if (d->kh * d->kw > WG_MAXTAPS) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: kernels up to 64 taps");
@@ -3146,17 +3149,23 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
                            eps1, part, B, RB);
         HIP_CHECK_LAUNCH("k_bwd_wgrad");
     }
-    if (nchunk >= 64)
-        hipLaunchKernelGGL(k_bwd_reduce4<16>, dim3(nblk(per_chunk, 64)), dim3(1024), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
-    else if (nchunk >= 16)
-        hipLaunchKernelGGL(k_bwd_reduce4<4>, dim3(nblk(per_chunk, 64)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
-    else
-        hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
-    HIP_CHECK_LAUNCH("k_bwd_reduce");
+    if (open_part) {
+        *open_part = part;
+        *open_nchunk = (int32_t)nchunk;
+    } else {
+        if (nchunk >= 64)
+            hipLaunchKernelGGL(k_bwd_reduce4<16>, dim3(nblk(per_chunk, 64)), dim3(1024), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+        else if (nchunk >= 16)
+            hipLaunchKernelGGL(k_bwd_reduce4<4>, dim3(nblk(per_chunk, 64)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+        else
+            hipLaunchKernelGGL(k_bwd_reduce, dim3(nblk(per_chunk, 256)), dim3(256), 0, st, part, dW, db, (int)nchunk, d->c_out, rowlen);
+        HIP_CHECK_LAUNCH("k_bwd_reduce");
+    }
     if (g_o) {
         const int K = d->c_out * ph * pw, N = d->target;
-        // the partial-sum area of the weight gradient is free again (stream order): reuse it for the batch chunks
-        long nsplit = (scratch_floats - nconv) / ((long)N * (K + 1));
+        // the partial-sum area of the weight gradient is free again (stream order): reuse it for the batch chunks —
+        // unless the partial rows are still wanted (open form): then only the forms without partial sums serve
+        long nsplit = open_part ? 0 : (scratch_floats - nconv) / ((long)N * (K + 1));
         if (nsplit > 16) nsplit = 16;
         if (nsplit > B) nsplit = B;
         if (N <= 32 && K % 32 == 0) {
@@ -3176,6 +3185,25 @@ extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1
         }
     }
     return DCLL_OK;
+}
+
+extern "C" int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
+                                      const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
+                                      const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
+                                      float *scratch, int64_t scratch_floats, int32_t B, void *stream)
+{
+    return conv_lif_backward_impl(d, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, dW, db, d_outW, d_outb, scratch,
+                                  scratch_floats, B, stream, nullptr, nullptr);
+}
+
+extern "C" int dcll_conv_lif_backward_open(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,
+                                           const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
+                                           const float *i2o_W, float *d_outW, float *d_outb, float *scratch,
+                                           int64_t scratch_floats, int32_t B, const float **part, int32_t *nchunk, void *stream)
+{
+    if (!part || !nchunk) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward_open: null part / nchunk");
+    return conv_lif_backward_impl(d, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, nullptr, nullptr, d_outW, d_outb, scratch,
+                                  scratch_floats, B, stream, part, nchunk);
 }
 
 // ------------------------------------------------------------------------------------------------------------

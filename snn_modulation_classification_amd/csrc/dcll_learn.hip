@@ -208,16 +208,19 @@ struct adam_args {
     int n_tensors;
 };
 
-__global__ __launch_bounds__(256) void k_adam_multi(adam_args a)
+// the update of element i of tensor k, its gradient given (the ONE place the arithmetic lives: k_adam_multi and
+// k_grad_reduce_adam give the same bits for the same gradient)
+__device__ __forceinline__ void adam_update(const adam_args &a, int k, long i, float grad, float p, float m, float v);
+__device__ __forceinline__ void adam_element(const adam_args &a, int k, long i, float grad)
 {
-    int k = 0;
-    while (k + 1 < a.n_tensors && (long)blockIdx.x >= a.first[k + 1]) ++k;      // wave-uniform
-    const dcll_adam_tensor t = a.t[k];
-    const long i = ((long)blockIdx.x - a.first[k]) * 256 + threadIdx.x;
-    if (i >= t.n) return;
-    float p = t.param[i];
-    const float g = t.grad[i] + t.weight_decay * p;
-    float m = t.exp_avg[i], v = t.exp_avg_sq[i];
+    const dcll_adam_tensor &t = a.t[k];
+    adam_update(a, k, i, grad, t.param[i], t.exp_avg[i], t.exp_avg_sq[i]);
+}
+// (parameter and moments already in registers: k_grad_reduce_adam requests them before it adds the partial rows)
+__device__ __forceinline__ void adam_update(const adam_args &a, int k, long i, float grad, float p, float m, float v)
+{
+    const dcll_adam_tensor &t = a.t[k];
+    const float g = grad + t.weight_decay * p;
     const float w = 1.0f - t.beta1;
     m = w < 0.5f ? m + w * (g - m) : g - (g - m) * (1.0f - w);                 // torch's lerp
     v = v * t.beta2 + ((1.0f - t.beta2) * g) * g;
@@ -228,6 +231,15 @@ __global__ __launch_bounds__(256) void k_adam_multi(adam_args a)
     t.exp_avg[i] = m;
     t.exp_avg_sq[i] = v;
     t.param[i] = p;
+}
+
+__global__ __launch_bounds__(256) void k_adam_multi(adam_args a)
+{
+    int k = 0;
+    while (k + 1 < a.n_tensors && (long)blockIdx.x >= a.first[k + 1]) ++k;      // wave-uniform
+    const long i = ((long)blockIdx.x - a.first[k]) * 256 + threadIdx.x;
+    if (i >= a.t[k].n) return;
+    adam_element(a, k, i, a.t[k].grad[i]);
 }
 
 static int adam_launch(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream);
@@ -243,29 +255,163 @@ extern "C" int dcll_adam_step_dyn(const dcll_adam_tensor *tensors, int32_t n_ten
     return adam_launch(tensors, n_tensors, dyn, stream);
 }
 
-static int adam_launch(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream)
+// tensors -> adam_args with `per_block` elements per workgroup; tensors with skip[k] set get no blocks of their own
+static int adam_fill(adam_args &a, const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, int per_block,
+                     const bool *skip, long *blocks_out, const char *who)
 {
-    if (n_tensors == 0) return DCLL_OK;
     if (!tensors || n_tensors < 0 || n_tensors > DCLL_ADAM_MAX_TENSORS)
-        return fail(DCLL_ERR_INVALID, "dcll_adam_step: bad argument (1..8 tensors)");
-    adam_args a;
+        return fail(DCLL_ERR_INVALID, "bad argument (1..8 tensors)", who);
     a.dyn = dyn;
     long blocks = 0;
     for (int k = 0; k < n_tensors; ++k) {
         if (!tensors[k].param || !tensors[k].grad || !tensors[k].exp_avg || !tensors[k].exp_avg_sq || tensors[k].n < 0 ||
             tensors[k].step < 1)
-            return fail(DCLL_ERR_INVALID, "dcll_adam_step: null tensor or step < 1");
+            return fail(DCLL_ERR_INVALID, "null tensor or step < 1", who);
         a.t[k] = tensors[k];
         a.first[k] = blocks;
-        blocks += (tensors[k].n + 255) / 256;
+        if (!(skip && skip[k])) blocks += (tensors[k].n + per_block - 1) / per_block;
         a.inv_bc1[k] = (float)(1.0 / (1.0 - pow((double)tensors[k].beta1, (double)tensors[k].step)));
         a.inv_sqrt_bc2[k] = (float)(1.0 / sqrt(1.0 - pow((double)tensors[k].beta2, (double)tensors[k].step)));
     }
     a.first[n_tensors] = blocks;
     a.n_tensors = n_tensors;
+    *blocks_out = blocks;
+    return DCLL_OK;
+}
+
+static int adam_launch(const dcll_adam_tensor *tensors, int32_t n_tensors, const float *dyn, void *stream)
+{
+    if (n_tensors == 0) return DCLL_OK;
+    adam_args a;
+    long blocks = 0;
+    int rc = adam_fill(a, tensors, n_tensors, dyn, 256, nullptr, &blocks, "dcll_adam_step");
+    if (rc) return rc;
     if (blocks == 0) return DCLL_OK;
     hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     HIP_CHECK_LAUNCH("k_adam_multi");
+    return DCLL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_grad_reduce_adam — the end of a learning timestep in ONE launch (round 5; before: a k_bwd_reduce4 per layer + k_adam_multi,
+// four dependent launches of 5-8 us around 50 k-element arrays): the weight-gradient partial rows that
+// dcll_conv_lif_backward_open left in the layers' scratch are added in the fixed order of k_bwd_reduce4 / k_bwd_reduce
+// (same grouping by row count: bit-identical gradients), written to dW / db, and the thread that holds a finished
+// gradient element applies torch.optim.Adam's update to its parameter element right there (adam_element).  Tensors no
+// layer refers to (output_.weight / output_.bias, whose gradients k_bwd_outgrad_mfma wrote) get the plain elementwise
+// update in further workgroups of the same launch.
+// ------------------------------------------------------------------------------------------------------------
+struct reduce_adam_args {
+    adam_args a;
+    dcll_grad_parts L[DCLL_REDUCE_MAX_LAYERS];
+    long lfirst[DCLL_REDUCE_MAX_LAYERS + 1];     // prefix sums of the layers' workgroups (64 gradient elements each)
+    int groups[DCLL_REDUCE_MAX_LAYERS];          // partial-row groups: 16 / 4 / 1, as the standalone reduce kernels choose
+    int n_layers;
+};
+
+__global__ __launch_bounds__(1024) void k_grad_reduce_adam(reduce_adam_args ra)
+{
+    __shared__ float red[16][64];
+    const long blk = blockIdx.x;
+    if (blk >= ra.lfirst[ra.n_layers]) {                        // plain Adam workgroups: 1024 elements each
+        const long b2 = blk - ra.lfirst[ra.n_layers];
+        int k = 0;
+        while (k + 1 < ra.a.n_tensors && b2 >= ra.a.first[k + 1]) ++k;
+        const long i = (b2 - ra.a.first[k]) * 1024 + threadIdx.x;
+        if (i < ra.a.t[k].n) adam_element(ra.a, k, i, ra.a.t[k].grad[i]);
+        return;
+    }
+    int l = 0;
+    while (l + 1 < ra.n_layers && blk >= ra.lfirst[l + 1]) ++l;     // wave-uniform
+    const dcll_grad_parts &P = ra.L[l];
+    const int GR = ra.groups[l];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long i = (blk - ra.lfirst[l]) * 64 + lane;
+    const long total = (long)P.c_out * P.rowlen;
+    // the element this lane finishes (group 0 only) and its optimizer operands: requested NOW, so that they land under the
+    // partial-row loads (behind the reduction they were a second exposed memory round trip per workgroup: 40 instead of
+    // 29 us for the timestep's tail, against the four launches this kernel replaces)
+    const int co = (int)(i / P.rowlen);
+    const long n = i % P.rowlen;
+    const bool isw = n < P.rowlen - 1;
+    const int kt = isw ? P.adam_w : P.adam_b;
+    const long e = isw ? (long)co * (P.rowlen - 1) + n : co;
+    float p0 = 0.0f, m0 = 0.0f, v0 = 0.0f;
+    if (grp == 0 && i < total && kt >= 0) {
+        p0 = ra.a.t[kt].param[e];
+        m0 = ra.a.t[kt].exp_avg[e];
+        v0 = ra.a.t[kt].exp_avg_sq[e];
+    }
+    float acc = 0.0f;
+    if (i < total && grp < GR) {
+        const int per = (P.nchunk + GR - 1) / GR, c0 = grp * per, c1 = min(P.nchunk, c0 + per);
+        const float *src = P.part + i;
+        int c = c0;
+        if (GR > 1) {
+            for (; c + 8 <= c1; c += 8) {                     // eight loads in flight, added in chunk order
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = src[(long)(c + q) * total];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += t[q];
+            }
+        }
+        for (; c < c1; ++c) acc += src[(long)c * total];
+    }
+    red[grp][lane] = acc;
+    __syncthreads();
+    if (grp != 0 || i >= total) return;
+    float tot = red[0][lane];
+    for (int q = 1; q < GR; ++q) tot += red[q][lane];
+    if (isw) P.dW[e] = tot;
+    else if (P.db) P.db[co] = tot;
+    if (kt >= 0) adam_update(ra.a, kt, e, tot, p0, m0, v0);
+}
+
+extern "C" int dcll_grad_reduce_adam(const dcll_grad_parts *layers, int32_t n_layers, const dcll_adam_tensor *tensors,
+                                     int32_t n_tensors, const float *dyn, void *stream)
+{
+    if (n_layers == 0 && n_tensors == 0) return DCLL_OK;
+    if (n_layers < 0 || n_layers > DCLL_REDUCE_MAX_LAYERS || (n_layers > 0 && !layers))
+        return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: bad argument (0..4 layers)");
+    reduce_adam_args ra;
+    bool taken[DCLL_ADAM_MAX_TENSORS] = {false};
+    long blocks = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const dcll_grad_parts &P = layers[l];
+        if (!P.part || !P.dW || P.nchunk < 1 || P.c_out < 1 || P.rowlen < 2)
+            return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: bad layer entry");
+        for (int idx : {P.adam_w, P.adam_b}) {
+            if (idx < -1 || idx >= n_tensors) return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: tensor index out of range");
+            if (idx >= 0) {
+                if (taken[idx]) return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: a tensor is referred to twice");
+                taken[idx] = true;
+            }
+        }
+        if (P.adam_w >= 0 && tensors[P.adam_w].n != (int64_t)P.c_out * (P.rowlen - 1))
+            return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: weight tensor size != c_out * (rowlen - 1)");
+        if (P.adam_b >= 0 && tensors[P.adam_b].n != P.c_out)
+            return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: bias tensor size != c_out");
+        ra.L[l] = P;
+        ra.groups[l] = P.nchunk >= 64 ? 16 : P.nchunk >= 16 ? 4 : 1;
+        ra.lfirst[l] = blocks;
+        blocks += ((long)P.c_out * P.rowlen + 63) / 64;
+    }
+    ra.lfirst[n_layers] = blocks;
+    ra.n_layers = n_layers;
+    long ablocks = 0;
+    if (n_tensors > 0) {
+        int rc = adam_fill(ra.a, tensors, n_tensors, dyn, 1024, taken, &ablocks, "dcll_grad_reduce_adam");
+        if (rc) return rc;
+    } else {
+        ra.a.n_tensors = 0;
+        ra.a.dyn = nullptr;
+        ra.a.first[0] = 0;
+    }
+    if (blocks + ablocks == 0) return DCLL_OK;
+    if (blocks + ablocks > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: too many elements");
+    hipLaunchKernelGGL(k_grad_reduce_adam, dim3((unsigned)(blocks + ablocks)), dim3(1024), 0, (hipStream_t)stream, ra);
+    HIP_CHECK_LAUNCH("k_grad_reduce_adam");
     return DCLL_OK;
 }
 

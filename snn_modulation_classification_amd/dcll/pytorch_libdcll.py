@@ -272,9 +272,10 @@ class ContinuousConv2D(nn.Module):
                 rows.append(flat[:, 0])
         return torch.stack(rows).contiguous()
 
-    def _step(self, input, pooling=(1, 1), i2o=None, output_=None, out=None, stacked=None, finish=None, want_v=True):
+    def _step(self, input, pooling=(1, 1), i2o=None, output_=None, out=None, stacked=None, finish=None, want_v=True,
+              defer_ro=False):
         """Run one step through dcll_conv_lif_step; returns (s_pooled, p, o, pv_pooled, v).  `out`: optional dict of
-        reusable output buffers; `stacked` / `finish`: the fused readout tail of the step (ops.conv_lif_step)."""
+        reusable output buffers; `stacked` / `finish` / `defer_ro`: the fused readout tail of the step (ops.conv_lif_step)."""
         if not self.spiking:
             raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
         self._check_batch(input)
@@ -288,7 +289,7 @@ class ContinuousConv2D(nn.Module):
                 st.eps0, st.eps1, arp,
                 None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
                 None if output_ is None else output_.weight, None if output_ is None else output_.bias, out=out,
-                q8=self.int8_weights(), stacked=stacked, finish=finish, want_v=want_v)
+                q8=self.int8_weights(), stacked=stacked, finish=finish, want_v=want_v, defer_ro=defer_ro)
 
     def forward(self, input):
         """-> (output spikes, pv, pvmem), un-pooled (reference :407-426)."""
@@ -854,6 +855,14 @@ class DCLLBase(nn.Module):
         clout_out: write the recorded argmax there instead of appending a fresh tensor to clout (graph capture: the
         caller copies it out after each replay).
         -> (output, pvoutput, pv, pvmem, loss (1,) device tensor or None, learned)"""
+        ctx = self._learn_forward(input, target, want_loss=want_loss, clout_out=clout_out)
+        loss = self._learn_tail(ctx)
+        return ctx['out'] + (loss, ctx['learned'])
+
+    def _learn_forward(self, input, target, want_loss=True, clout_out=None, defer=False):
+        """The layer kernel of one learning step (+ its readout tail unless `defer`): -> ctx for _learn_tail.  With `defer`
+        the readouts, loss gradients and the backward are ALL left to _learn_tail: ConvNetwork.learn launches the layer
+        kernels of every slice first — slice l+1 needs slice l's spikes, not its readouts — and the tails behind them."""
         L = self.dclllayer
         i2h = L.i2h
         bufs = self.__dict__.setdefault('_learn_bufs', {})
@@ -867,35 +876,53 @@ class DCLLBase(nn.Module):
                 # the readouts' finishing launch also yields the local-loss gradients and the recorded argmax
                 fin = dict(clout=(clout_out if clout_out is not None else True) if rec else None, target=target,
                            kind=self._native_learning())
+            elif defer:
+                fin = dict(clout=None)
             s, p, o, pv, v = i2h._step(input, L.pooling, L.i2o, L.output_ if L.output_layer else None, out=bufs,
-                                       stacked=L.stacked_readout() if L.output_layer else None, finish=fin)
+                                       stacked=L.stacked_readout() if L.output_layer else None, finish=fin,
+                                       defer_ro=defer)
             if self.collect_stats and (self.iter % 20) == 0:
                 self.activity_hist.append((ops.pv_lowhigh(pv, 1, self.iter - 1)[0], pv.numel()))
-            if learned:
-                if fin is not None and fin.get('done'):
-                    g_p, g_o, loss = fin['g_p'], fin['g_o'], None
-                    if rec and clout_out is None:
-                        self._clout.append(fin['clout'])
-                else:
-                    res = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(), out=bufs,
-                                              want_loss=want_loss, want_clout=rec, clout_out=clout_out)
-                    g_p, g_o, loss = res[:3]
-                    if rec and clout_out is None:
-                        self._clout.append(res[3])
-                prm = [i2h.weight, i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
-                for q in prm:
-                    if q.grad is None:
-                        q.grad = torch.zeros_like(q)
-                desc = i2h.make_desc(input.shape[2:4], L.pooling, L.i2o.weight.shape[0], L.output_layer)
-                gb = bufs.setdefault('grads', {})
-                gb.update(dW=prm[0].grad, db=prm[1].grad)
-                if L.output_layer:
-                    gb.update(d_outW=prm[2].grad, d_outb=prm[3].grad)
-                ops.conv_lif_backward(desc, i2h.state.eps1, v, pv, g_p, g_o, None, None, L.i2o.weight,
-                                      want_out=L.output_layer, out=gb)
+        return dict(out=((o if L.output_layer else s), p, pv, v), fin=fin, learned=learned, rec=rec, input=input,
+                    target=target, want_loss=want_loss, clout_out=clout_out, p=p, o=o, pv=pv, v=v)
+
+    def _learn_tail(self, ctx, open_reduce=False):
+        """What follows the layer kernel of a learning step: the (deferred) readout tail, then — once iter >= burnin — the
+        local-loss gradients (from the readouts' finishing launch where it served them, else dcll_local_loss_grad) and
+        dcll_conv_lif_backward into the parameters' .grad.  `open_reduce`: the weight gradient's last reduction is left to
+        the caller's ops.grad_reduce_adam (self._learn_bufs['grads']['parts']).  -> loss (1,) device tensor or None"""
+        L = self.dclllayer
+        i2h = L.i2h
+        fin, rec, clout_out = ctx['fin'], ctx['rec'], ctx['clout_out']
+        bufs = self._learn_bufs
+        with torch.no_grad():
+            if fin is not None and 'run_readouts' in fin:
+                fin.pop('run_readouts')()
+            if not ctx['learned']:
+                return None
+            p, o, pv, v, target = ctx['p'], ctx['o'], ctx['pv'], ctx['v'], ctx['target']
+            if fin is not None and fin.get('done') and fin.get('g_p') is not None:
+                g_p, g_o, loss = fin['g_p'], fin['g_o'], None
+                if rec and clout_out is None:
+                    self._clout.append(fin['clout'])
             else:
-                loss = None
-        return (o if L.output_layer else s), p, pv, v, loss, learned
+                res = ops.local_loss_grad(p, o if L.output_layer else None, target, self._native_learning(), out=bufs,
+                                          want_loss=ctx['want_loss'], want_clout=rec, clout_out=clout_out)
+                g_p, g_o, loss = res[:3]
+                if rec and clout_out is None:
+                    self._clout.append(res[3])
+            prm = [i2h.weight, i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
+            for q in prm:
+                if q.grad is None:
+                    q.grad = torch.zeros_like(q)
+            desc = i2h.make_desc(ctx['input'].shape[2:4], L.pooling, L.i2o.weight.shape[0], L.output_layer)
+            gb = bufs.setdefault('grads', {})
+            gb.update(dW=prm[0].grad, db=prm[1].grad)
+            if L.output_layer:
+                gb.update(d_outW=prm[2].grad, d_outb=prm[3].grad)
+            ops.conv_lif_backward(desc, i2h.state.eps1, v, pv, g_p, g_o, None, None, L.i2o.weight,
+                                  want_out=L.output_layer, out=gb, open_reduce=open_reduce)
+        return loss
 
     def _grads_into_slab(self):
         """Make the .grad tensors of this slice's trainable parameters views of ONE flat buffer (+ one count element): the

@@ -116,21 +116,58 @@ class ConvNetwork(torch.nn.Module):
         # Under ranks every slice's gradients are ONE slab whose all-reduce starts as soon as its backward is enqueued and
         # runs under the next slice's forward / backward (slice l+1 needs slice l's spikes, not its gradients); the
         # single Adam launch waits for all of them.
-        spikes, learned, pending = x, [], []
-        for s in self.dcll_slices:
-            spikes, _, _, _, _, l = s._learn_forward_backward(spikes, labels, want_loss=False)   # nobody reads the value
-            if l:
-                learned.append(s)
-                if ranks:
-                    pending.append(parallel.allreduce_slab_begin(s._grad_slab, x.shape[0], global_batch))
+        learned, pending = self._learn_tails(self._learn_forwards(x, labels), ranks, x.shape[0], global_batch)
         for h in pending:
             parallel.allreduce_slab_end(h)
         if learned:
-            ops.adam_step([t for s in learned for t in s._adam_tensors()])
+            if ranks:
+                ops.adam_step([t for s in learned for t in s._adam_tensors()])
+            else:
+                self._finish_learning(learned)
             for s in learned:
                 s.dclllayer.weights_written()          # (raw-pointer write: no version counter sees it)
             if len(learned) == len(self.dcll_slices):
                 self._learn_eager_steps[key] = self._learn_eager_steps.get(key, 0) + 1
+
+    def _learn_forwards(self, x, labels, clout_rows=None):
+        """The layer kernels of one learning timestep, slice after slice: the chain the timestep cannot shorten (slice l+1
+        consumes slice l's spikes).  Everything else of the step is left to _learn_tails.  -> per-slice contexts"""
+        spikes, ctxs = x, []
+        for i, s in enumerate(self.dcll_slices):
+            ctx = s._learn_forward(spikes, labels, want_loss=False, defer=True,              # (nobody reads the loss value)
+                                   clout_out=None if clout_rows is None else clout_rows[i])
+            spikes = ctx['out'][0]
+            ctxs.append(ctx)
+        return ctxs
+
+    def _learn_tails(self, ctxs, ranks=False, local_n=0, global_batch=None):
+        """Readouts, local-loss gradients and backward of every slice, behind all layer kernels of the timestep.  Under ranks
+        a slice's gradient slab starts its all-reduce as soon as its backward is enqueued and travels under the next slice's
+        tail.  Single rank: the weight gradients' last reduction stays open — _finish_learning does it for all slices
+        together with the optimizer step.  -> (slices that learned, pending slab handles)"""
+        from .. import parallel
+        learned, pending = [], []
+        for s, ctx in zip(self.dcll_slices, ctxs):
+            s._learn_tail(ctx, open_reduce=not ranks)
+            if ctx['learned']:
+                learned.append(s)
+                if ranks:
+                    pending.append(parallel.allreduce_slab_begin(s._grad_slab, local_n, global_batch))
+        return learned, pending
+
+    @staticmethod
+    def _finish_learning(learned, advance=True, dyn=None):
+        """Single rank: ONE launch reduces the open weight gradients of the slices that learned (fixed order: the gradients
+        in .grad are bit-identical to the per-slice reduction) and applies torch.optim.Adam's update to all their tensors
+        (ops.grad_reduce_adam; output_.* get the plain elementwise update in the same launch)."""
+        tensors, layers = [], []
+        for s in learned:
+            base = len(tensors)
+            tensors += s._adam_tensors(advance=advance)
+            parts = dict(s._learn_bufs['grads']['parts'])
+            parts.update(adam_w=base, adam_b=base + 1)         # (_adam_tensors: i2h.weight, i2h.bias first)
+            layers.append(parts)
+        ops.grad_reduce_adam(layers, tensors, dyn=dyn)
 
     # -- the learning timestep as a captured hipGraph ------------------------------------------------------------------
     # At the reference's small batches (argparse default 64) a learning timestep is ~25 kernel launches of a few
@@ -308,12 +345,9 @@ class ConvNetwork(torch.nn.Module):
             # (thread_local: API calls of other host threads — a data loader pinning memory — do not break the capture)
             if not ranks:
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                    spikes = g['x']
-                    for i, s in enumerate(self.dcll_slices):
-                        spikes, _, _, _, _, l = s._learn_forward_backward(spikes, g['y'], want_loss=False,
-                                                                         clout_out=g['clout'][i])
-                        assert l
-                    ops.adam_step([t for s in self.dcll_slices for t in s._adam_tensors(advance=False)], dyn=g['dyn'])
+                    learned, _ = self._learn_tails(self._learn_forwards(g['x'], g['y'], clout_rows=g['clout']))
+                    assert len(learned) == len(self.dcll_slices)
+                    self._finish_learning(learned, advance=False, dyn=g['dyn'])
             else:
                 # one graph per slice (the slabs' collectives run between them, outside any capture) + one for Adam,
                 # all in one memory pool: a segment's outputs are the next one's inputs

@@ -84,7 +84,7 @@ def _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=None, tau4=None):
 
 
 def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i2o_W=None, i2o_b=None,
-                  out_W=None, out_b=None, want_v=True, out=None, q8=None, stacked=None, finish=None):
+                  out_W=None, out_b=None, want_v=True, out=None, q8=None, stacked=None, finish=None, defer_ro=False):
     """One Conv2dDCLLlayer.forward step (dcll/pytorch_libdcll.py:599-608); state tensors are updated in place.
 
     Returns (s_pooled, p, o, pv_pooled, v) — p / o are None when the corresponding weights are None.
@@ -96,6 +96,9 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     `finish`: dict asking dcll_step_readouts for what follows the readouts of this step — 'clout': True or an int32 (B)
     tensor to write the recorded argmax to; 'target' (B, target) + 'kind': the local-loss gradients — left in `finish` as
     'clout', 'g_p', 'g_o' (only where the fused path serves the shape: finish['done'] says so).
+    `defer_ro` (needs `finish`): where the fused readout tail serves the shape, only the layer kernel is launched now; the
+    readout tail is left in finish['run_readouts'] for the caller to launch later (p / o are unwritten until then) — a
+    learning timestep launches all layer kernels first (layer l+1 needs layer l's spikes, not its readouts).
     """
     out = {} if out is None else out
     B = x.shape[0]
@@ -143,6 +146,10 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
             ptr(s), None, None, ptr(pv), ptr(v), ptr(scratch), opts, B, stream_ptr())
         check(rc, "dcll_conv_lif_step")
         Wt, bias = (i2o_W, i2o_b) if stacked is None else stacked
+        if defer_ro and finish is not None:
+            finish['run_readouts'] = lambda: step_readouts(pv.reshape(B, -1), Wt, bias, desc.target, n2, p, o, scratch=out,
+                                                           finish=finish)
+            return s, p, o, pv, v
         step_readouts(pv.reshape(B, -1), Wt, bias, desc.target, n2, p, o, scratch=out, finish=finish)
         return s, p, o, pv, v
     if (i2o_W is not None and B <= 2048 and _lib.get().dcll_readout_splitk_scratch(B, K_ro, desc.target) > 0 and
@@ -170,9 +177,11 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     return s, p, o, pv, v
 
 
-def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want_out, out=None):
+def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want_out, out=None, open_reduce=False):
     """Gradients of one layer step (dcll_conv_lif_backward) -> (dW, db, d_outW, d_outb).  `out`: optional dict with
-    preallocated 'dW', 'db', 'd_outW', 'd_outb', 'bwd_scratch' (the learning loop writes into the parameters' .grad)."""
+    preallocated 'dW', 'db', 'd_outW', 'd_outb', 'bwd_scratch' (the learning loop writes into the parameters' .grad).
+    `open_reduce`: dcll_conv_lif_backward_open — dW / db are NOT written yet; the partial rows of the weight gradient stay
+    in out['bwd_scratch'] and out['parts'] describes them for grad_reduce_adam, which finishes several layers in one launch."""
     B = eps1.shape[0]
     dev = eps1.device
     out = {} if out is None else out
@@ -204,6 +213,16 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
     if scratch is None or scratch.numel() != n_scratch:
         scratch = out['bwd_scratch'] = torch.empty((n_scratch,), device=dev, dtype=torch.float32)
     c = lambda t: None if t is None else _f32(t, "grad").contiguous()
+    if open_reduce:
+        part, nchunk = ctypes.c_void_p(), ctypes.c_int32()
+        rc = _lib.get().dcll_conv_lif_backward_open(
+            ctypes.byref(desc), ptr(eps1), ptr(v), ptr(pv_pooled), ptr(c(g_p)), ptr(c(g_o) if want_out else None),
+            ptr(c(g_pv)), ptr(c(g_v)), ptr(i2o_W), ptr(d_outW), ptr(d_outb), ptr(scratch), n_scratch, B,
+            ctypes.byref(part), ctypes.byref(nchunk), stream_ptr())
+        check(rc, "dcll_conv_lif_backward_open")
+        out['parts'] = dict(part=part.value, nchunk=nchunk.value, c_out=desc.c_out,
+                            rowlen=desc.c_in * desc.kh * desc.kw + 1, dW=dW, db=db, keep=scratch)
+        return dW, db, d_outW, d_outb
     rc = _lib.get().dcll_conv_lif_backward(
         ctypes.byref(desc), ptr(eps1), ptr(v), ptr(pv_pooled), ptr(c(g_p)), ptr(c(g_o) if want_out else None),
         ptr(c(g_pv)), ptr(c(g_v)), ptr(i2o_W), ptr(dW), ptr(db), ptr(d_outW), ptr(d_outb), ptr(scratch), n_scratch, B,
@@ -675,6 +694,44 @@ def adam_step(tensors, dyn=None):
                   "dcll_adam_step_dyn")
         else:
             check(lib.dcll_adam_step(arr, len(part), stream_ptr()), "dcll_adam_step")
+
+
+def _adam_array(tensors):
+    arr = (_lib.AdamTensor * max(1, len(tensors)))()
+    for a, t in zip(arr, tensors):
+        prm = t["param"]
+        if not prm.is_cuda or not prm.is_contiguous():
+            raise _lib.DCLLHipError("adam: parameters must be contiguous device tensors")
+        for key in ("param", "grad", "exp_avg", "exp_avg_sq"):
+            _expect(t[key], key, torch.float32, numel=prm.numel())
+        a.param, a.grad = prm.data_ptr(), ptr(t["grad"]).value
+        a.exp_avg, a.exp_avg_sq = ptr(t["exp_avg"]).value, ptr(t["exp_avg_sq"]).value
+        a.n, a.step = prm.numel(), int(t["step"])
+        a.lr, a.weight_decay = float(t["lr"]), float(t["weight_decay"])
+        a.beta1, a.beta2, a.eps = float(t["beta1"]), float(t["beta2"]), float(t["eps"])
+    return arr
+
+
+def grad_reduce_adam(layers, tensors, dyn=None):
+    """The end of a learning timestep in one launch (dcll_grad_reduce_adam): `layers` = the out['parts'] of
+    conv_lif_backward(open_reduce=True), each with 'adam_w' / 'adam_b' = index into `tensors` (adam_step's dicts) of the
+    Adam entry of its weight / bias (-1: reduce only); the other tensors get the plain update.  dyn as in adam_step."""
+    if len(layers) > _lib.REDUCE_MAX_LAYERS or len(tensors) > _lib.ADAM_MAX_TENSORS:
+        raise ValueError("grad_reduce_adam: at most %d layers and %d tensors" % (_lib.REDUCE_MAX_LAYERS, _lib.ADAM_MAX_TENSORS))
+    if dyn is not None:
+        _expect(dyn, "dyn", torch.float32, numel=3 * len(tensors))
+    larr = (_lib.GradParts * max(1, len(layers)))()
+    for a, L in zip(larr, layers):
+        _expect(L["dW"], "dW", torch.float32, numel=L["c_out"] * (L["rowlen"] - 1))
+        _expect(L["db"], "db", torch.float32, numel=L["c_out"])
+        a.part, a.dW, a.db = L["part"], ptr(L["dW"]).value, ptr(L["db"]).value
+        a.rowlen, a.nchunk, a.c_out = L["rowlen"], L["nchunk"], L["c_out"]
+        a.adam_w, a.adam_b = int(L.get("adam_w", -1)), int(L.get("adam_b", -1))
+        for idx, key in ((a.adam_w, "dW"), (a.adam_b, "db")):
+            if idx >= 0 and tensors[idx]["grad"].data_ptr() != L[key].data_ptr():
+                raise ValueError("grad_reduce_adam: tensors[%d]['grad'] is not the layer's %s" % (idx, key))
+    check(_lib.get().dcll_grad_reduce_adam(larr, len(layers), _adam_array(tensors), len(tensors), ptr(dyn), stream_ptr()),
+          "dcll_grad_reduce_adam")
 
 
 def cells_to_planes(cells, hw):

@@ -674,6 +674,40 @@ def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
     if out_layer:
         np.testing.assert_allclose(doW.cpu().numpy(), layer.out_w.grad.numpy(), **tol(layer.out_w.grad))
         np.testing.assert_allclose(dob.cpu().numpy(), layer.out_b.grad.numpy(), **tol(layer.out_b.grad))
+    # The open form (dcll_conv_lif_backward_open + dcll_grad_reduce_adam: the last reduction of the weight gradient and the
+    # optimizer step in ONE launch, what ConvNetwork.learn runs): gradients bit-identical to the closed form for every
+    # partial-row count (serial / 4 / 16 groups), parameters and Adam moments bit-identical to dcll_adam_step on them.
+    hp = dict(lr=1e-6, weight_decay=10.0, beta1=0.0, beta2=.95, eps=1e-8)
+    hp2 = dict(lr=1e-4, weight_decay=0.0, beta1=.9, beta2=.999, eps=1e-8)
+
+    def adam_entries(params, grads, hps, step):
+        return [dict(param=q, grad=g_, exp_avg=torch.zeros_like(q), exp_avg_sq=torch.zeros_like(q), step=step, **h)
+                for q, g_, h in zip(params, grads, hps)]
+    names = ["i2h.weight", "i2h.bias"] + (["output_.weight", "output_.bias"] if out_layer else [])
+    hps = [hp, hp] + ([hp2, hp2] if out_layer else [])
+    closed_p = [t[n].clone() for n in names]
+    closed_t = adam_entries(closed_p, [dW, db] + ([doW, dob] if out_layer else []), hps, 3)
+    ops.adam_step(closed_t)
+    out2 = {}
+    dW2, db2, doW2, dob2 = ops.conv_lif_backward(d, eps1, v, pv, r_p.to(dev), None if r_o is None else r_o.to(dev), None, None,
+                                                 t["i2o.weight"], want_out=out_layer, out=out2, open_reduce=True)
+    open_p = [t[n].clone() for n in names]
+    open_t = adam_entries(open_p, [dW2, db2] + ([doW2, dob2] if out_layer else []), hps, 3)
+    ops.grad_reduce_adam([dict(out2['parts'], adam_w=0, adam_b=1)], open_t)
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)
+    if out_layer:
+        assert torch.equal(doW2, doW) and torch.equal(dob2, dob)
+    for a, b_ in zip(closed_t, open_t):
+        for key in ("param", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(a[key], b_[key]), key
+    assert not torch.equal(open_p[0], t["i2h.weight"])
+    # reduce only (no optimizer entries): the gradients alone
+    out3 = {}
+    dW3, db3, _, _ = ops.conv_lif_backward(d, eps1, v, pv, r_p.to(dev), None, None, None, t["i2o.weight"], want_out=False,
+                                           out=out3, open_reduce=True)
+    dW3.fill_(7.0)
+    ops.grad_reduce_adam([dict(out3['parts'])], [])
+    assert torch.equal(dW3, dW) and torch.equal(db3, db)
 
 
 def test_edge_cases_empty_and_single(dev):
