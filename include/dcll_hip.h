@@ -380,7 +380,9 @@ int dcll_readout_splitk(const float *pv, const float *Wt, const float *bias, flo
  *   DCLLClassification.forward :724-728  clout (rows) int32 = argmax of o (of p when N2 == 0), first maximum; NULL = off;
  *   DCLLBase.train_dcll :692-704         target != NULL: g_p, g_o = gradients of the mean local losses of kind `kind`
  *                                        (dcll_local_loss_grad without the loss value; NULL = inference step).
- * p (rows, N1) and o (rows, N2) come out as separate contiguous arrays, bit-identical to dcll_readout_splitk per column.
+ * p (rows, N1) and o (rows, N2) come out as separate contiguous arrays; per column bit-identical to a dcll_readout_splitk call
+ * that splits K into slices of the same width (the slice width follows rows and N1 + N2: for rows <= 512 a call with
+ * N1 <= 32 < N1 + N2 here uses 256-column slices where a call on the N1 columns alone would use 128).
  * Shapes: rows <= 2048, 2048 <= K < 65536, K % 256 == 0, N1 + N2 <= 64, 16-byte aligned pv / Wt — else
  * DCLL_ERR_UNSUPPORTED (callers fall back to dcll_readout + dcll_argmax_vote / dcll_local_loss_grad);
  * scratch_floats >= dcll_step_readouts_scratch(rows, K, N1, N2).

@@ -24,6 +24,7 @@ from torch.utils.data import DataLoader, TensorDataset
 
 RML2016_FILES = ("RML2016.10a_dict.pkl", "RML2016.10a_dict.dat")
 GOLD_2018 = "GOLD_XYZ_OSC.0001_1024.hdf5"
+SPLIT_DONE_BLOCK = (23, 30)             # the reference takes class23_snr30 for "the split has been done" (:23)
 
 
 def open_hdf5(path):
@@ -46,6 +47,17 @@ def split_gold_file(data_dir, log=print):
     Y = np.argmax(np.asarray(f["Y"][:]), axis=1)
     Z = np.asarray(f["Z"][:])[:, 0]
     X = f["X"]
+
+    def write(c, snr, arr):
+        # written under a temporary name and moved into place: a reader never sees a half-written block, and an interrupted
+        # split leaves no file that a later run would take for complete
+        path = os.path.join(data_dir, "class%d_snr%d.npy" % (c, int(snr)))
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        with open(tmp, "wb") as fh:
+            np.save(fh, arr)
+        os.replace(tmp, path)
+        log("Wrote (SNR {z}, class {cl}) data to `{path}`.".format(z=int(snr), cl=c, path=path))
+    last = None                                           # the block whose presence says "split done" (:23) goes last
     for c in range(int(Y.max()) + 1):
         idx = np.nonzero(Y == c)[0]
         if len(idx) == 0:
@@ -54,9 +66,41 @@ def split_gold_file(data_dir, log=print):
         class_x = np.asarray(X[lo:hi])[idx - lo]
         class_z = Z[idx]
         for snr in np.unique(class_z):
-            path = os.path.join(data_dir, "class%d_snr%d.npy" % (c, int(snr)))
-            np.save(path, np.ascontiguousarray(class_x[class_z == snr], dtype=np.float32))
-            log("Wrote (SNR {z}, class {cl}) data to `{path}`.".format(z=int(snr), cl=c, path=path))
+            arr = np.ascontiguousarray(class_x[class_z == snr], dtype=np.float32)
+            if (c, int(snr)) == SPLIT_DONE_BLOCK:
+                last = arr
+            else:
+                write(c, snr, arr)
+    if last is not None:
+        write(SPLIT_DONE_BLOCK[0], SPLIT_DONE_BLOCK[1], last)
+
+
+def _split_done(data_dir):
+    return any(os.path.exists(os.path.join(data_dir, "class%d_snr%d%s" % (SPLIT_DONE_BLOCK + (ext,))))
+               for ext in (".hdf5", ".npy"))
+
+
+def ensure_split(data_dir):
+    """The reference's trigger (:23): the monolithic file is there and no class23_snr30 block yet -> split it.  ONE process
+    does it: under ranks (`--gpus N`: every rank builds its loader) rank 0 splits and the others wait at a barrier; plain
+    processes that share the directory serialise on a lock file and look again once they hold it.  (Unguarded, N ranks made
+    N passes over the 20 GB file at once, each rewriting the same blocks under the others' np.load.)"""
+    if not os.path.exists(os.path.join(data_dir, GOLD_2018)):
+        return
+    from .. import parallel
+    if parallel.is_distributed():
+        import torch.distributed as dist
+        if dist.get_rank() == 0 and not _split_done(data_dir):
+            split_gold_file(data_dir)
+        parallel.barrier()
+        return
+    if _split_done(data_dir):
+        return
+    import fcntl
+    with open(os.path.join(data_dir, ".split.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)                  # (released when the file is closed)
+        if not _split_done(data_dir):
+            split_gold_file(data_dir)
 
 
 def _block_2018(data_dir, class_idx, snr):
@@ -91,9 +135,7 @@ def load_split(data_dir, train, min_snr=6, max_snr=30, per_h5_frac=0.5, train_fr
         get = lambda c, s: table.get((c, s))
     else:
         n_classes = 24
-        if (os.path.exists(os.path.join(data_dir, GOLD_2018)) and
-                not any(os.path.exists(os.path.join(data_dir, "class23_snr30" + ext)) for ext in (".hdf5", ".npy"))):
-            split_gold_file(data_dir)                 # the reference's trigger: no class23_snr30 block yet (:23)
+        ensure_split(data_dir)                        # the reference's trigger: no class23_snr30 block yet (:23)
         get = lambda c, s: _block_2018(data_dir, c, s)
     blocks = []
     for c in range(n_classes):

@@ -20,22 +20,25 @@ class Hdf5Unsupported(RuntimeError):
 
 
 class MiniHdf5:
+    PAGE = 1 << 16                  # metadata is read in 64 KiB pages at the address asked for, a few of them cached
+
     def __init__(self, path):
         self.path = path
+        self._pages = {}
         with open(path, 'rb') as f:
-            self.buf = f.read(1 << 20)          # metadata of the files in question sits in the first few KB
             self.f_size = f.seek(0, 2)
-        if self.buf[:8] != b'\x89HDF\r\n\x1a\n':
+        head = self._bytes(0, 16)
+        if head[:8] != b'\x89HDF\r\n\x1a\n':
             raise Hdf5Unsupported('%s: no HDF5 signature at offset 0' % path)
-        ver = self.buf[8]
+        ver = head[8]
         if ver > 1:
             raise Hdf5Unsupported('%s: superblock version %d (written with libver="latest"?); only 0 / 1' % (path, ver))
-        if self.buf[13] != 8 or self.buf[14] != 8:
-            raise Hdf5Unsupported('%s: offsets / lengths of %d / %d bytes; only 8 / 8' % (path, self.buf[13], self.buf[14]))
+        if head[13] != 8 or head[14] != 8:
+            raise Hdf5Unsupported('%s: offsets / lengths of %d / %d bytes; only 8 / 8' % (path, head[13], head[14]))
         pos = 24 + (4 if ver == 1 else 0)
         self.base = self._u64(pos)
         root_entry = pos + 32                   # base, free-space, end-of-file, driver-info addresses
-        cache_type = struct.unpack_from('<I', self.buf, root_entry + 16)[0]
+        cache_type = struct.unpack('<I', self._bytes(root_entry + 16, 4))[0]
         if cache_type == 1:                     # B-tree / heap addresses cached in the scratch pad
             btree, heap = self._u64(root_entry + 24), self._u64(root_entry + 32)
         else:
@@ -46,72 +49,86 @@ class MiniHdf5:
             btree, heap = struct.unpack_from('<QQ', stab[0])
         self.links = {}
         self._walk_group(btree, self._heap_data(heap))
+        self._pages.clear()
 
     # -- low-level ---------------------------------------------------------------------------------------------------
-    def _need(self, end):
-        if end > len(self.buf):
-            with open(self.path, 'rb') as f:
-                self.buf = f.read(max(end, 2 * len(self.buf)))
+    def _bytes(self, pos, n):
+        """n bytes of the file at pos.  Seek + bounded reads (64 KiB pages around the address, at most 16 cached): an object
+        header, continuation block or symbol-table node that lies BEHIND a 20 GB data block (files whose metadata was
+        written after the data) costs one page, not a read of everything in front of it."""
+        if pos < 0 or pos + n > self.f_size:
+            raise Hdf5Unsupported('%s: truncated file (metadata at %d + %d beyond the end)' % (self.path, pos, n))
+        out = bytearray()
+        first = pos // self.PAGE
+        for pg in range(first, (pos + max(n, 1) - 1) // self.PAGE + 1):
+            page = self._pages.get(pg)
+            if page is None:
+                with open(self.path, 'rb') as f:
+                    f.seek(pg * self.PAGE)
+                    page = f.read(self.PAGE)
+                if len(self._pages) >= 16:
+                    self._pages.pop(next(iter(self._pages)))
+                self._pages[pg] = page
+            out += page
+        off = pos - first * self.PAGE
+        return bytes(out[off:off + n])
 
     def _u64(self, pos):
-        self._need(pos + 8)
-        return struct.unpack_from('<Q', self.buf, pos)[0]
+        return struct.unpack('<Q', self._bytes(pos, 8))[0]
 
     def _heap_data(self, addr):
         addr += self.base
-        self._need(addr + 32)
-        if self.buf[addr:addr + 4] != b'HEAP':
+        head = self._bytes(addr, 32)
+        if head[:4] != b'HEAP':
             raise Hdf5Unsupported('%s: local heap signature missing' % self.path)
-        size, _, data = struct.unpack_from('<QQQ', self.buf, addr + 8)
-        self._need(self.base + data + size)
-        return self.buf[self.base + data:self.base + data + size]
+        size, _, data = struct.unpack_from('<QQQ', head, 8)
+        return self._bytes(self.base + data, size)
 
     def _walk_group(self, addr, heap):
         addr += self.base
-        self._need(addr + 24)
-        if self.buf[addr:addr + 4] != b'TREE' or self.buf[addr + 4] != 0:
+        head = self._bytes(addr, 24)
+        if head[:4] != b'TREE' or head[4] != 0:
             raise Hdf5Unsupported('%s: group B-tree node expected' % self.path)
-        level, used = self.buf[addr + 5], struct.unpack_from('<H', self.buf, addr + 6)[0]
-        self._need(addr + 24 + 16 * used + 8)
+        level, used = head[5], struct.unpack_from('<H', head, 6)[0]
         for k in range(used):
             child = self._u64(addr + 24 + 16 * k + 8)            # key k, child k, key k+1, ...
             if level > 0:
                 self._walk_group(child, heap)
                 continue
             node = child + self.base
-            self._need(node + 8)
-            if self.buf[node:node + 4] != b'SNOD':
+            nh = self._bytes(node, 8)
+            if nh[:4] != b'SNOD':
                 raise Hdf5Unsupported('%s: symbol table node expected' % self.path)
-            n = struct.unpack_from('<H', self.buf, node + 6)[0]
-            self._need(node + 8 + 40 * n)
+            n = struct.unpack_from('<H', nh, 6)[0]
+            entries = self._bytes(node + 8, 40 * n)
             for e in range(n):
-                name_off, header = struct.unpack_from('<QQ', self.buf, node + 8 + 40 * e)
+                name_off, header = struct.unpack_from('<QQ', entries, 40 * e)
                 name = heap[name_off:heap.index(b'\0', name_off)].decode()
                 self.links[name] = header
 
     def _messages(self, addr):
         """(type, data) of every message of a version-1 object header, continuation blocks included."""
         addr += self.base
-        self._need(addr + 16)
-        if self.buf[addr:addr + 4] == b'OHDR':
+        head = self._bytes(addr, 16)
+        if head[:4] == b'OHDR':
             raise Hdf5Unsupported('%s: version-2 object header (libver="latest"); only version 1' % self.path)
-        if self.buf[addr] != 1:
-            raise Hdf5Unsupported('%s: object header version %d' % (self.path, self.buf[addr]))
-        n_msgs = struct.unpack_from('<H', self.buf, addr + 2)[0]
-        blocks = [(addr + 16, struct.unpack_from('<I', self.buf, addr + 8)[0])]
+        if head[0] != 1:
+            raise Hdf5Unsupported('%s: object header version %d' % (self.path, head[0]))
+        n_msgs = struct.unpack_from('<H', head, 2)[0]
+        blocks = [(addr + 16, struct.unpack_from('<I', head, 8)[0])]
         out = []
         while blocks and len(out) < n_msgs:
             pos, size = blocks.pop(0)
-            self._need(pos + size)
-            end = pos + size
-            while pos + 8 <= end and len(out) < n_msgs:
-                mtype, msize = struct.unpack_from('<HH', self.buf, pos)
-                data = self.buf[pos + 8:pos + 8 + msize]
+            blk = self._bytes(pos, size)
+            p = 0
+            while p + 8 <= size and len(out) < n_msgs:
+                mtype, msize = struct.unpack_from('<HH', blk, p)
+                data = blk[p + 8:p + 8 + msize]
                 out.append((mtype, data))
                 if mtype == 0x10:                                 # continuation: (offset, length)
                     o, l = struct.unpack_from('<QQ', data)
                     blocks.append((o + self.base, l))
-                pos += 8 + msize
+                p += 8 + msize
         return out
 
     # -- datasets ----------------------------------------------------------------------------------------------------

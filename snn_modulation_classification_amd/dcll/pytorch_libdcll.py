@@ -403,6 +403,9 @@ class Conv2dDCLLlayer(nn.Module):
         if output_layer:
             self.output_ = nn.Linear(flat, target_size, bias=True)
         self.reset_lc_parameters()
+        if output_layer:
+            self.stacked_readout()              # aliasing established HERE (and in _apply), not lazily inside a forward
+            self._register_state_dict_hook(Conv2dDCLLlayer._unalias_state_dict)
 
     def reset_lc_parameters(self):
         stdv = self.lc_ampl / math.sqrt(self.i2o.weight.size(1))
@@ -478,12 +481,33 @@ class Conv2dDCLLlayer(nn.Module):
                 return 'packed'
         return None
 
+    def _apply(self, fn, *args, **kwargs):
+        """module.to() / .cuda() / .cpu() re-bind every parameter's .data: the readouts' shared storage is re-established
+        right behind it — a defined point, never inside a (possibly captured) forward."""
+        out = super()._apply(fn, *args, **kwargs)
+        if self.output_layer and 'output_' in self._modules:
+            self.__dict__.pop('_stacked', None)
+            self.stacked_readout()
+        return out
+
+    @staticmethod
+    def _unalias_state_dict(module, state_dict, prefix, local_metadata):
+        """state_dict() hands out the readouts' tensors as tensors of their own (contiguous clones), not as offset views of
+        the stacked storage: a checkpoint then holds four independent tensors, like the reference's."""
+        for name in ('i2o.weight', 'i2o.bias', 'output_.weight', 'output_.bias'):
+            t = state_dict.get(prefix + name)
+            if t is not None:
+                state_dict[prefix + name] = t.detach().clone()
+        return state_dict
+
     def stacked_readout(self):
         """(weight (24|48, K), bias) of i2o, with output_ stacked behind it on the output layer — one readout GEMM
         then serves both (reference :602-606).  Free of copies: the two Linear modules' parameters are made VIEWS of one
-        stacked storage (their `.data` re-bound once, values kept), so every later write to them — an in-place torch op,
-        load_state_dict's copy_, dcll_adam_step through the raw pointer — is a write to the stacked matrix; only a re-bind
-        of `.data` (module.to(), .cpu()) breaks the aliasing, which is detected here by address and re-established."""
+        stacked storage (their `.data` re-bound, values kept), so every later write to them — an in-place torch op,
+        load_state_dict's copy_, dcll_adam_step through the raw pointer — is a write to the stacked matrix.  The aliasing is
+        established at the end of __init__ and behind every _apply (to / cuda / cpu re-bind `.data`); should somebody
+        re-bind `.data` by hand, the mismatch is detected here by address and repaired — but never during a stream
+        capture, where the new storage would land in the graph's private pool (round-4 advisor)."""
         if not self.output_layer:
             return self.i2o.weight, self.i2o.bias
         W1, W2, b1, b2 = self.i2o.weight, self.output_.weight, self.i2o.bias, self.output_.bias
@@ -492,6 +516,9 @@ class Conv2dDCLLlayer(nn.Module):
         if not (st is not None and st[0].device == W1.device and W1.data_ptr() == st[0].data_ptr() and
                 W2.data_ptr() == st[0].data_ptr() + 4 * n * K and b1.data_ptr() == st[1].data_ptr() and
                 b2.data_ptr() == st[1].data_ptr() + 4 * n and W2.shape == W1.shape):
+            if W1.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('Conv2dDCLLlayer: the readout parameters were re-bound (.data) since the last step; their '
+                                   'shared storage cannot be re-established inside a stream capture — run one eager step first')
             with torch.no_grad():
                 Wt = torch.cat([W1.detach(), W2.detach()], 0).contiguous()
                 bias = torch.cat([b1.detach(), b2.detach()], 0).contiguous()

@@ -187,15 +187,18 @@ class ConvNetwork(torch.nn.Module):
     GRAPH_MAX_PIXELS = 128 * 256
     GRAPH_TUNE_MAX_PIXELS = 2048 * 256
     TUNE_STEPS = 6
+    TUNE_WINDOWS = 2
 
     def _graph_small(self, x):
         return x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] <= self.GRAPH_MAX_PIXELS
 
     def _graph_tuned(self, path, x, key):
         """Whether this step of `path` ('learn' / 'test') on geometry `key` should be a graph replay.  Small workloads: yes.
-        Mid-size ones: the running job is timed — the first TUNE_STEPS eligible steps eagerly, one replay to take the
-        capture, TUNE_STEPS replays — and the faster form is kept (ties: eager, it has no static-buffer copies).  A step
-        that is not eligible (burn-in, pv statistics) restarts the window it falls into (graph_interrupted)."""
+        Mid-size ones: the running job is timed — TUNE_WINDOWS windows of TUNE_STEPS eligible steps eagerly, one replay to
+        take the capture, the same number of windows of replays — and the faster form (best window of each) is kept; ties:
+        eager, it has no static-buffer copies.  A step that is not eligible (burn-in, pv statistics) restarts the window it
+        falls into (graph_interrupted).  When eager wins the capture, its static buffers and its pinned ring are dropped;
+        the decision is logged."""
         if self._graph_small(x):
             return True
         if not (self.graph_autotune and x.dim() == 4 and
@@ -205,19 +208,30 @@ class ConvNetwork(torch.nn.Module):
         tk = (path, key)
         st = self._graph_tune.get(tk)
         if st is None:
-            st = self._graph_tune[tk] = dict(phase='eager', n=0, t0=0.0, eager_ms=None, graph_ms=None, use_graph=None)
+            st = self._graph_tune[tk] = dict(phase='eager', n=0, w=0, t0=0.0, eager_ms=None, graph_ms=None, use_graph=None)
         if st['use_graph'] is not None:
             return st['use_graph']
         if st['phase'] in ('eager', 'graph') and st['n'] == self.TUNE_STEPS:
             torch.cuda.synchronize(x.device)
             ms = 1e3 * (time.perf_counter() - st['t0']) / self.TUNE_STEPS
-            if st['phase'] == 'eager':
-                st.update(eager_ms=ms, phase='capture', n=0)
-            else:
-                st.update(graph_ms=ms, use_graph=bool(ms < 0.97 * st['eager_ms']))
-                return st['use_graph']
+            which = st['phase'] + '_ms'
+            st[which] = ms if st[which] is None else min(st[which], ms)
+            st['n'], st['w'] = 0, st['w'] + 1
+            if st['w'] == self.TUNE_WINDOWS:
+                if st['phase'] == 'eager':
+                    st.update(phase='capture', w=0)
+                else:
+                    st['use_graph'] = bool(st['graph_ms'] < 0.97 * st['eager_ms'])
+                    import logging
+                    logging.getLogger(__name__).info(
+                        'net.%s %s: eager %.3f ms, hipGraph replay %.3f ms per timestep (best of %d windows of %d) -> %s',
+                        path, key, st['eager_ms'], st['graph_ms'], self.TUNE_WINDOWS, self.TUNE_STEPS,
+                        'replay' if st['use_graph'] else 'eager')
+                    if not st['use_graph']:             # the capture is not going to be replayed again: free it
+                        (self._learn_graphs if path == 'learn' else self._test_graphs).pop(key, None)
+                    return st['use_graph']
         if st['phase'] == 'capture':               # one untimed replay takes the capture
-            st.update(phase='graph', n=0)
+            st.update(phase='graph', n=0, w=0)
             return True
         if st['n'] == 0:
             torch.cuda.synchronize(x.device)

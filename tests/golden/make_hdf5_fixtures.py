@@ -9,6 +9,10 @@ Run with an interpreter that has h5py — in this image:  /opt/conda/bin/python3
                                           int64; ordered by class, SNRs 28 / 30 interleaved within a class; N = 24*2*3, L = 8
   blocks/class{c}_snr{s}.hdf5             per-(class, SNR) files as `h5f.create_dataset('X', data=...)` writes them (:44-50):
                                           24 classes x SNR 28, 30; 5 examples of L = 8
+  late_meta/behind_data.hdf5              metadata BEHIND a data block (round-4 advisor): 'X' (40000, 2) float32 = 320 KB is
+                                          written first, then eleven small datasets — their object headers, the second
+                                          symbol-table node and the grown heap are allocated after X's data (> 64 KiB into
+                                          the file), which a reader that only looks at the head of the file never sees
   expected.npz                            the arrays that went in
 """
 import os
@@ -43,5 +47,13 @@ for c in range(24):
         h5f = h5py.File(os.path.join(OUT, "blocks", "class%d_snr%d.hdf5" % (c, snr)), "w")
         h5f.create_dataset("X", data=x)
         h5f.close()
-np.savez_compressed(os.path.join(OUT, "expected.npz"), X=X, Y=Y, Z=Z, **blocks)
+# metadata behind data
+os.makedirs(os.path.join(OUT, "late_meta"), exist_ok=True)
+late = {"late_X": (np.arange(80000, dtype=np.float32) * 0.25).reshape(40000, 2)}
+with h5py.File(os.path.join(OUT, "late_meta", "behind_data.hdf5"), "w") as f:
+    f.create_dataset("X", data=late["late_X"])
+    for k in range(11):
+        late["late_d%d" % k] = (rng.randint(-5, 5, size=(3, k + 1))).astype(np.int64)
+        f.create_dataset("d%d" % k, data=late["late_d%d" % k])
+np.savez_compressed(os.path.join(OUT, "expected.npz"), X=X, Y=Y, Z=Z, **blocks, **late)
 print("h5py %s, HDF5 %s" % (h5py.__version__, h5py.version.hdf5_version))
