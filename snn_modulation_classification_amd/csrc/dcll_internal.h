@@ -167,6 +167,20 @@ __device__ __forceinline__ float refractory(float pvmem, float &arp, float alpha
     return v;
 }
 
+// (v > 0 ? 1.0f : 0.0f) on a register pair in TWO packed instructions: clamp(clamp(v * 2^127) * 2^127), clamp = the VOP3P
+// clamp to [0, 1].  Exact for every fp32 value a membrane can take — a positive denormal reaches 2^-22 after the first
+// multiplication and 1 after the second (fp32 denormals are on in this build), zeros and negatives clamp to +0
+// (experiments/pk_clamp_probe.hip checks every class on the device).  Replaces 2 v_cmp + 2 v_cndmask in the refractory
+// update s * wrp of the epilogues that share their vector pipe with fp32 MFMAs.
+__device__ __forceinline__ f32x2 spike01_pk(f32x2 v)
+{
+    const f32x2 big = {0x1p127f, 0x1p127f};          // (an SGPR pair: the kernels that use this have no vector register to spare)
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(v), "s"(big));
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(r), "s"(big));
+    return r;
+}
+
 // Buffer-store addressing for the epilogues of the sequence kernels: a 128-bit descriptor (base = a wave-uniform pointer, in
 // SGPRs) + 32-bit scalar or immediate offset + 32-bit lane byte offset — no 64-bit address per store and no address
 // register pairs to keep (or spill) across the time loop.  Offsets must stay below 2^31.

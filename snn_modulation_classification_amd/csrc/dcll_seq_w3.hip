@@ -300,12 +300,14 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
                     constexpr int k = decltype(kc)::value, r = r0 + 2 * k, cr = (r & 3) + 8 * (r >> 2);
                     float vx = acc[r], vy = acc[r + 1];
                     if (REFRACTORY) {       // refractory() of dcll_internal.h on the register pair (packed fp32: same IEEE ops)
-                        const f32x2 al2 = {alpharp, alpharp};
+                        const f32x2 al2 = {alpharp, alpharp}, wrp2 = {wrp, wrp};
                         const f32x2 a2 = al2 * f32x2{arp[r], arp[r + 1]};
                         const f32x2 v2 = f32x2{acc[r], acc[r + 1]} + a2;
                         vx = v2[0], vy = v2[1];
-                        const f32x2 sw2 = {vx > 0.0f ? wrp : 0.0f, vy > 0.0f ? wrp : 0.0f};        // s * wrp, exact
-                        const f32x2 n2 = a2 - sw2;
+                        // arp' = a - s * wrp: s = (v > 0) as 0.0 / 1.0 from two packed clamps (spike01_pk), s * wrp exact, so
+                        // the fused form rounds once, like the reference's subtraction (:503): 5 packed instructions per pair
+                        // (before: 3 + 2 v_cmp + 2 v_cndmask)
+                        const f32x2 n2 = __builtin_elementwise_fma(-spike01_pk(v2), wrp2, a2);
                         arp[r] = n2[0], arp[r + 1] = n2[1];
                         // pinned here: the new arp is not read before the next step, and the compiler would otherwise sink
                         // all 32 updates (cmp, select, subtract) of both tiles to the end of the loop body — v and a of

@@ -398,8 +398,10 @@ class Conv2dDCLLlayer(nn.Module):
         self.i2o = nn.Linear(flat, target_size, bias=True)
         self.i2o.weight.requires_grad = False
         self.i2o.bias.requires_grad = False
-        if lc_dropout is not False:
-            raise NotImplementedError('lc_dropout is not implemented by the HIP path (ConvNetwork passes False)')
+        # dropout on the local readout (reference :572-575, :603): an nn.Dropout module (follows .train() / .eval()) applied to
+        # pvoutput behind the HIP step; while it is active the learning step takes the autograd path (its mask scales g_p)
+        self.lc_dropout = lc_dropout
+        self.dropout = nn.Dropout(p=lc_dropout) if lc_dropout is not False else None
         if output_layer:
             self.output_ = nn.Linear(flat, target_size, bias=True)
         self.reset_lc_parameters()
@@ -441,16 +443,23 @@ class Conv2dDCLLlayer(nn.Module):
                                        self.output_.bias if self.output_layer else None)
             if self.output_layer:
                 s, p, pv, v, o = out
-                return o, p, pv, v
+                return o, self._drop(p), pv, v
             s, p, pv, v = out
-            return s, p, pv, v
+            return s, self._drop(p), pv, v
         # (`_finish`: a slice asks for the step's fused tail — the recorded argmax — DCLLClassification.forward;
         #  `_skip_vmem`: ConvNetwork.test discards the tuple, so the un-pooled membrane map is not written: pvmem = None)
         s, p, o, pv, v = self.i2h._step(input, self.pooling, self.i2o, self.output_ if self.output_layer else None,
                                         stacked=self.stacked_readout() if self.output_layer else None,
                                         finish=self.__dict__.get('_finish'),
                                         want_v=not self.__dict__.get('_skip_vmem', False))
-        return (o if self.output_layer else s), p, pv, v
+        return (o if self.output_layer else s), self._drop(p), pv, v
+
+    def _drop(self, p):
+        return p if self.dropout is None else self.dropout(p)
+
+    def dropout_active(self):
+        """True while pvoutput is really masked: lc_dropout > 0 and the module in training mode."""
+        return self.dropout is not None and self.training and self.dropout.p > 0
 
     def init_hiddens(self, batch_size, init_value=0):
         self.i2h.init_state(batch_size, self.im_dims, init_value=init_value)
@@ -465,7 +474,7 @@ class Conv2dDCLLlayer(nn.Module):
         i = self.i2h
         H, W = self.im_dims
         if not (i.stride == 1 and i.dilation == 1 and i.groups == 1 and i.bias is not None and i.spiking) or \
-                i.tau_per_channel() is None:
+                i.tau_per_channel() is None or self.dropout_active():     # (a masked readout is drawn per step: per-step path)
             return None
         if i.kernel_size == (7, 7) and i.padding == (3, 3) and self.pooling == (1, 1) and i.out_channels <= 32 and \
                 ((H, W) == (16, 16) or (H % 8 == 0 and W % 32 == 0)):         # k_lif_seq_c1/c32 or the tiled c1t/c32t
@@ -707,8 +716,8 @@ class DenseDCLLlayer(nn.Module):
             self.i2o.bias.requires_grad = False
         self.input_size = self.out_channels
         self.reset_lc_parameters()
-        if lc_dropout is not False:
-            raise NotImplementedError('lc_dropout is not implemented by the HIP path')
+        self.lc_dropout = lc_dropout
+        self.dropout = nn.Dropout(p=lc_dropout) if lc_dropout is not False else None       # (reference :238-241, :253)
 
     reset_lc_parameters = Conv2dDCLLlayer.reset_lc_parameters
 
@@ -718,7 +727,7 @@ class DenseDCLLlayer(nn.Module):
     def forward(self, input):
         """-> (output spikes, pvoutput, pv, pvmem)  (reference :250-255)."""
         s, p, pv, v = self.i2h._step(input.reshape(-1, self.in_channels), self.i2o)
-        return s, p, pv, v
+        return s, (p if self.dropout is None else self.dropout(p)), pv, v
 
     def forward_sequence(self, x_seq, want_v=False):
         """`for t: self.forward(x_seq[t])` in one C-ABI call (dcll_dense_lif_sequence): x_seq (T,B,...) -> (output spikes
@@ -853,7 +862,8 @@ class DCLLBase(nn.Module):
         kind = None
         crit, opt = getattr(self, 'crit', None), getattr(self, 'optimizer', None)
         ok = (os.environ.get('DCLL_NATIVE_LEARNING', '1') != '0' and isinstance(self.dclllayer, Conv2dDCLLlayer) and
-              crit is not None and opt is not None and getattr(crit, 'reduction', None) == 'mean')
+              crit is not None and opt is not None and getattr(crit, 'reduction', None) == 'mean' and
+              self.dclllayer.dropout is None)               # (lc_dropout: torch's mask and its gradient, autograd path)
         if ok and type(crit) is nn.SmoothL1Loss and getattr(crit, 'beta', 1.0) == 1.0:
             kind = ops.LOSS_KINDS['SmoothL1Loss']
         elif ok and type(crit) is nn.MSELoss:
@@ -1062,7 +1072,7 @@ class DCLLClassification(DCLLBase):
     def forward(self, input, ignore_burnin=False):
         L = self.dclllayer
         record = ignore_burnin or (self.iter + 1) >= self.burnin
-        fused = (record and isinstance(L, Conv2dDCLLlayer) and
+        fused = (record and isinstance(L, Conv2dDCLLlayer) and not L.dropout_active() and    # (a masked p: argmax after the mask)
                  not (getattr(L, 'build_graph', False) and torch.is_grad_enabled()))      # (not the autograd node)
         if fused:
             L._finish = {'clout': True}         # the step's finishing launch also writes the argmax recorded below
