@@ -4,8 +4,8 @@
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd, mode = sys.argv[1], sys.argv[2]
-tag = {"ref": "ref_b4096", "plane128": "plane128_b64"}.get(mode, "b%s" % mode)
-src = os.path.join(ROOT, "gpurun_out", "%sprof_%s" % (rnd, mode if mode in ("ref", "plane128") else "b" + mode))
+tag = {"ref": "ref_b4096", "plane128": "plane128_b64", "t1024": "t1024_b512"}.get(mode, "b%s" % mode)
+src = os.path.join(ROOT, "gpurun_out", "%sprof_%s" % (rnd, mode if mode in ("ref", "plane128", "t1024") else "b" + mode))
 dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_kernel_stats_%s.csv" % (rnd, tag)))
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
@@ -22,7 +22,7 @@ out = {"command": "rocprofv3 --pmc <one group per pass> --output-format csv -- p
                          "(MI355X_MICROARCH.md, rocprofv3 HBM section)",
        "hot_kernels": hot, "kernels": pmc["kernels"]}
 if hot_prefix == "k_lif_seq_c32d" and hot:
-    out.update(k_lif_seq_c32_batch=int(mode), k_lif_seq_c32_kernel=hot[0],
+    out.update(k_lif_seq_c32_batch=512 if mode == "t1024" else int(mode), k_lif_seq_c32_kernel=hot[0],
                k_lif_seq_c32_traffic_bytes_per_launch=pmc["kernels"][hot[0]]["hbm_bytes_per_launch"])
 json.dump(out, open(os.path.join(dst, "%s_pmc_%s.json" % (rnd, tag)), "w"), indent=1)
 print("wrote profiles/%s_*_%s" % (rnd, tag))

@@ -1568,3 +1568,24 @@ def test_lc_dropout_on_the_local_readout():
     assert float((p_eval == 0).float().mean()) < 0.2
     D.train()
     assert 0.1 < float((D.forward(xd)[1] == 0).float().mean()) < 0.9
+
+
+def test_entry_points_at_the_reference_scripts_sequence_length(tmp_path):
+    """The recorded configuration of the reference runs 1024 timesteps per window (scripts/test_radio_ml.sh:17-18,
+    scripts/train_radio_ml.sh:20-23; also the argparse default, train.py:63-66): test_radio_ml.py with its DEFAULT
+    --n_iters_test (fused sequence path == per-step path, accuracy for accuracy) and one train.py step with its default
+    --n_iters (burn-in 20 on the sequence kernels + 1004 learning timesteps), evaluation and checkpoint included."""
+    import test_radio_ml
+    import train
+    assert train.parse_args([]).n_iters == 1024 == train.parse_args([]).n_iters_test
+    common = ['--I_resolution', '16', '--Q_resolution', '16', '--arp', '1.0', '--burnin', '20', '--batch_size_test', '16',
+              '--n_test_samples', '16', '--synthetic', '16', '--min_snr', '10', '--max_snr', '12']
+    a = test_radio_ml.main(common + ['--out_dir', str(tmp_path / 'seq')])
+    b = test_radio_ml.main(common + ['--out_dir', str(tmp_path / 'step'), '--no_sequence_path'])
+    assert np.asarray(a).shape == (2, 3) and np.array_equal(np.asarray(a), np.asarray(b))
+    out_dir = train.main(common + ['--batch_size', '16', '--n_steps', '1', '--n_test_interval', '1', '--output',
+                                   str(tmp_path / 'results'), '--learning_rates', '1e-7'])
+    sd = torch.load(os.path.join(out_dir, 'parameters_0.pth'))
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    acc = np.load(os.path.join(out_dir, 'acc_test.npy'))
+    assert acc.shape[-1] == 3 and np.isfinite(acc).all()
