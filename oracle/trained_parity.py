@@ -68,21 +68,22 @@ def restore_pair(ckpt, batch, device='cuda'):
     return net, ref, convs, IQEncoder(R, R, device=device)
 
 
-def held_out_batches(n_batches, batch, seed=4242, snrs=tuple(range(6, 32, 2))):
+def held_out_batches(n_batches, batch, seed=4242, snrs=tuple(range(6, 32, 2)), length=T_STEPS):
     """`n_batches` batches of the synthetic modulation set the training run has not seen (its batches are seeded
     seed + 7919 * (step + 1), these 4242 + ...), cycling through the SNRs test_radio_ml.py evaluates (:114)."""
     from test_radio_ml import synthetic_modulation_batches
     out = []
     for i in range(n_batches):
         snr = int(snrs[i % len(snrs)])
-        out.append(synthetic_modulation_batches(batch, batch, snr, T_STEPS, seed + 31 * i)[0] + (snr,))
+        out.append(synthetic_modulation_batches(batch, batch, snr, length, seed + 31 * i)[0] + (snr,))
     return out
 
 
-def evaluate(net, ref, enc, batches, count_flips=True, log=None):
+def evaluate(net, ref, enc, batches, count_flips=True, log=None, T=None):
     """Both paths over the same windows, zero neuron state per batch (as bench.py's step; the flip classification needs
-    it).  -> report dict"""
+    it); T timesteps per window (default 128; the windows must be at least that long).  -> report dict"""
     from oracle import flip_count
+    T_STEPS = globals()['T_STEPS'] if T is None else int(T)
     L = len(net.dcll_slices)
     n = 0
     correct_gpu, correct_cpu, agree = np.zeros(L), np.zeros(L), np.zeros(L)

@@ -942,6 +942,29 @@ class _Writer:
         self.scalars[name] = float(value)
 
 
+@pytest.mark.timeout(1200)
+def test_top1_parity_on_trained_weights_at_the_scripts_1024_timesteps(trained_checkpoint, capsys):
+    """The trained-weights comparison at the reference's own sequence length (n_iters_test = 1024, scripts/test_radio_ml.sh:17-18):
+    256 held-out modulation windows of 1024 samples (SNR 10 / 20 dB), the restored network on the fused HIP path and on the CPU
+    reference path (oracle/torch_ref.py) for all 1024 steps.  Eight times as many steps for a tie-break to occur in as at
+    T = 128: votes must still agree, top-1 must be the reference's, and every window's first flip must sit inside the
+    rounding band."""
+    from oracle import trained_parity
+    B, T = 128, 1024
+    net, ref, convs, enc = trained_parity.restore_pair(trained_checkpoint, B)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    batches = trained_parity.held_out_batches(2, B, seed=5151, snrs=(10, 20), length=T)
+    assert batches[0][0].reshape(B, 2, -1).shape[-1] == T
+    rep = trained_parity.evaluate(net, ref, enc, batches, count_flips=True, T=T)
+    with capsys.disabled():
+        print("\n[top-1 on trained weights at T = 1024, fused HIP path vs reference CPU path] %s" % json.dumps(rep))
+    assert rep["windows"] == 2 * B and rep["spike_flips"]["steps"] == T
+    assert min(rep["top1_gpu"][1:]) > 5 * rep["chance"]
+    assert max(rep["top1_abs_diff"]) <= 1.0 / (2 * B) + 1e-12, rep            # at most one window of 256
+    assert min(rep["vote_agreement_per_layer"]) >= 0.99 and rep["output_layer_per_step_argmax_agreement"] >= 0.999, rep
+    assert rep["spike_flips"]["first_flips_outside_rounding_band"] == 0, rep["spike_flips"]
+
+
 @pytest.mark.parametrize("R_,T,B", [(16, 65, 6), (32, 41, 2)])
 def test_fused_path_fills_pv_activity_statistics(R_, T, B, capsys):
     """The pv low / high activity counters (DCLLBase.forward :658-661, write_stats :678-688) of the fused sequence path
