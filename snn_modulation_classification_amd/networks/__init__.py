@@ -641,6 +641,13 @@ class ConvNetwork(torch.nn.Module):
         s0, stot = (0, B) if shard is None else (int(shard[0]), int(shard[1]))
         per_sample = 4 * T * max(s.dclllayer.out_channels * int(np.prod(s.dclllayer.output_shape)) for s in self.dcll_slices)
         chunk = max(1, min(B, int(self.pv_budget_bytes // max(per_sample, 1))))
+        if chunk < B and dev.type == 'cuda' and os.environ.get('DCLL_CHUNK_ROUND', '1') != '0':
+            # the 32 -> 32 layer kernels run one workgroup per sample and one workgroup per CU: a chunk that is not a multiple
+            # of the CU count ends in a partly filled generation.  (The default 24 GiB lands on multiples by itself — 6144
+            # windows at T = 128, 768 at T = 1024 — other budgets need not: 20 GB at T = 1024 = 596 = 256 + 256 + 84.)
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            if chunk >= ncu:
+                chunk -= chunk % ncu
         if chunk < B:
             for s in self.dcll_slices:
                 if s.dclllayer.i2h.state is None or s.dclllayer.i2h.state.eps0.shape[0] != B:

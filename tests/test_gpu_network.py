@@ -244,7 +244,7 @@ def test_t1024_fused_sequence_vs_oracle_and_per_step():
 
 def test_t1024_batch1024_runs_in_pv_budget_chunks():
     """T = 1024 at batch 1024: one layer's pv buffer would be 34 GB (33.5 MB per window), so the sequence path runs in
-    chunks under net.pv_budget_bytes (default 24 GB: 716 + 308 windows).  Votes, per-step argmax, logits, statistics and the
+    chunks under net.pv_budget_bytes (default 24 GiB: 768 + 256 windows).  Votes, per-step argmax, logits, statistics and the
     final state do not depend on the budget (8 GB: five chunks), the statistics have dcll_pv_lowhigh_steps rows, and a
     sample's results do not depend on the batch around it (a shard of 64 windows)."""
     from snn_modulation_classification_amd import ops
