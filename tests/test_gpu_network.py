@@ -188,6 +188,36 @@ def test_sequence_path_chunks_large_batches():
         assert torch.equal(ra["o"], rb["o"])
 
 
+def test_t1024_sequence_path_reproduces_the_reference_run(golden):
+    """Fixture g2_radio_r16_t1024_b2 (generated by importing the reference: radio_ml_conv.yaml, 16x16, two raw IQ windows of
+    1024 samples, all 1024 timesteps = the reference's n_iters_test default and script setting): the fused path — raw IQ
+    through the encoder inside the first layer's kernel — gives the REFERENCE's spike trains of all three layers bit for
+    bit over all 1024 steps, its readouts within 1e-4, its per-step argmax, votes, accuracy, and its final neuron state."""
+    from test_host_logic import _check_against_r32_fixture
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    g = golden("g2_radio_r16_t1024_b2.npz")
+    net = _radio_net(2, 16)
+    _check_against_r32_fixture(net, g)
+    T, B = g["cells"].shape
+    enc = IQEncoder(16, 16, device='cuda')
+    net.reset()
+    np.random.seed(3)                                           # the reference's crop draw (L == T: start 0)
+    res = net.test_sequence(iq=torch.from_numpy(g["iq"]).cuda(), encoder=enc, T=T, keep_spikes=True)
+    for i in range(3):
+        ref_words = g["spikes/%d" % i].view(np.int32).reshape(T, B, 32, 8)
+        got = res["spikes"][i].cpu().numpy()
+        assert np.array_equal(got, ref_words), "layer %d: %d spike words differ from the reference" % (i, int((got != ref_words).sum()))
+        np.testing.assert_allclose(res["logits"][i].cpu().numpy(), g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+        assert np.array_equal(np.array(net.dcll_slices[i].clout), g["clout/%d" % i])
+        assert np.array_equal(res["vote"][i].cpu().numpy(), g["vote/%d" % i])
+        st = net.dcll_slices[i].dclllayer.i2h.state
+        for nm in ("eps0", "eps1", "arp"):
+            assert np.array_equal(getattr(st, nm).cpu().numpy().view(np.uint32), g["final/%d/%s" % (i, nm)].view(np.uint32)), (i, nm)
+    np.testing.assert_allclose(res["o"].cpu().numpy(), g["o_last"], atol=LOGIT_TOL, rtol=0)
+    y = _one_hot_labels(g["labels"], T, 24)
+    assert net.accuracy(y) == list(g["acc"])
+
+
 def test_t1024_fused_sequence_vs_oracle_and_per_step():
     """The reference's OWN sequence length: n_iters / n_iters_test default to 1024 (train.py:63-66), the recorded scripts
     run 1024 (scripts/train_radio_ml.sh:20-23, scripts/test_radio_ml.sh:17-18) and RadioML-2018 windows are 1024 samples

@@ -225,6 +225,55 @@ def test_seeded_network_and_oracle_on_32x32_plane(golden, cpu_device):
         assert np.array_equal(ref.votes()[i], g["vote/%d" % i])
 
 
+def test_seeded_network_and_both_oracles_on_the_t1024_fixture(golden, cpu_device):
+    """Fixture g2_radio_r16_t1024_b2 — the imported reference at ITS OWN sequence length (n_iters_test = 1024, train.py:63-66,
+    scripts/test_radio_ml.sh:17-18): the seeded constructor reproduces the reference's network; the torch oracle reproduces all
+    1024 steps bit for bit (spikes, readouts, argmax, votes); and the pinned-order C oracle, free-running from the same
+    input, reproduces EVERY spike of the 3 x 2 x 8192 x 1024 neuron-steps and the final state (the fixture's IQ seed was
+    searched for exactly that: no |v| inside the rounding band of the two summation orders)."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from snn_modulation_classification_amd.data.utils import iq2cells
+    from oracle import c_oracle as C
+    from oracle import torch_ref as R
+    g = golden("g2_radio_r16_t1024_b2.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(), (1, 16, 16), 2, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    _check_against_r32_fixture(net, g)                       # (conv tensors element for element, readouts by checksum)
+    cells = g["cells"]
+    T, B = cells.shape
+    assert (T, B) == (1024, 2)
+    np.random.seed(3)
+    mine, t0 = iq2cells(torch.from_numpy(g["iq"]), out_w=16, out_h=16, max_duration=T)
+    assert t0 == 0 and np.array_equal(mine.numpy(), cells)  # the host encoder on the fixture's raw IQ windows of 1024 samples
+    sds = [{k: v.detach().clone() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
+    ref = R.RefConvNetwork(sds, [dict(padding=3, pooling=1)] * 3, 1.0)
+    orc = C.OracleConvNetwork([{k: v.numpy() for k, v in sd.items()} for sd in sds], convs, (16, 16), 1.0)
+    torch.set_num_threads(1)
+    worst = 0.0
+    for step in range(T):
+        x = torch.zeros(B, 1, 256)
+        x[torch.arange(B), 0, torch.from_numpy(cells[step]).long()] = 1.0
+        x = x.reshape(B, 1, 16, 16)
+        outs = ref.test(x)
+        oo = orc.step(x.numpy())
+        for i, (o, p, pv, v) in enumerate(outs):
+            bits = np.unpackbits(g["spikes/%d" % i][step], axis=-1, bitorder="little")
+            assert np.array_equal((v > 0).float().reshape(B, -1).numpy(), bits), ("torch oracle", step, i)
+            assert np.array_equal(p.numpy(), g["p/%d" % i][step]), (step, i)
+            assert np.array_equal(oo[i]["s"].reshape(B, -1), bits), ("C oracle: spike flip", step, i)
+            worst = max(worst, float(np.abs(oo[i]["p"] - g["p/%d" % i][step]).max()))
+        assert np.array_equal(outs[-1][0].numpy(), g["o_last"][step])
+    assert worst <= 1e-4
+    for i in range(3):
+        assert np.array_equal(np.array(ref.clout[i]), g["clout/%d" % i]) and np.array_equal(ref.votes()[i], g["vote/%d" % i])
+        for j, nm in enumerate(("eps0", "eps1", "arp")):
+            assert np.array_equal(orc.layers[i].state[j].view(np.uint32), g["final/%d/%s" % (i, nm)].view(np.uint32)), (i, nm)
+
+
 def test_mnist_network_shapes(golden, cpu_device):
     from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
     g = golden("g2_mnist_t50_b4.npz")
