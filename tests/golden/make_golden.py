@@ -12,6 +12,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-g9  # only the checkpoint fixture (added in round 2)
     python tests/golden/make_golden.py --only-g6b # only the production-geometry learning fixture (added in round 5)
     python tests/golden/make_golden.py --only-t1024 # only the T = 1024 rollout (added in round 5)
+    python tests/golden/make_golden.py --only-refyaml # only the radio_ml_conv_ref.yaml rollout (added in round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -122,10 +123,12 @@ def synth_iq(B, L=128, s=1):
     return 0.4 * torch.randn(B, 2, 1, L, generator=g)
 
 
-def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.0, store_readouts=True, L=128, iq_seed=1):
+def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.0, store_readouts=True, L=128, iq_seed=1,
+            hw=None, store_final=True):
     convs = nets.load_network_spec(os.path.join(REF, "networks", yaml_name))
     seed(1)
-    net = nets.ConvNetwork(args, (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+    H, Wd = (R, R) if hw is None else hw
+    net = nets.ConvNetwork(args, (1, H, Wd), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
                            opt_param={}, learning_rates=None, burnin=20)
     net.reset(True)
     if weight_gain != 1.0:
@@ -136,7 +139,7 @@ def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.
     labels = torch.randint(0, 24, (B,), generator=torch.Generator().manual_seed(2))
     y1h = du.to_one_hot(labels, 24)
     np.random.seed(3)
-    spikes, targets = du.iq2spiketrain(x, y1h, out_w=R, out_h=R, max_duration=T)
+    spikes, targets = du.iq2spiketrain(x, y1h, out_w=Wd, out_h=H, max_duration=T)
     xin = torch.Tensor(spikes)
     out = {}
     for i, s in enumerate(net.dcll_slices):
@@ -196,10 +199,15 @@ def rollout(lib, nets, du, yaml_name, R, T, B, args, full_traces, weight_gain=1.
     out["confusion"] = conf
     for k, vlist in traces.items():
         out[k] = np.stack(vlist)
-    # final neuron state (for the state-carry-over quirk Q3)
+    # final neuron state (for the state-carry-over quirk Q3); large planes: float64 checksums instead
     for i, s in enumerate(net.dcll_slices):
         for j, nm in enumerate(s.dclllayer.i2h.state._fields):
-            out["final/%d/%s" % (i, nm)] = npy(s.dclllayer.i2h.state[j])
+            st = npy(s.dclllayer.i2h.state[j])
+            if store_final:
+                out["final/%d/%s" % (i, nm)] = st
+            else:
+                w = st.astype(np.float64)
+                out["finalsum/%d/%s" % (i, nm)] = np.array([w.sum(), np.abs(w).sum(), w.reshape(-1)[::997].sum()])
     return out
 
 
@@ -238,6 +246,25 @@ def g2_t1024(lib, nets, du):
     r.pop("minabs_v")
     np.savez_compressed(os.path.join(OUT, "g2_radio_r16_t1024_b2.npz"), **r)
     return dict(R=16, T=1024, B=2, L=1024, iq_seed=852)
+
+
+def g2_ref_yaml(lib, nets, du):
+    """networks/radio_ml_conv_ref.yaml THROUGH THE DCLL BUILDER (ConvNetwork; the network of BASELINE config 5 before this
+    build's int8 quantisation): seven layers of 64 channels, kernels (1,3), padding (0,1), max-pool (1,2), on a Q = 16 x I = 128
+    plane — the reference can build it there (at 16x16 the width reaches 0 after four poolings).  fp32 weights as the
+    reference initialises them, B = 2, T = 64, free-running: pooled packed spikes of all seven layers, readouts, argmax, votes.
+    Pins the (1,3) / pooling kernels (k_lif_seq_w3, per-step path) against the reference itself; the int8 form of config 5 is
+    then tied to it by "int8 through the ABI == the dequantised fp32 run" (no reference counterpart: parity unpinned)."""
+    r = rollout(lib, nets, du, "radio_ml_conv_ref.yaml", R=None, T=64, B=2, args=make_args(), full_traces=False,
+                store_readouts=False, hw=(16, 128), store_final=False)
+    # the time constants are per-input-channel values broadcast over the plane (:398-405): stored per channel
+    for k in list(r):
+        if k.startswith("sd/") and k.split(".")[-1] in ("alpha", "tau_m__dt", "alphas", "tau_s__dt"):
+            a = r[k]
+            assert np.array_equal(a, np.broadcast_to(a[:, :1, :1], a.shape))
+            r[k] = np.ascontiguousarray(a[:, 0, 0])
+    np.savez_compressed(os.path.join(OUT, "g2_ref_yaml_h16_w128_t64_b2.npz"), **r)
+    return dict(H=16, W=128, T=64, B=2, layers=7)
 
 
 def g2_mnist(lib, nets, du):
@@ -544,6 +571,13 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-refyaml" in sys.argv:
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["g2_ref_yaml"] = g2_ref_yaml(lib, nets, du)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, default=lambda o: list(o))
+        return
     if "--only-t1024" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -575,6 +609,7 @@ def main():
         "g2_r32": g2_r32(lib, nets, du),
         "g2_mnist": g2_mnist(lib, nets, du),
         "g2_t1024": g2_t1024(lib, nets, du),
+        "g2_ref_yaml": g2_ref_yaml(lib, nets, du),
         "g5": {k: [{kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in d.items()} for d in v]
                for k, v in g5_specs(nets).items()},
     }

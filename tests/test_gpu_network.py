@@ -1434,6 +1434,68 @@ def test_ref_yaml_network_fused_sequence_equals_per_step_and_oracle():
     assert res["vote"][6].shape == (B,)
 
 
+def test_ref_yaml_network_reproduces_the_reference_run(golden):
+    """Fixture g2_ref_yaml_h16_w128_t64_b2 (generated by importing the reference): networks/radio_ml_conv_ref.yaml — the
+    network of BASELINE config 5 — built by the REFERENCE's DCLL builder on the Q = 16 x I = 128 plane, fp32 weights, B = 2,
+    T = 64.  The fused (1,3) kernels (k_lif_seq_w3 per layer) give the REFERENCE's pooled spike trains of all seven layers bit
+    for bit, its readouts within 1e-4, its per-step argmax and votes; so does the per-step path.  (The int8 form of config 5
+    is tied to this by tests/test_gpu_abi_v3.py — int8 through the ABI == the run on the dequantised fp32 tensors, bit for
+    bit, for every kernel family: the chain reference -> fp32 kernels -> int8 kernels has no unpinned link except the
+    quantisation rule itself, which the reference does not define.)"""
+    from test_host_logic import _check_against_r32_fixture
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from snn_modulation_classification_amd import ops, quant
+    g = golden("g2_ref_yaml_h16_w128_t64_b2.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv_ref.yaml"))
+    H, W = 16, 128
+    T, B = g["cells"].shape
+
+    def make():
+        torch.manual_seed(1)
+        np.random.seed(1)
+        net = ConvNetwork(_args(), (1, H, W), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
+                          learning_rates=None, burnin=20)
+        net.reset(True)
+        return net
+    seq, stp = make(), make()
+    _check_against_r32_fixture(seq, g, n_layers=7)
+    assert seq.sequence_supported() and all(s.dclllayer.i2h.int8_weights() is None for s in seq.dcll_slices)
+    cells = torch.from_numpy(g["cells"]).cuda()
+    seq.reset()
+    res = seq.test_sequence(cells, keep_spikes=True)
+    for i in range(7):
+        if i < 6:       # (the output layer's 16 pooled pixels per channel are half a spike word: nothing consumes them, they are
+                        #  not packed; its spikes are pinned through its refractory state below)
+            nw = 64 * (H * (W >> (i + 1))) // 32               # pooled spike words per sample
+            ref_words = g["spikes/%d" % i].view(np.int32).reshape(T, B, -1)
+            got = res["spikes"][i].cpu().numpy().reshape(T, B, -1)
+            assert got.shape[-1] == nw == ref_words.shape[-1], (i, got.shape, ref_words.shape)
+            assert np.array_equal(got, ref_words), "layer %d: %d spike words differ from the reference" % (i, int((got != ref_words).sum()))
+        np.testing.assert_allclose(res["logits"][i].cpu().numpy(), g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+        assert np.array_equal(np.array(seq.dcll_slices[i].clout), g["clout/%d" % i])
+        assert np.array_equal(res["vote"][i].cpu().numpy(), g["vote/%d" % i])
+    np.testing.assert_allclose(res["o"].cpu().numpy(), g["o_last"], atol=LOGIT_TOL, rtol=0)
+    # the per-step path (the literal .forward drop-in) on the same input
+    planes = ops.cells_to_planes(cells, H * W).reshape(T, B, 1, H, W)
+    stp.reset()
+    for t in range(T):
+        cur = planes[t]
+        for i, s in enumerate(stp.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            if i < 6:
+                bits = np.unpackbits(g["spikes/%d" % i][t], axis=-1, bitorder="little")
+                assert np.array_equal(o.reshape(B, -1).cpu().numpy(), bits[:, :o[0].numel()]), (t, i)
+            np.testing.assert_allclose(p.cpu().numpy(), g["p/%d" % i][t], atol=LOGIT_TOL, rtol=0)
+            cur = o
+    for i in range(7):
+        for nm in ("eps0", "eps1", "arp"):
+            assert torch.equal(getattr(seq.dcll_slices[i].dclllayer.i2h.state, nm), getattr(stp.dcll_slices[i].dclllayer.i2h.state, nm))
+        for nm in ("eps0", "eps1", "arp"):
+            st = getattr(seq.dcll_slices[i].dclllayer.i2h.state, nm).cpu().numpy().astype(np.float64)
+            want = g["finalsum/%d/%s" % (i, nm)]
+            np.testing.assert_allclose([st.sum(), np.abs(st).sum(), st.reshape(-1)[::997].sum()], want, rtol=1e-12, atol=1e-12)
+
+
 def test_restoring_a_reference_written_checkpoint(golden):
     """test_radio_ml.py's restore protocol (:104-110) on a .pth the REFERENCE wrote (fixture G9): load_state_dict ->
     reset(True) -> T steps; the per-step path and the fused path reproduce the reference's own run after its restore:
