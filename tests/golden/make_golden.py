@@ -13,6 +13,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-g6b # only the production-geometry learning fixture (added in round 5)
     python tests/golden/make_golden.py --only-t1024 # only the T = 1024 rollout (added in round 5)
     python tests/golden/make_golden.py --only-refyaml # only the radio_ml_conv_ref.yaml rollout (added in round 5)
+    python tests/golden/make_golden.py --only-r128 # only the 128x128-plane rollout (added in round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -265,6 +266,23 @@ def g2_ref_yaml(lib, nets, du):
             r[k] = np.ascontiguousarray(a[:, 0, 0])
     np.savez_compressed(os.path.join(OUT, "g2_ref_yaml_h16_w128_t64_b2.npz"), **r)
     return dict(H=16, W=128, T=64, B=2, layers=7)
+
+
+def g2_r128(lib, nets, du):
+    """radio_ml_conv.yaml on the ARGPARSE-DEFAULT 128x128 plane (train.py:37-40, test_radio_ml.py:52-53): B = 2, T = 12,
+    free-running reference spikes / readouts / argmax / votes (the 32x32 fixture covers every tile-edge combination of the
+    tiled kernels; this one the default geometry itself: 64 tiles per layer, interior tiles included).  Readout matrices
+    (3 x 50 MB) and final state as float64 checksums."""
+    r = rollout(lib, nets, du, "radio_ml_conv.yaml", R=128, T=12, B=2, args=make_args(), full_traces=False,
+                store_readouts=False, store_final=False)
+    for k in list(r):
+        if k.startswith("sd/") and k.split(".")[-1] in ("alpha", "tau_m__dt", "alphas", "tau_s__dt"):
+            a = r[k]
+            assert np.array_equal(a, np.broadcast_to(a[:, :1, :1], a.shape))
+            r[k] = np.ascontiguousarray(a[:, 0, 0])
+    r.pop("minabs_v")
+    np.savez_compressed(os.path.join(OUT, "g2_radio_r128_t12_b2.npz"), **r)
+    return dict(R=128, T=12, B=2)
 
 
 def g2_mnist(lib, nets, du):
@@ -571,6 +589,13 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-r128" in sys.argv:
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["g2_r128"] = g2_r128(lib, nets, du)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, default=lambda o: list(o))
+        return
     if "--only-refyaml" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -610,6 +635,7 @@ def main():
         "g2_mnist": g2_mnist(lib, nets, du),
         "g2_t1024": g2_t1024(lib, nets, du),
         "g2_ref_yaml": g2_ref_yaml(lib, nets, du),
+        "g2_r128": g2_r128(lib, nets, du),
         "g5": {k: [{kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in d.items()} for d in v]
                for k, v in g5_specs(nets).items()},
     }

@@ -350,6 +350,47 @@ def test_tiled_sequence_path_reproduces_reference_run_32x32(golden):
     assert np.array_equal(net2.confusion_matrix(y), g["confusion"])
 
 
+def test_default_128x128_plane_reproduces_the_reference_run(golden):
+    """Fixture g2_radio_r128_t12_b2 (generated by importing the reference): radio_ml_conv.yaml on the reference's
+    ARGPARSE-DEFAULT 128x128 I/Q plane, B = 2, T = 12.  The tiled all-T kernels (k_lif_seq_c1t / k_lif_seq_c32t, 64 tiles per
+    layer) and the per-step path (k_trace4 + k_lif_step_c32t) give the REFERENCE's spike trains bit for bit, its readouts
+    within 1e-4, its per-step argmax and votes; final state by its float64 checksums."""
+    from test_host_logic import _check_against_r32_fixture
+    from snn_modulation_classification_amd import ops
+    g = golden("g2_radio_r128_t12_b2.npz")
+    seq, stp = _radio_net(2, 128), _radio_net(2, 128)
+    _check_against_r32_fixture(seq, g)
+    cells = torch.from_numpy(g["cells"]).cuda()
+    T, B = cells.shape
+    seq.reset()
+    res = seq.test_sequence(cells, keep_spikes=True)
+    for i in range(3):
+        ref_words = g["spikes/%d" % i].view(np.int32).reshape(T, B, 32, 128 * 128 // 32)
+        got = res["spikes"][i].cpu().numpy()
+        assert np.array_equal(got, ref_words), "layer %d: %d spike words differ from the reference" % (i, int((got != ref_words).sum()))
+        np.testing.assert_allclose(res["logits"][i].cpu().numpy(), g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+        assert np.array_equal(np.array(seq.dcll_slices[i].clout), g["clout/%d" % i])
+        assert np.array_equal(res["vote"][i].cpu().numpy(), g["vote/%d" % i])
+    np.testing.assert_allclose(res["o"].cpu().numpy(), g["o_last"], atol=LOGIT_TOL, rtol=0)
+    planes = ops.cells_to_planes(cells, 128 * 128).reshape(T, B, 1, 128, 128)
+    stp.reset()
+    for t in range(T):
+        cur = planes[t]
+        for i, s in enumerate(stp.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            if i < 2:
+                bits = np.unpackbits(g["spikes/%d" % i][t], axis=-1, bitorder="little")
+                assert np.array_equal(o.reshape(B, -1).cpu().numpy(), bits), (t, i)
+            np.testing.assert_allclose(p.cpu().numpy(), g["p/%d" % i][t], atol=LOGIT_TOL, rtol=0)
+            cur = o
+    for net in (seq, stp):
+        for i in range(3):
+            for nm in ("eps0", "eps1", "arp"):
+                st = getattr(net.dcll_slices[i].dclllayer.i2h.state, nm).cpu().numpy().astype(np.float64)
+                np.testing.assert_allclose([st.sum(), np.abs(st).sum(), st.reshape(-1)[::997].sum()],
+                                           g["finalsum/%d/%s" % (i, nm)], rtol=1e-12, atol=1e-12)
+
+
 def test_config5_int8_weights_and_packed_spikes():
     """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code => parity unpinned):
     radio_ml_conv_ref.yaml with per-channel int8 conv weights and 1-bit packed inter-layer spikes.  What can be pinned:

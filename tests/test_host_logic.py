@@ -240,6 +240,46 @@ def test_seeded_ref_yaml_network_and_both_oracles_on_the_reference_run(golden, c
         assert np.array_equal(np.array(ref.clout[i]), g["clout/%d" % i]) and np.array_equal(ref.votes()[i], g["vote/%d" % i])
 
 
+def test_seeded_network_and_both_oracles_on_the_default_128x128_plane(golden, cpu_device):
+    """Fixture g2_radio_r128_t12_b2: the reference on its ARGPARSE-DEFAULT I/Q plane (128x128; train.py:37-40), B = 2, T = 12.
+    Seeded constructor == the reference's network (conv tensors element for element, the 50 MB readout matrices by
+    checksum); torch oracle == the run bit for bit; C oracle == every spike (0 flips), readouts within 1e-4."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from oracle import c_oracle as C
+    from oracle import torch_ref as R
+    g = golden("g2_radio_r128_t12_b2.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(), (1, 128, 128), 2, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
+                      learning_rates=None, burnin=20)
+    net.reset(True)
+    _check_against_r32_fixture(net, g)
+    assert net.sequence_supported()
+    sds = [{k: v.detach().clone() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
+    ref = R.RefConvNetwork(sds, [dict(padding=3, pooling=1)] * 3, 1.0)
+    orc = C.OracleConvNetwork([{k: v.numpy() for k, v in sd.items()} for sd in sds], convs, (128, 128), 1.0)
+    cells = g["cells"]
+    T, B = cells.shape
+    torch.set_num_threads(1)
+    worst = 0.0
+    for step in range(T):
+        x = torch.zeros(B, 1, 128 * 128)
+        x[torch.arange(B), 0, torch.from_numpy(cells[step]).long()] = 1.0
+        x = x.reshape(B, 1, 128, 128)
+        outs = ref.test(x)
+        oo = orc.step(x.numpy())
+        for i, (o, p, pv, v) in enumerate(outs):
+            bits = np.unpackbits(g["spikes/%d" % i][step], axis=-1, bitorder="little")
+            assert np.array_equal((v > 0).float().reshape(B, -1).numpy(), bits), ("torch oracle", step, i)
+            assert np.array_equal(p.numpy(), g["p/%d" % i][step]), (step, i)
+            assert np.array_equal(oo[i]["s"].reshape(B, -1), bits), ("C oracle: spike flip", step, i)
+            worst = max(worst, float(np.abs(oo[i]["p"] - g["p/%d" % i][step]).max()))
+    assert worst <= 1e-4
+    for i in range(3):
+        assert np.array_equal(np.array(ref.clout[i]), g["clout/%d" % i]) and np.array_equal(ref.votes()[i], g["vote/%d" % i])
+
+
 def test_seeded_network_and_oracle_on_32x32_plane(golden, cpu_device):
     """32x32 plane (served by the tiled sequence kernels): the seeded constructor reproduces the reference's network
     (fixture g2_radio_r32_t40_b2: i2h parameters stored, readout matrices as checksums), and the torch oracle run
