@@ -14,6 +14,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-t1024 # only the T = 1024 rollout (added in round 5)
     python tests/golden/make_golden.py --only-refyaml # only the radio_ml_conv_ref.yaml rollout (added in round 5)
     python tests/golden/make_golden.py --only-r128 # only the 128x128-plane rollout (added in round 5)
+    python tests/golden/make_golden.py --only-g6r # only the regularised / MSELoss learning steps (added in round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -422,6 +423,49 @@ def g6_train_step(lib, nets, du):
     np.savez_compressed(os.path.join(OUT, "g6_train_steps.npz"), **out)
 
 
+def g6r_train_variants(lib, nets, du):
+    """Two more train_dcll variants on the reduced radio net of G6 (netscale 0.25, 8x8, B = 3, T = 6, burn-in 3, Adam betas
+    (0, .95), weight_decay 10, lr 1e-6):
+      reg/  SmoothL1Loss with train_dcll's DEFAULT regularize = 0.05 (dcll/pytorch_libdcll.py:690, :697-701: the two regulariser
+            terms reach pvmem and pv directly) — the slices called one after the other as ConvNetwork.learn does, but with the
+            default argument;
+      mse/  MSELoss (train.py --loss_type MSELoss), regularize = False as ConvNetwork.learn passes it.
+    Per variant: initial state dicts, the gradients of every post-burn-in step, the losses train_dcll returns, final state
+    dicts (inputs and targets are G6's)."""
+    convs = nets.load_network_spec(os.path.join(REF, "networks", "radio_ml_conv.yaml"))
+    B, R, T = 3, 8, 6
+    out = {}
+    for tag, loss, reg in (("reg", torch.nn.SmoothL1Loss, 0.05), ("mse", torch.nn.MSELoss, False)):
+        seed(1)
+        net = nets.ConvNetwork(make_args(netscale=0.25), (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=loss,
+                               opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0},
+                               learning_rates=[1e-6], burnin=3)
+        net.reset(True)
+        x = synth_iq(B, 128, 4)
+        labels = torch.randint(0, 24, (B,), generator=torch.Generator().manual_seed(2))
+        np.random.seed(3)
+        spikes, targets = du.iq2spiketrain(x, du.to_one_hot(labels, 24), out_w=R, out_h=R, max_duration=T)
+        xin, tg = torch.Tensor(spikes), torch.Tensor(targets)
+        if tag == "reg":
+            out["x"] = spikes.astype(np.float32)
+            out["targets"] = np.asarray(targets, dtype=np.float32)
+        for i, s in enumerate(net.dcll_slices):
+            out.update(state_dict_np(s.dclllayer, "%s/sd0/%d/" % (tag, i)))
+        net.reset()
+        net.train()
+        for t in range(T):
+            cur = xin[t]
+            for i, s in enumerate(net.dcll_slices):
+                cur, _, _, _, l = s.train_dcll(cur, tg[t], regularize=reg)
+                out["%s/loss/%d/%d" % (tag, t, i)] = npy(l).reshape(-1)
+                if s.iter >= s.burnin:
+                    out["%s/grad/%d/%d/w" % (tag, t, i)] = npy(s.dclllayer.i2h.weight.grad)
+                    out["%s/grad/%d/%d/b" % (tag, t, i)] = npy(s.dclllayer.i2h.bias.grad)
+        for i, s in enumerate(net.dcll_slices):
+            out.update(state_dict_np(s.dclllayer, "%s/sd1/%d/" % (tag, i)))
+    np.savez_compressed(os.path.join(OUT, "g6r_train_variants.npz"), **out)
+
+
 def g6b_train_production(lib, nets, du):
     """Eight consecutive train_dcll steps of the reference at the PRODUCTION geometry (round-4 verdict, weak #1):
     radio_ml_conv.yaml, netscale 1 (32 channels), 16x16 plane, arp 1.0, random_tau, SmoothL1 + Adam(betas (0,.95),
@@ -589,6 +633,9 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-g6r" in sys.argv:
+        g6r_train_variants(lib, nets, du)
+        return
     if "--only-r128" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -642,6 +689,7 @@ def main():
     g3_iq(du)
     g4_votes(lib)
     g6_train_step(lib, nets, du)
+    g6r_train_variants(lib, nets, du)
     meta["g6b"] = g6b_train_production(lib, nets, du)
     g7_dense(lib)
     g8_image(du)

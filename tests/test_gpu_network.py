@@ -551,6 +551,56 @@ def test_local_learning_matches_reference_train_steps(golden, native, monkeypatc
                 assert not np.array_equal(mine, g["sd0/%d/%s" % (i, k)]), "parameter did not train: %d %s" % (i, k)
 
 
+@pytest.mark.parametrize("tag,native", [("reg", True), ("mse", True), ("mse", False)])
+def test_learning_variants_match_reference_train_steps(golden, tag, native, monkeypatch):
+    """Fixture g6r (generated by importing the reference; reduced radio net of G6): 'reg' = train_dcll with its DEFAULT
+    regularize = 0.05 (dcll/pytorch_libdcll.py:690, :697-701 — the regulariser terms reach pvmem and pv directly: autograd path
+    around the HIP forward / backward), 'mse' = MSELoss (train.py --loss_type MSELoss) on the native C-ABI path and on the
+    autograd path.  The gradients of every post-burn-in step, the loss values train_dcll returns and the final parameters
+    against the reference's."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    monkeypatch.setenv("DCLL_NATIVE_LEARNING", "1" if native else "0")
+    g = golden("g6r_train_variants.npz")
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    B, R_, T = 3, 8, 6
+    loss = torch.nn.SmoothL1Loss if tag == "reg" else torch.nn.MSELoss
+    reg = 0.05 if tag == "reg" else False
+    net = ConvNetwork(_args(netscale=0.25), (1, R_, R_), B, convs, 24, act=torch.nn.Sigmoid(), loss=loss,
+                      opt=torch.optim.Adam, opt_param={"betas": [0.0, .95], "weight_decay": 10.0}, learning_rates=[1e-6], burnin=3)
+    net.reset(True)
+    if tag == "mse":
+        assert all((s._native_learning() is not None) == native for s in net.dcll_slices)
+    for i in range(3):
+        for k, v in g.sub("%s/sd0/%d/" % (tag, i)).items():
+            assert np.array_equal(net.state_dict()["dcll_slices.%d.dclllayer.%s" % (i, k)].cpu().numpy(), v), (i, k)
+    x = torch.from_numpy(g["x"]).cuda()
+    y = torch.from_numpy(g["targets"]).cuda()
+    net.reset()
+    net.train()
+    for t in range(T):
+        cur = x[t]
+        for i, s in enumerate(net.dcll_slices):
+            cur, _, _, _, l = s.train_dcll(cur, y[t], regularize=reg)
+            want = float(g["%s/loss/%d/%d" % (tag, t, i)][0])
+            assert abs(float(l) - want) <= 1e-5 * max(abs(want), 1e-3), (t, i, float(l), want)
+            key = "%s/grad/%d/%d/w" % (tag, t, i)
+            if key in g.keys():
+                gw, gb = s.dclllayer.i2h.weight.grad.cpu().numpy(), s.dclllayer.i2h.bias.grad.cpu().numpy()
+                rw, rb = g[key], g["%s/grad/%d/%d/b" % (tag, t, i)]
+                np.testing.assert_allclose(gw, rw, rtol=2e-3, atol=1e-6 * np.abs(rw).max(), err_msg="%d %d w" % (t, i))
+                np.testing.assert_allclose(gb, rb, rtol=2e-3, atol=1e-6 * np.abs(rb).max(), err_msg="%d %d b" % (t, i))
+    for i in range(3):
+        for k, v in g.sub("%s/sd1/%d/" % (tag, i)).items():
+            mine = net.state_dict()["dcll_slices.%d.dclllayer.%s" % (i, k)].cpu().numpy()
+            if k.startswith("i2o") or "alpha" in k or "tau" in k:
+                assert np.array_equal(mine, v), (i, k)         # frozen
+            else:
+                np.testing.assert_allclose(mine, v, rtol=0, atol=2e-3 * np.abs(v).max(), err_msg="%d %s" % (i, k))
+                assert not np.array_equal(mine, g["%s/sd0/%d/%s" % (tag, i, k)]), "parameter did not train: %d %s" % (i, k)
+
+
 @pytest.mark.parametrize("mode", ["native", "native_unsplit_eager", "autograd"])
 def test_local_learning_matches_reference_at_production_geometry(golden, golden_meta, mode, monkeypatch):
     """Fixture G6b (round-4 verdict, weak #1): EIGHT consecutive train_dcll steps of the imported reference at the geometry
