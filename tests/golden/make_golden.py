@@ -15,6 +15,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-refyaml # only the radio_ml_conv_ref.yaml rollout (added in round 5)
     python tests/golden/make_golden.py --only-r128 # only the 128x128-plane rollout (added in round 5)
     python tests/golden/make_golden.py --only-g6r # only the regularised / MSELoss learning steps (added in round 5)
+    python tests/golden/make_golden.py --only-variants # only the arp 0 / scalar-tau rollouts at 16x16 (added in round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -267,6 +268,22 @@ def g2_ref_yaml(lib, nets, du):
             r[k] = np.ascontiguousarray(a[:, 0, 0])
     np.savez_compressed(os.path.join(OUT, "g2_ref_yaml_h16_w128_t64_b2.npz"), **r)
     return dict(H=16, W=128, T=64, B=2, layers=7)
+
+
+def g2_r16_variants(lib, nets, du):
+    """radio_ml_conv.yaml at the production geometry (32 channels, 16x16, B = 2, T = 64) in the two settings the scripts do
+    not use but the argparse surface offers: `--arp 0` (train.py:84-85 default: the NON-refractory ContinuousConv2D,
+    :407-426) with random_tau, and `random_tau=False` (scalar time constants, :349-356) with arp 1.  Band-free IQ seeds (1 / 2)."""
+    a = rollout(lib, nets, du, "radio_ml_conv.yaml", R=16, T=64, B=2, args=make_args(arp=0.0), full_traces=False,
+                store_readouts=False, store_final=False, iq_seed=1)
+    b = rollout(lib, nets, du, "radio_ml_conv.yaml", R=16, T=64, B=2, args=make_args(random_tau=False), full_traces=False,
+                store_readouts=False, store_final=False, iq_seed=2)
+    out = {}
+    for tag, r in (("norp", a), ("scalar_tau", b)):
+        r.pop("minabs_v")
+        out.update({tag + "/" + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(OUT, "g2_radio_r16_t64_b2_variants.npz"), **out)
+    return dict(R=16, T=64, B=2, variants=["norp (arp 0, random_tau)", "scalar_tau (arp 1, random_tau False)"])
 
 
 def g2_r128(lib, nets, du):
@@ -633,6 +650,13 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-variants" in sys.argv:
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["g2_r16_variants"] = g2_r16_variants(lib, nets, du)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, default=lambda o: list(o))
+        return
     if "--only-g6r" in sys.argv:
         g6r_train_variants(lib, nets, du)
         return
@@ -683,6 +707,7 @@ def main():
         "g2_t1024": g2_t1024(lib, nets, du),
         "g2_ref_yaml": g2_ref_yaml(lib, nets, du),
         "g2_r128": g2_r128(lib, nets, du),
+        "g2_r16_variants": g2_r16_variants(lib, nets, du),
         "g5": {k: [{kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in d.items()} for d in v]
                for k, v in g5_specs(nets).items()},
     }

@@ -391,6 +391,51 @@ def test_default_128x128_plane_reproduces_the_reference_run(golden):
                                            g["finalsum/%d/%s" % (i, nm)], rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("tag,arp,rtau", [("norp", 0.0, True), ("scalar_tau", 1.0, False)])
+def test_arp0_and_scalar_tau_runs_reproduce_the_reference(golden, tag, arp, rtau):
+    """Fixture g2_radio_r16_t64_b2_variants (generated by importing the reference): radio_ml_conv.yaml at the production
+    geometry with `--arp 0` (train.py's argparse default: the non-refractory ContinuousConv2D) and with scalar time constants
+    (`random_tau=False`), B = 2, T = 64.  Fused sequence kernels (REFRACTORY = false instantiations / scalar tau) and the
+    per-step path: the reference's spike trains bit for bit, readouts within 1e-4, argmax, votes, final state by checksum."""
+    from test_host_logic import _Sub, _check_against_r32_fixture
+    from snn_modulation_classification_amd import ops
+    g = _Sub(golden("g2_radio_r16_t64_b2_variants.npz"), tag + "/")
+    seq, stp = _radio_net(2, 16, arp=arp, random_tau=rtau), _radio_net(2, 16, arp=arp, random_tau=rtau)
+    _check_against_r32_fixture(seq, g)
+    assert seq.sequence_supported()
+    cells = torch.from_numpy(g["cells"]).cuda()
+    T, B = cells.shape
+    seq.reset()
+    res = seq.test_sequence(cells, keep_spikes=True)
+    for i in range(3):
+        ref_words = g["spikes/%d" % i].view(np.int32).reshape(T, B, 32, 8)
+        got = res["spikes"][i].cpu().numpy()
+        assert np.array_equal(got, ref_words), "layer %d: %d spike words differ from the reference" % (i, int((got != ref_words).sum()))
+        np.testing.assert_allclose(res["logits"][i].cpu().numpy(), g["p/%d" % i], atol=LOGIT_TOL, rtol=0)
+        assert np.array_equal(np.array(seq.dcll_slices[i].clout), g["clout/%d" % i])
+        assert np.array_equal(res["vote"][i].cpu().numpy(), g["vote/%d" % i])
+    np.testing.assert_allclose(res["o"].cpu().numpy(), g["o_last"], atol=LOGIT_TOL, rtol=0)
+    planes = ops.cells_to_planes(cells, 256).reshape(T, B, 1, 16, 16)
+    stp.reset()
+    for t in range(T):
+        cur = planes[t]
+        for i, s in enumerate(stp.dcll_slices):
+            o, p, pv, v = s.forward(cur, ignore_burnin=True)
+            if i < 2:
+                bits = np.unpackbits(g["spikes/%d" % i][t], axis=-1, bitorder="little")
+                assert np.array_equal(o.reshape(B, -1).cpu().numpy(), bits), (t, i)
+            np.testing.assert_allclose(p.cpu().numpy(), g["p/%d" % i][t], atol=LOGIT_TOL, rtol=0)
+            cur = o
+    names = ("eps0", "eps1") + (("arp",) if arp > 0 else ())
+    for net in (seq, stp):
+        for i in range(3):
+            assert len(net.dcll_slices[i].dclllayer.i2h.state) == len(names)
+            for nm in names:
+                st = getattr(net.dcll_slices[i].dclllayer.i2h.state, nm).cpu().numpy().astype(np.float64)
+                np.testing.assert_allclose([st.sum(), np.abs(st).sum(), st.reshape(-1)[::997].sum()],
+                                           g["finalsum/%d/%s" % (i, nm)], rtol=1e-12, atol=1e-12)
+
+
 def test_config5_int8_weights_and_packed_spikes():
     """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code => parity unpinned):
     radio_ml_conv_ref.yaml with per-channel int8 conv weights and 1-bit packed inter-layer spikes.  What can be pinned:
