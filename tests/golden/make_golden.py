@@ -16,6 +16,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-r128 # only the 128x128-plane rollout (added in round 5)
     python tests/golden/make_golden.py --only-g6r # only the regularised / MSELoss learning steps (added in round 5)
     python tests/golden/make_golden.py --only-variants # only the arp 0 / scalar-tau rollouts at 16x16 (added in round 5)
+    python tests/golden/make_golden.py --only-g7b # only the dense sequences (added in round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -582,6 +583,38 @@ def g7_dense(lib):
     np.savez_compressed(os.path.join(OUT, "g7_dense.npz"), **out)
 
 
+def g7b_dense_sequence(lib, x_seeds=(11, 12)):
+    """DenseDCLLlayer over T = 24 steps at sizes the two dense kernel forms serve (the all-T on-chip kernel: in <= 1024,
+    out <= 128; the per-step fp32-MFMA GEMM beyond): (512 -> 128, refractory, random_tau) and (600 -> 160, plain, scalar
+    tau; odd tile counts), B = 5, target 10 — input spikes, output spikes, readouts per step, final state.  x_seeds: input
+    seeds for which the reference's and the pinned-order spike trains agree on every neuron-step (tests/test_oracle_c.py)."""
+    out = {}
+    for (name, cin, cout, wrp, rtau), xs in zip((("rrp_512_128", 512, 128, 1.0, True), ("plain_600_160", 600, 160, 0.0, False)), x_seeds):
+        seed(9)
+        layer = lib.DenseDCLLlayer(cin, cout, target_size=10, alpha=.9, alphas=.85, alpharp=.65, wrp=wrp,
+                                   random_tau=rtau).init_hiddens(5)
+        with torch.no_grad():
+            layer.i2h.weight.mul_(60.0)
+            layer.i2h.bias.mul_(0.02)
+        pre = "g7b/%s/" % name
+        out.update(state_dict_np(layer, pre + "sd/"))
+        g = torch.Generator().manual_seed(xs)
+        T, B = 24, 5
+        xs_, ss, ps = [], [], []
+        for t in range(T):
+            x = (torch.rand(B, cin, generator=g) < 0.2).float()
+            o, p, pv, v = layer.forward(x)
+            xs_.append(pack_bits(npy(x)))
+            ss.append(pack_bits(npy(o)))
+            ps.append(npy(p))
+        out[pre + "x"] = np.stack(xs_)
+        out[pre + "s"] = np.stack(ss)
+        out[pre + "p"] = np.stack(ps)
+        for i, nm in enumerate(layer.i2h.state._fields):
+            out[pre + "final_%s" % nm] = npy(layer.i2h.state[i])
+    np.savez_compressed(os.path.join(OUT, "g7b_dense_sequence.npz"), **out)
+
+
 def g8_image(du):
     rng = np.random.RandomState(3)
     x = rng.rand(3, 6, 6).astype(np.float32)
@@ -650,6 +683,9 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-g7b" in sys.argv:
+        g7b_dense_sequence(lib)
+        return
     if "--only-variants" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -717,6 +753,7 @@ def main():
     g6r_train_variants(lib, nets, du)
     meta["g6b"] = g6b_train_production(lib, nets, du)
     g7_dense(lib)
+    g7b_dense_sequence(lib)
     g8_image(du)
     meta["g9"] = g9_checkpoint(lib, nets, du)
     with open(os.path.join(OUT, "meta.json"), "w") as f:

@@ -535,6 +535,39 @@ def test_dense_twins_vs_oracle(dev, cin, cout, B, T, ttau, wrp):
     assert 0.01 < nspk / (T * B * cout) < 0.99, "degenerate test"
 
 
+@pytest.mark.parametrize("case,cin,cout,wrp,rtau", [("rrp_512_128", 512, 128, 1.0, True), ("plain_600_160", 600, 160, 0.0, False)])
+def test_dense_layer_reproduces_the_reference_sequence(golden, dev, case, cin, cout, wrp, rtau):
+    """Fixture g7b (generated by importing the reference): DenseDCLLlayer over 24 steps — 512 -> 128 refractory with
+    per-feature time constants (the all-T on-chip kernel k_dense_lif_seq) and 600 -> 160 plain with scalar ones (the per-step
+    fp32-MFMA GEMM k_dense_lif_mfma, odd tile counts).  `.forward` step by step AND `.forward_sequence` give the reference's
+    output spikes bit for bit, its readouts within 1e-4, and its final state (traces bit for bit)."""
+    from snn_modulation_classification_amd.dcll.pytorch_libdcll import DenseDCLLlayer
+    g = golden("g7b_dense_sequence.npz")
+    pre = "g7b/%s/" % case
+    T, B = g[pre + "x"].shape[0], 5
+    x = torch.from_numpy(np.unpackbits(g[pre + "x"], axis=-1, bitorder="little")[..., :cin].astype(np.float32)).to(dev)
+    want_s = np.unpackbits(g[pre + "s"], axis=-1, bitorder="little")[..., :cout].astype(np.float32)
+
+    def make():
+        L = DenseDCLLlayer(cin, cout, target_size=10, alpha=.9, alphas=.85, alpharp=.65, wrp=wrp, random_tau=False)
+        sd = {k: torch.from_numpy(v) for k, v in g.sub(pre + "sd/").items()}
+        for nm in ("alpha", "tau_m__dt", "alphas", "tau_s__dt"):       # (per-feature tensors when the reference drew them)
+            getattr(L.i2h, nm).data = sd["i2h." + nm].clone()
+        L.load_state_dict(sd)
+        return L.to(dev).init_hiddens(B)
+    a, b = make(), make()
+    for t_ in range(T):
+        s, p, pv, v = a.forward(x[t_])
+        assert np.array_equal(s.cpu().numpy(), want_s[t_]), (t_, int((s.cpu().numpy() != want_s[t_]).sum()))
+        np.testing.assert_allclose(p.cpu().numpy(), g[pre + "p"][t_], atol=LOGIT_TOL, rtol=0)
+    s_seq, p_seq, pv_seq, _ = b.forward_sequence(x)
+    assert np.array_equal(s_seq.cpu().numpy(), want_s)
+    np.testing.assert_allclose(p_seq.cpu().numpy(), g[pre + "p"], atol=LOGIT_TOL, rtol=0)
+    for L in (a, b):
+        for i, nm in enumerate(("eps0", "eps1", "arp")[:3 if wrp > 0 else 2]):
+            assert bits_equal(getattr(L.i2h.state, nm).cpu().numpy(), g[pre + "final_" + nm]), (nm,)
+
+
 def test_dense_layer_forward_sequence_equals_forward(dev):
     """DenseDCLLlayer.forward_sequence == T calls of .forward (the reference's protocol, :250-255), bit for bit."""
     from snn_modulation_classification_amd.dcll.pytorch_libdcll import DenseDCLLlayer

@@ -207,3 +207,23 @@ def test_argmax_vote_matches_reference_votes(golden):
     from oracle.torch_ref import predictions_by_vote
     _, v3 = C.argmax_vote(logits, t_begin=3)
     assert np.array_equal(v3, predictions_by_vote(list(clout[3:])))
+
+
+@pytest.mark.parametrize("case,cin,cout,wrp", [("rrp_512_128", 512, 128, 1.0), ("plain_600_160", 600, 160, 0.0)])
+def test_g7b_dense_sequence_free_running(golden, case, cin, cout, wrp):
+    """Fixture g7b (from the imported reference): DenseDCLLlayer over 24 steps at the sizes the two dense kernel forms serve.
+    The pinned-order oracle, free-running from zero state on the reference's input, reproduces every output spike (the input
+    seeds were chosen band-free), the readouts within 1e-4 and the final traces bit for bit."""
+    g = golden("g7b_dense_sequence.npz")
+    pre = "g7b/%s/" % case
+    layer = C.OracleDenseLayer(g.sub(pre + "sd/"), wrp)
+    T = g[pre + "x"].shape[0]
+    for t in range(T):
+        x = np.unpackbits(g[pre + "x"][t], axis=-1, bitorder="little")[:, :cin].astype(np.float32)
+        s, p, pv, v = layer.forward(x)
+        ref = np.unpackbits(g[pre + "s"][t], axis=-1, bitorder="little")[:, :cout]
+        assert np.array_equal(s, ref), (t, int((s != ref).sum()))
+        np.testing.assert_allclose(p, g[pre + "p"][t], atol=LOGIT_TOL, rtol=0)
+    assert np.array_equal(layer.state[0], g[pre + "final_eps0"]) and np.array_equal(layer.state[1], g[pre + "final_eps1"])
+    if wrp > 0:
+        assert np.array_equal(layer.state[2], g[pre + "final_arp"])

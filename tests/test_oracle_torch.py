@@ -96,3 +96,18 @@ def test_g4_votes(golden):
     y = np.zeros((T, B, 5), np.float32)
     y[:, np.arange(B), g["labels"]] = 1
     assert R.accuracy_by_vote(clout, y) == float(g["acc"])
+
+
+@pytest.mark.parametrize("case,cin,cout,wrp", [("rrp_512_128", 512, 128, 1.0), ("plain_600_160", 600, 160, 0.0)])
+def test_g7b_dense_sequence_bit_exact(golden, case, cin, cout, wrp):
+    g = golden("g7b_dense_sequence.npz")
+    pre = "g7b/%s/" % case
+    layer = R.RefDenseLayer(sd_t(g.sub(pre + "sd/")), wrp)
+    torch.set_num_threads(1)
+    for step in range(g[pre + "x"].shape[0]):
+        x = t(np.unpackbits(g[pre + "x"][step], axis=-1, bitorder="little")[:, :cin].astype(np.float32))
+        s, p, pv, v = layer.forward(x)
+        assert np.array_equal(s.numpy(), np.unpackbits(g[pre + "s"][step], axis=-1, bitorder="little")[:, :cout])
+        assert np.array_equal(p.numpy(), g[pre + "p"][step])
+    for i, nm in enumerate(("eps0", "eps1", "arp")[:3 if wrp > 0 else 2]):
+        assert np.array_equal(layer.state[i].numpy(), g[pre + "final_" + nm])
