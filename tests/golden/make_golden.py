@@ -17,6 +17,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-g6r # only the regularised / MSELoss learning steps (added in round 5)
     python tests/golden/make_golden.py --only-variants # only the arp 0 / scalar-tau rollouts at 16x16 (added in round 5)
     python tests/golden/make_golden.py --only-g7b # only the dense sequences (added in round 5)
+    python tests/golden/make_golden.py --only-carry # only the two-batch state carry-over run (added in round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -285,6 +286,51 @@ def g2_r16_variants(lib, nets, du):
         out.update({tag + "/" + k: v for k, v in r.items()})
     np.savez_compressed(os.path.join(OUT, "g2_radio_r16_t64_b2_variants.npz"), **out)
     return dict(R=16, T=64, B=2, variants=["norp (arp 0, random_tau)", "scalar_tau (arp 1, random_tau False)"])
+
+
+def g2_carry(lib, nets, du):
+    """Quirk Q3: `net.reset()` between batches does NOT zero the neuron state (networks/__init__.py:187-189 passes
+    init_states=False; dcll/pytorch_libdcll.py:648-653) — the second batch starts from the first batch's final state.  Two
+    consecutive batches of B = 2 windows, T = 24 each, production geometry, the reference's evaluation protocol
+    (test_radio_ml.py:142-146: reset, T x test, accuracy): spikes / readouts / argmax of the SECOND batch and its votes."""
+    convs = nets.load_network_spec(os.path.join(REF, "networks", "radio_ml_conv.yaml"))
+    seed(1)
+    B, R, T = 2, 16, 24
+    net = nets.ConvNetwork(make_args(), (1, R, R), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                           opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    out = {}
+    for i, s in enumerate(net.dcll_slices):
+        sd = state_dict_np(s.dclllayer, "sd/%d/" % i)
+        for k in list(sd):
+            if k.split("/")[-1].startswith(("i2o.weight", "output_.weight")):
+                w = sd.pop(k).astype(np.float64)
+                out["sdsum/" + k[3:]] = np.array([w.sum(), np.abs(w).sum(), w.reshape(-1)[::4097].sum()])
+        out.update(sd)
+    for k in range(2):
+        x = synth_iq(B, 128, 21 + k)
+        labels = torch.randint(0, 24, (B,), generator=torch.Generator().manual_seed(5 + k))
+        np.random.seed(30 + k)
+        spikes, targets = du.iq2spiketrain(x, du.to_one_hot(labels, 24), out_w=R, out_h=R, max_duration=T)
+        xin = torch.Tensor(spikes)
+        out["cells/%d" % k] = spikes.reshape(T, B, -1).argmax(-1).astype(np.int32)
+        out["labels/%d" % k] = labels.numpy()
+        net.reset()                                              # (init_states=False: state carried over)
+        spk = [[] for _ in net.dcll_slices]
+        pl = [[] for _ in net.dcll_slices]
+        for t in range(T):
+            cur = xin[t]
+            for i, s in enumerate(net.dcll_slices):
+                o, p, pv, v = s.forward(cur, ignore_burnin=True)
+                spk[i].append(pack_bits(npy((v > 0).float()).reshape(B, -1)))
+                pl[i].append(npy(p))
+                cur = o
+        for i in range(3):
+            out["spikes/%d/%d" % (k, i)] = np.stack(spk[i])
+            out["p/%d/%d" % (k, i)] = np.stack(pl[i])
+            out["clout/%d/%d" % (k, i)] = np.array(net.dcll_slices[i].clout)
+        out["acc/%d" % k] = np.array(net.accuracy(torch.Tensor(targets)))
+    np.savez_compressed(os.path.join(OUT, "g2_radio_r16_carry_over.npz"), **out)
 
 
 def g2_r128(lib, nets, du):
@@ -683,6 +729,9 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-carry" in sys.argv:
+        g2_carry(lib, nets, du)
+        return
     if "--only-g7b" in sys.argv:
         g7b_dense_sequence(lib)
         return
@@ -754,6 +803,7 @@ def main():
     meta["g6b"] = g6b_train_production(lib, nets, du)
     g7_dense(lib)
     g7b_dense_sequence(lib)
+    g2_carry(lib, nets, du)
     g8_image(du)
     meta["g9"] = g9_checkpoint(lib, nets, du)
     with open(os.path.join(OUT, "meta.json"), "w") as f:
