@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 char *dcll_err_buf(void) { static char b[512]; return b; }
+void dcll_trace_note(const char *) {}
 
 static float run(int B, int Wd, int T, const uint32_t *spk_in, const float *W, const float *bias, const float *tau4, float *e0,
                  float *e1, float *arp, uint32_t *spk_out, float *pv, int reps)
@@ -22,10 +23,10 @@ static float run(int B, int Wd, int T, const uint32_t *spk_in, const float *W, c
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(a);
         if (Wd >= 32)
-            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, 5, true>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr,
+            hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, 5, true>), dim3(nwg), dim3(512), 0, 0, spk_in,
                                dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f);
         else {
-#define W3_NARROW(LW_) hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, LW_, true>), dim3(nwg), dim3(512), 0, 0, spk_in, (const int32_t *)nullptr, \
+#define W3_NARROW(LW_) hipLaunchKernelGGL((k_lif_seq_w3<64, true, 5, LW_, true>), dim3(nwg), dim3(512), 0, 0, spk_in, \
                                dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f)
             if (logW == 4) W3_NARROW(4); else if (logW == 3) W3_NARROW(3); else if (logW == 2) W3_NARROW(2); else W3_NARROW(1);
 #undef W3_NARROW
@@ -77,14 +78,14 @@ static int run_first(int B, int Wd, int T)
     hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(bias, hb.data(), 256, hipMemcpyHostToDevice); hipMemcpy(tau4, ht.data(), 16, hipMemcpyHostToDevice);
     hipMemset(e0, 0, nin * 4); hipMemset(e1, 0, nin * 4); hipMemset(arp, 0, nout * 4);
-    const long nwg = ((long)B * NTS + 7) / 8;
+    const long nitems = (long)B * (HW / 128) * (64 / W3F_NCH), nblk = (nitems + W3F_WPB - 1) / W3F_WPB;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e30f;
     for (int r = 0; r < 4; ++r) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k_lif_seq_w3<1, true, 5, 5, true>), dim3(nwg), dim3(512), 0, 0, (const uint32_t *)nullptr, cells,
-                           dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, 0.65f, 1.0f);
+        hipLaunchKernelGGL((k_lif_seq_w3f<true, 5, W3F_NCH>), dim3(nblk), dim3(64 * W3F_WPB), 0, 0, cells,
+                           dcll_wsrc{W, nullptr, nullptr}, bias, tau4, e0, e1, arp, spk_out, pv, (float *)nullptr, T, B, HW, logW, nitems, 0.65f, 1.0f);
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms;
@@ -92,7 +93,7 @@ static int run_first(int B, int Wd, int T)
         if (ms < best) best = ms;
     }
     const double bytes = (double)T * B * 64 * (HW / 2) * 4 * (1 + 1 / 32.0);
-    printf("k_lif_seq_w3<1> (first layer) B=%d W=%d T=%d: %.2f ms = %.2f TB/s of pooled map + spikes\n", B, Wd, T, best, bytes / best / 1e9);
+    printf("k_lif_seq_w3f (first layer) B=%d W=%d T=%d: %.2f ms = %.2f TB/s of pooled map + spikes\n", B, Wd, T, best, bytes / best / 1e9);
     print_stamps(T);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -1,6 +1,7 @@
 // dcll_seq_w3.hip — k_lif_seq_w3: the fused all-T layer kernel for the geometry of networks/radio_ml_conv_ref.yaml
-// (BASELINE config 5): 64 output channels, kernel (1,3), padding (0,1), max-pool (1,2), c_in = 1 (first layer, input =
-// one spike per step as a cell index) or 64 (bit-packed spikes in) — fifth translation unit of libdcll_hip.so.
+// (BASELINE config 5): 64 output channels, kernel (1,3), padding (0,1), max-pool (1,2) — k_lif_seq_w3 for the six 64 -> 64
+// layers (bit-packed spikes in, fp32-MFMA chains), k_lif_seq_w3f for the first layer (c_in = 1, input = one spike per step as
+// a cell index: a register-only streaming kernel, below) — fifth translation unit of libdcll_hip.so.
 //
 // What the geometry gives: the kernel height is 1, so the rows of the plane are independent in every layer, and pooling
 // pairs are neighbours in the row-major flattening.  A layer's input is therefore handled as a stream of 32-pixel TILES
@@ -41,13 +42,6 @@ constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 #ifndef W3_ORDER
 #define W3_ORDER 0                  // 0: chain A, epilogue A, chain B, epilogue B; 1: both chains, then both epilogues
 #endif
-// experiments/ablate_w3 B W first: neither changes the first layer's 4.7 TB/s (experiments/README.md)
-#ifndef W3_DB_FIRST
-#define W3_DB_FIRST 0               // first layer (c_in = 1): two images by step parity and one barrier per step
-#endif
-#ifndef W3_WAVES_FIRST
-#define W3_WAVES_FIRST 2            // first layer: waves per SIMD the register budget allows (4 = two workgroups per CU)
-#endif
 #ifndef W3_TRG
 #define W3_TRG 8                    // trace elements per group (read - update - write)
 #endif
@@ -87,7 +81,7 @@ __device__ unsigned long long w3_stamps[8][8];
 // is a compile-time constant, and the ~100 scalar instructions per wave and step that predicate the stores on it (exec
 // masks, branches around every store group) are gone from the time loop.
 template <int CIN, bool REFRACTORY, int OUT, int LW, bool FULL>
-__global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in, const int32_t *__restrict__ cells,
+__global__ __launch_bounds__(512, 2) void k_lif_seq_w3(const uint32_t *__restrict__ spk_in,
                                                      const dcll_wsrc W, const float *__restrict__ bias,
                                                      const float *__restrict__ tau4, float *__restrict__ eps0_g,
                                                      float *__restrict__ eps1_g, float *__restrict__ arp_g,
@@ -95,15 +89,16 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
                                                      float *__restrict__ v_out, int T, int B, int HW, int logW,
                                                      float alpharp, float wrp)
 {
-    constexpr int NK = CIN == 1 ? 2 : 96;               // MFMA k-steps of a chain
-    constexpr int NE = CIN == 1 ? 1 : 32;               // trace elements per owning thread
+    static_assert(CIN == 64, "the 64 -> 64 layers; the first layer (c_in = 1) is k_lif_seq_w3f");
+    constexpr int NK = 96;                              // MFMA k-steps of a chain
+    constexpr int NE = 32;                              // trace elements per owning thread
     // DB (wide 64-channel layers = 3/4 of the network's work): a channel image needs only 256 + 256/32 + 1 floats, so TWO
     // images fit (2 x 74.8 KB), double-buffered by step parity: the traces of step t+1 are written into the other image
     // right after a wave's own chains of step t — one barrier per step instead of two, and the waves of a SIMD drift apart
     // (one in its trace / epilogue phase while the other issues MFMAs).
     constexpr bool WIDE = LW >= 5;
-    constexpr bool DB = WIDE && (CIN == 64 || W3_DB_FIRST);
-    constexpr int PST = CIN == 1 ? 1 : 66;              // floats per padded pixel position
+    constexpr bool DB = WIDE;
+    constexpr int PST = 66;                             // floats per padded pixel position
     constexpr int IMG = (DB ? 266 : W3_NPOS) * PST + 8;
     __shared__ __attribute__((aligned(16))) float img[(DB ? 2 : 1) * IMG];
     __shared__ float sbias[64];
@@ -118,12 +113,11 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
     if (tid < 64) sbias[tid] = bias[tid];
 
     // ---- trace ownership -------------------------------------------------------------------------------------------
-    // CIN = 64: thread (ci = lane, wq = wave) owns the 32 pixels of tile wq of channel ci (= one input word): a wave is
-    //           one tile of all 64 channels — validity, sample and tile index are wave-uniform, LDS accesses conflict-free;
-    // CIN = 1:  threads 0..255 own one pixel each of the single channel
-    const int ci_t = CIN == 1 ? 0 : lane, wq = CIN == 1 ? tid >> 5 : w;
+    // thread (ci = lane, wq = wave) owns the 32 pixels of tile wq of channel ci (= one input word): a wave is one tile of all
+    // 64 channels — validity, sample and tile index are wave-uniform, LDS accesses conflict-free
+    const int ci_t = lane, wq = w;
     const long Gt = G0 + wq;
-    const bool tvalid = (FULL || Gt < ntot) && (CIN == 64 || tid < W3_PX);
+    const bool tvalid = FULL || Gt < ntot;
     const long bt = tvalid ? Gt / NTS : 0;
     const int mtile = tvalid ? (int)(Gt % NTS) : 0;
     const float ta = tau4[0 * CIN + ci_t], tm = tau4[1 * CIN + ci_t], tas = tau4[2 * CIN + ci_t], ts = tau4[3 * CIN + ci_t];
@@ -131,9 +125,9 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
     // LDS offset of my first pixel: block pixel p -> (p + (p >> logW) + 1) * PST + ci
     // (for my 32 consecutive pixels 32 wq + i the row term splits into a per-thread part and a wave-uniform one:
     //  (32 wq + i) >> logW == ((32 wq) >> logW) + (i >> logW), W a power of two)
-    const int p0 = CIN == 1 ? tid & (W3_PX - 1) : 32 * wq;
+    const int p0 = 32 * wq;
     const int loff0 = (p0 + 1 + (p0 >> logW)) * PST + ci_t;
-    const long sbase = (bt * CIN + ci_t) * HW + 32L * mtile + (CIN == 1 ? (tid & 31) : 0);     // my first state element
+    const long sbase = (bt * CIN + ci_t) * HW + 32L * mtile;             // my first state element
     __syncthreads();                                     // image zeroed
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -143,18 +137,14 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
 
     // ---- weights of my output-channel tile, stationary: A[co = 32 mt + jj][k] ----------------------------------------
     float wf[NK];
-    if (CIN == 1) {         // k lanes = tap parity: step 0 = taps (0,1), step 1 = taps (2, zero-weight pad)
-        wf[0] = W.at((32 * mt + jj) * 3 + h, 32 * mt + jj);
-        wf[NK - 1] = h == 0 ? W.at((32 * mt + jj) * 3 + 2, 32 * mt + jj) : 0.0f;
-    } else {                // k lanes = input-channel pair: step s = cp * 3 + kx -> W[co][2 cp + h][kx]
-        if (W.q) {          // (one wave-uniform branch on the weight format around the whole load)
-            const float sc = W.scale[32 * mt + jj];
+    // k lanes = input-channel pair: step s = cp * 3 + kx -> W[co][2 cp + h][kx]
+    if (W.q) {              // (one wave-uniform branch on the weight format around the whole load)
+        const float sc = W.scale[32 * mt + jj];
 #pragma unroll
-            for (int s = 0; s < NK; ++s) wf[s] = (float)W.q[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3] * sc;
-        } else {
+        for (int s = 0; s < NK; ++s) wf[s] = (float)W.q[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3] * sc;
+    } else {
 #pragma unroll
-            for (int s = 0; s < NK; ++s) wf[s] = W.f[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3];
-        }
+        for (int s = 0; s < NK; ++s) wf[s] = W.f[((long)(32 * mt + jj) * CIN + 2 * (s / 3) + h) * 3 + s % 3];
     }
     // ---- my two pixel tiles (independent chains) ----------------------------------------------------------------------
     const int perm = jj < 16 ? 2 * jj : 2 * (jj - 16) + 1;          // lane -> pixel of the tile (even | odd)
@@ -166,7 +156,7 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
     const int mA = __builtin_amdgcn_readfirstlane(validA ? (int)(GA % NTS) : 0);
     const int mB = __builtin_amdgcn_readfirstlane(validB ? (int)((GA + 1) % NTS) : 0);
     const int pA = 64 * g + perm, pB = pA + 32;
-    // B-fragment lane base: CIN = 64: channel h of the pair; CIN = 1: tap h of the pair (tap kx reads x + kx - 1)
+    // B-fragment lane base: channel h of the pair
     const int baseA = h + (pA + (pA >> logW)) * PST, baseB = h + (pB + (pB >> logW)) * PST;
     float arpA[16], arpB[16];
 #pragma unroll
@@ -178,16 +168,13 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
     const int HW2 = HW >> 1, NW2 = NTS >> 1;             // pooled pixels / pooled words per channel plane
     // input of step 0
     uint32_t word = 0;
-    int cell = -1;
-    if (CIN == 1) cell = cells[bt];
-    else if (tvalid) word = spk_in[(bt * CIN + ci_t) * NTS + mtile];
+    if (tvalid) word = spk_in[(bt * CIN + ci_t) * NTS + mtile];
     const long in_step = (long)B * CIN * NTS;
 
     // traces of one step (dcll/pytorch_libdcll.py:493-494, every op rounded separately): eps1 read from image `src`,
     // written to image `dst` (float offsets; the same image when single-buffered); eight elements at a time (all 32 in
     // flight would hold 32 more registers on top of weights + accumulators + states)
-    auto trace_step = [&](const uint32_t wd, const int cl, const int src, const int dst) {
-        const int pix0 = 32 * mtile + (CIN == 1 ? (tid & 31) : 0);          // my first pixel inside the sample plane
+    auto trace_step = [&](const uint32_t wd, const int src, const int dst) {
         int lb = loff0;
         const f32x2 ta2 = {ta, ta}, tm2 = {tm, tm}, tas2 = {tas, tas};
         // opaque per step: keeps the 32 element addresses (and their 32 wave-uniform row terms) out of loop-invariant
@@ -198,25 +185,21 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
             float e1[W3_TRG];
 #pragma unroll
             for (int i = i0; i < i0 + W3_TRG && i < NE; ++i) e1[i - i0] = img[src + lb + (i + (WIDE ? 0 : (i >> LW))) * PST];
-            if (CIN == 1) {
-                trace_update(cl == pix0 ? 1.0f : 0.0f, ta, tm, tas, ts, e0[0], e1[0]);
-            } else {
-                // x * tau_s for x in {0, 1} = the sign-extended input bit AND tau_s (v_bfe_i32 + v_and_b32: exact), then
-                // the two trace lines of dcll/pytorch_libdcll.py:493-494, every op rounded separately — on PAIRS of
-                // elements: v_pk_mul_f32 / v_pk_add_f32 are the same IEEE operations at two per lane and issue
+            // x * tau_s for x in {0, 1} = the sign-extended input bit AND tau_s (v_bfe_i32 + v_and_b32: exact), then
+            // the two trace lines of dcll/pytorch_libdcll.py:493-494, every op rounded separately — on PAIRS of
+            // elements: v_pk_mul_f32 / v_pk_add_f32 are the same IEEE operations at two per lane and issue
 #pragma unroll
-                for (int i = i0; i < i0 + W3_TRG && i < NE; i += 2) {
-                    const f32x2 a = {__int_as_float(__builtin_amdgcn_sbfe((int)wd, i, 1) & __float_as_int(ts)),
-                                     __int_as_float(__builtin_amdgcn_sbfe((int)wd, i + 1, 1) & __float_as_int(ts))};
-                    f32x2 p0 = {e0[i], e0[i + 1]}, p1 = {e1[i - i0], e1[i - i0 + 1]};
-                    const f32x2 bb = tas2 * p0;
-                    p0 = a + bb;
-                    const f32x2 cc = ta2 * p1;
-                    const f32x2 dd = p0 * tm2;
-                    p1 = cc + dd;
-                    e0[i] = p0[0], e0[i + 1] = p0[1];
-                    e1[i - i0] = p1[0], e1[i - i0 + 1] = p1[1];
-                }
+            for (int i = i0; i < i0 + W3_TRG && i < NE; i += 2) {
+                const f32x2 a = {__int_as_float(__builtin_amdgcn_sbfe((int)wd, i, 1) & __float_as_int(ts)),
+                                 __int_as_float(__builtin_amdgcn_sbfe((int)wd, i + 1, 1) & __float_as_int(ts))};
+                f32x2 p0 = {e0[i], e0[i + 1]}, p1 = {e1[i - i0], e1[i - i0 + 1]};
+                const f32x2 bb = tas2 * p0;
+                p0 = a + bb;
+                const f32x2 cc = ta2 * p1;
+                const f32x2 dd = p0 * tm2;
+                p1 = cc + dd;
+                e0[i] = p0[0], e0[i + 1] = p0[1];
+                e1[i - i0] = p1[0], e1[i - i0 + 1] = p1[1];
             }
 #pragma unroll
             for (int i = i0; i < i0 + W3_TRG && i < NE; ++i)
@@ -225,7 +208,7 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
         }
     };
     if (DB) {               // step 0's traces in place in image 0, then the loop runs one barrier per step
-        trace_step(word, cell, 0, 0);
+        trace_step(word, 0, 0);
         lds_barrier();
     }
 #ifdef W3_STAMPS
@@ -237,16 +220,13 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
     for (int t = 0; t < T; ++t) {
         const int cur = DB ? (t & 1) * IMG : 0;             // image the chains of this step read
         if (!DB) {
-            trace_step(word, cell, 0, 0);
+            trace_step(word, 0, 0);
             W3_STAMP(4);
             lds_barrier();
             W3_STAMP(6);
         }
         // next step's input: lands during the chains
-        if (t + 1 < T) {
-            if (CIN == 1) cell = cells[(long)(t + 1) * B + bt];
-            else if (tvalid) word = spk_in[(long)(t + 1) * in_step + (bt * CIN + ci_t) * NTS + mtile];
-        }
+        if (t + 1 < T && tvalid) word = spk_in[(long)(t + 1) * in_step + (bt * CIN + ci_t) * NTS + mtile];
         // ---- (2) + (3) per tile: the chain in the pinned order (cp, kx, h), then its epilogue.  One tile after the other
         //      (two interleaved chains + a joint epilogue need 32 accumulator registers and twice the temporaries: with
         //      96 weight and 64 state registers that spilled ~160 VGPRs) ----
@@ -254,26 +234,21 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
         auto chain = [&](const int base, f32x16 &acc, const int st0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sbias[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
-            if (CIN == 1) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0], img[cur + base + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[NK - 1], img[cur + base + 2], acc, 0, 0, 0);
-            } else {
-                // the 6 B fragments of channel pairs cp + 2, cp + 3 are fetched before the MFMAs of pairs cp, cp + 1
-                float bq[2][6];
+            // the 6 B fragments of channel pairs cp + 2, cp + 3 are fetched before the MFMAs of pairs cp, cp + 1
+            float bq[2][6];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) bq[0][q] = img[cur + base + (q / 3) * 2 + (q % 3) * PST];
+            for (int q = 0; q < 6; ++q) bq[0][q] = img[cur + base + (q / 3) * 2 + (q % 3) * PST];
 #pragma unroll
-                for (int c2 = 0; c2 < 16; ++c2) {
-                    if (c2 + 1 < 16) {
+            for (int c2 = 0; c2 < 16; ++c2) {
+                if (c2 + 1 < 16) {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) bq[(c2 + 1) & 1][q] = img[cur + base + (2 * (c2 + 1) + q / 3) * 2 + (q % 3) * PST];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(CIN == 1) ? 0 : c2 * 6 + q], bq[c2 & 1][q], acc, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < 6; ++q) bq[(c2 + 1) & 1][q] = img[cur + base + (2 * (c2 + 1) + q / 3) * 2 + (q % 3) * PST];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c2 * 6 + q], bq[c2 & 1][q], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             W3_STAMP(st0);
         };
@@ -392,7 +367,7 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
             wp[cq * (unsigned)NW2] = ((uint32_t)vwA & 0xffffu) | ((uint32_t)vwB << 16);
             wp[(cq + 1) * (unsigned)NW2] = ((uint32_t)vwA >> 16) | ((uint32_t)vwB & 0xffff0000u);
         }
-        if (DB && t + 1 < T) trace_step(word, cell, cur, cur ^ IMG);         // step t+1's traces into the other image
+        if (DB && t + 1 < T) trace_step(word, cur, cur ^ IMG);         // step t+1's traces into the other image
         W3_STAMP(4);
         lds_barrier();
         W3_STAMP(5);
@@ -420,6 +395,134 @@ __global__ __launch_bounds__(512, CIN == 1 ? W3_WAVES_FIRST : 2) void k_lif_seq_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_lif_seq_w3f — the FIRST layer of that network (c_in = 1 -> 64 channels, input = one spike per step as a cell index) as a
+// register-only streaming kernel (round 5).  With one input channel the layer is not matrix work — three fmaf per output —
+// but a 137 GB write stream of pooled membrane values at batch 4096, and the MFMA form above (k_lif_seq_w3<1>: 8 tiles per
+// 512-thread workgroup, an LDS image, two barriers per step, a 16-value-per-lane epilogue behind every 2-MFMA "chain")
+// spent its step in dependent epilogue code at two waves per SIMD: 4.6 TB/s.  Here nothing is shared between waves:
+//   - a WAVE owns 128 consecutive pixels of the flattened plane of one sample (lane l: pixels 2l, 2l+1 = one pooling pair)
+//     and NCH of the 64 output channels, for all T steps;
+//   - the single input channel's traces are a function of the cell index alone, so every lane advances the traces of ITS
+//     FOUR pixels 2l-1 .. 2l+2 itself (the two neighbours redundantly: 10 packed instructions per step against ~12 per
+//     channel) — no LDS image, no cross-lane traffic, no barrier; a neighbour beyond the row end is the conv's zero padding;
+//   - weights of the NCH channels in SGPRs (wave-uniform), bias and the 2 x NCH refractory traces in VGPRs;
+//   - per channel: the pinned chain bias -> kx = 0, 1, 2 as three v_pk_fma_f32 on the pixel pair, the refractory update on
+//     the pair (packed, same IEEE operations as refractory() of dcll_internal.h), the (1,2) max-pool INSIDE the lane (one
+//     v_max_f32), the pooled spike = (pooled v > 0) as a v_cmp whose 64-bit lane mask IS the two packed output words of this
+//     (channel, segment), and one 256-byte store of pooled pv (two whole lines per instruction);
+//   - four or five waves per SIMD with independent instruction streams hide each other's latencies.
+// Same arithmetic, same outputs and state layout as k_lif_seq_w3<1> (bit-identical un-pooled v, spikes, state).
+constexpr int W3F_NCH = 8, W3F_WPB = 4;      // channels per wave, waves per workgroup (measured: below)
+template <bool REFRACTORY, int OUT, int NCH>
+__global__ __launch_bounds__(64 * W3F_WPB) void k_lif_seq_w3f(const int32_t *__restrict__ cells, const dcll_wsrc W,
+                                                      const float *__restrict__ bias, const float *__restrict__ tau4,
+                                                      float *__restrict__ eps0_g, float *__restrict__ eps1_g,
+                                                      float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
+                                                      float *__restrict__ pv_out, float *__restrict__ v_out, int T, int B, int HW,
+                                                      int logW, long nitems, float alpharp, float wrp)
+{
+    constexpr int NCG = 64 / NCH;
+    const int lane = threadIdx.x & 63;
+    // XCD-aware order (workgroup ids go round-robin over the 8 XCDs): the workgroups of one sample run on ONE XCD, one after
+    // the other — a sample-step's 256 KB of pooled map leave through one L2, close together in time
+    long bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const long item = uniform_long(bid * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (item >= nitems) return;                          // (whole waves; the kernel has no barrier)
+    const int NSEG = HW >> 7;                            // 128-pixel segments per sample plane
+    const int sg = __builtin_amdgcn_readfirstlane((int)(item % NSEG));
+    const int cg = __builtin_amdgcn_readfirstlane((int)((item / NSEG) % NCG));
+    const long b = uniform_long(item / NSEG / NCG);
+    const int ch0 = cg * NCH;
+
+    // ---- my four pixels: L = 2l-1 (left neighbour), A = 2l, B = 2l+1 (the pooling pair I own), R = 2l+2 --------------
+    const int pA = 128 * sg + 2 * lane, Wm = (1 << logW) - 1;
+    const bool vL = (pA & Wm) != 0, vR = ((pA + 2) & Wm) != 0;          // inside my row (else: zero padding)
+    // cell index that sets the input spike of each of them (a padding position never spikes)
+    const int qL = vL ? pA - 1 : -7, qA = pA, qB = pA + 1, qR = vR ? pA + 2 : -7;
+    const float ta = tau4[0], tm = tau4[1], tas = tau4[2], ts = tau4[3];
+    const long sb = b * HW + pA;
+    f32x2 e0LA = {vL ? eps0_g[sb - 1] : 0.0f, eps0_g[sb]}, e0BR = {eps0_g[sb + 1], vR ? eps0_g[sb + 2] : 0.0f};
+    f32x2 e1LA = {vL ? eps1_g[sb - 1] : 0.0f, eps1_g[sb]}, e1BR = {eps1_g[sb + 1], vR ? eps1_g[sb + 2] : 0.0f};
+
+    // ---- weights of my channels: wave-uniform, converted once (dcll_wsrc::at), kept in SGPRs; bias in VGPRs -----------
+    float w0[NCH], w1[NCH], w2[NCH], bv[NCH];
+    f32x2 arp[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int co = ch0 + c;
+        w0[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(W.at(co * 3 + 0, co))));
+        w1[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(W.at(co * 3 + 1, co))));
+        w2[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(W.at(co * 3 + 2, co))));
+        bv[c] = bias[co];
+        arp[c] = REFRACTORY ? *(const f32x2 *)(arp_g + (b * 64 + co) * HW + pA) : f32x2{0.0f, 0.0f};
+    }
+    const int HW2 = HW >> 1, NW2 = HW >> 6;              // pooled pixels / pooled words per channel plane
+    int cell = cells[b];
+    const f32x2 ta2 = {ta, ta}, tm2 = {tm, tm}, tas2 = {tas, tas}, al2 = {alpharp, alpharp}, wrp2 = {wrp, wrp};
+
+    for (int t = 0; t < T; ++t) {
+        // traces of the step (dcll/pytorch_libdcll.py:493-494, every op rounded separately; x * tau_s for x in {0, 1})
+        {
+            const f32x2 xLA = {cell == qL ? ts : 0.0f, cell == qA ? ts : 0.0f}, xBR = {cell == qB ? ts : 0.0f, cell == qR ? ts : 0.0f};
+            e0LA = xLA + tas2 * e0LA;
+            e0BR = xBR + tas2 * e0BR;
+            e1LA = ta2 * e1LA + e0LA * tm2;
+            e1BR = ta2 * e1BR + e0BR * tm2;
+        }
+        if (t + 1 < T) cell = cells[(long)(t + 1) * B + b];             // (scalar load; lands during the channel loop)
+        const f32x2 e1AB = {e1LA[1], e1BR[0]};
+        const long row = ((long)t * B + b) * 64 + ch0;
+        const auto prs = tile_rsrc(pv_out + row * HW2 + 64 * sg), vrs = tile_rsrc(v_out + row * HW + 128 * sg);
+        uint32_t wlo = 0, whi = 0;
+        static_for<0, NCH / 2>([&](auto cc) {
+            unsigned long long mk[2];
+            static_for<0, 2>([&](auto kc) {
+                constexpr int k = decltype(kc)::value, c = 2 * decltype(cc)::value + k;
+                // the pinned chain of the pixel pair: bias, then kx = 0, 1, 2 (oracle/dcll_oracle.c: fmaf(eps1, w, acc))
+                f32x2 acc = {bv[c], bv[c]};
+                acc = __builtin_elementwise_fma(e1LA, f32x2{w0[c], w0[c]}, acc);
+                acc = __builtin_elementwise_fma(e1AB, f32x2{w1[c], w1[c]}, acc);
+                acc = __builtin_elementwise_fma(e1BR, f32x2{w2[c], w2[c]}, acc);
+                f32x2 v2 = acc;
+                if (REFRACTORY) {                                       // refractory() of dcll_internal.h on the pair
+                    const f32x2 a2 = al2 * arp[c];
+                    v2 = acc + a2;
+                    arp[c] = __builtin_elementwise_fma(-spike01_pk(v2), wrp2, a2);
+                }
+                if (OUT & 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2), vrs, 8 * lane, 4 * c * HW, 0);
+                const float pm = __builtin_fmaxf(v2[0], v2[1]);         // (1,2) max-pool of v; v is never NaN
+                // pooled spike = max(s_a, s_b) = (pooled v > 0) exactly; bit l of the ballot = pooled pixel 64 sg + l
+                mk[k] = __ballot(pm > 0.0f);
+                if (OUT & 1)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((OUT & 4) ? pm : sigmoidf_dev(pm)), prs, 4 * lane, 4 * c * HW2, 0);
+            });
+            // the two words of each channel parked in lane c of (wlo, whi); s_nop 1 = the two wait states a v_writelane needs
+            // behind the v_cmp that wrote its SGPR, whichever of the two compares the compiler placed last (as in k_lif_seq_w3)
+            constexpr int c0 = 2 * decltype(cc)::value;
+            uint32_t &wl = wlo, &wh = whi;      // (named here: an asm operand alone does not capture in a generic lambda)
+            asm("s_nop 1\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %1, %3, %6\n\t"
+                "v_writelane_b32 %0, %4, %7\n\tv_writelane_b32 %1, %5, %7"
+                : "+v"(wl), "+v"(wh) : "s"((uint32_t)mk[0]), "s"((uint32_t)(mk[0] >> 32)), "s"((uint32_t)mk[1]),
+                  "s"((uint32_t)(mk[1] >> 32)), "n"(c0), "n"(c0 + 1));
+        });
+        if (spk_out && lane < NCH) {                                    // lane c: the two words of channel ch0 + c
+            uint32_t *wp = spk_out + (row + lane) * NW2 + 2 * sg;
+            *(u32x2 *)wp = u32x2{wlo, whi};
+        }
+    }
+    // ---- state back to HBM: traces by the wave of channel group 0 (every group holds the same), arp by its owner ----------
+    if (cg == 0) {
+        *(f32x2 *)(eps0_g + sb) = f32x2{e0LA[1], e0BR[0]};
+        *(f32x2 *)(eps1_g + sb) = f32x2{e1LA[1], e1BR[0]};
+    }
+    if (REFRACTORY) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *(f32x2 *)(arp_g + (b * 64 + ch0 + c) * HW + pA) = arp[c];
+    }
+}
+
 // geometry served: c_in 1 or 64, c_out 64, kernel (1,3), padding (0,1), pooling (1,2), w a power of two <= 256,
 // h * w a multiple of 32 (64 when packed spikes are wanted), time constants per input channel
 bool dcll_seq_w3_geometry(const dcll_conv_desc *d)
@@ -437,47 +540,65 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     if (HW >= (1L << 24)) return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3): plane larger than 2^24 pixels");
     if (spk_out && HW % 64 != 0)
         return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3): packed pooled spikes need h * w % 64 == 0");
-    if (d->c_in == 1 && (HW / 32) % W3_NT != 0)
-        return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3), first layer: h * w must be a multiple of 256");
+    if (d->c_in == 1 && HW % 128 != 0)
+        return fail(DCLL_ERR_UNSUPPORTED, "sequence kernel (1,3), first layer: h * w must be a multiple of 128");
     int logW = 0;
     while ((1 << logW) < d->w) ++logW;
     const long ntile = (long)B * (HW / 32);
     const long nwg = (ntile + W3_NT - 1) / W3_NT;
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x tiles exceeds the grid limit");
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0) | ((pv_out && presigmoid) ? 4 : 0);
-#define DCLL_LAUNCH_W3W(C, R, O, WD)                                                                                    \
+    if (d->c_in == 1) {     // first layer: k_lif_seq_w3f, one wave per (sample, 128-pixel segment, group of W3F_NCH channels)
+        const long nitems = (long)B * (HW / 128) * (64 / W3F_NCH);
+        const long nblk = (nitems + W3F_WPB - 1) / W3F_WPB;
+        if (nblk > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x segments exceeds the grid limit");
+#define DCLL_LAUNCH_W3F(R, O)                                                                                           \
+    hipLaunchKernelGGL((k_lif_seq_w3f<R, O, W3F_NCH>), dim3((unsigned)nblk), dim3(64 * W3F_WPB), 0, st, cells, W, b, tau4, \
+                       eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, nitems, d->alpharp, d->wrp)
+#define DCLL_LAUNCH_W3FO(R)                                                                                             \
+    switch (out) {                                                                                                      \
+    case 0: DCLL_LAUNCH_W3F(R, 0); break;                                                                               \
+    case 1: DCLL_LAUNCH_W3F(R, 1); break;                                                                               \
+    case 2: DCLL_LAUNCH_W3F(R, 2); break;                                                                               \
+    case 3: DCLL_LAUNCH_W3F(R, 3); break;                                                                               \
+    case 5: DCLL_LAUNCH_W3F(R, 5); break;                                                                               \
+    default: DCLL_LAUNCH_W3F(R, 7); break;                                                                              \
+    }
+        if (d->refractory) { DCLL_LAUNCH_W3FO(true) } else { DCLL_LAUNCH_W3FO(false) }
+#undef DCLL_LAUNCH_W3FO
+#undef DCLL_LAUNCH_W3F
+        HIP_CHECK_LAUNCH("k_lif_seq_w3f");
+        return DCLL_OK;
+    }
+#define DCLL_LAUNCH_W3W(R, O, WD)                                                                                       \
     do {                                                                                                                \
         if (ntile % W3_NT == 0)                                                                                         \
-            hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD, true>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, \
-                               b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp);  \
+            hipLaunchKernelGGL((k_lif_seq_w3<64, R, O, WD, true>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, W, b, tau4, eps0, \
+                               eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp);             \
         else                                                                                                            \
-            hipLaunchKernelGGL((k_lif_seq_w3<C, R, O, WD, false>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, cells, W, \
-                               b, tau4, eps0, eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp);  \
+            hipLaunchKernelGGL((k_lif_seq_w3<64, R, O, WD, false>), dim3((unsigned)nwg), dim3(512), 0, st, spk_in, W, b, tau4, eps0, \
+                               eps1, arp, spk_out, pv_out, v_out, T, B, (int)HW, logW, d->alpharp, d->wrp);             \
     } while (0)
-#define DCLL_LAUNCH_W3(C, R, O)                                                                                         \
+#define DCLL_LAUNCH_W3(R, O)                                                                                            \
     do {                                                                                                                \
         switch (logW) {                                                                                                 \
-        case 1: DCLL_LAUNCH_W3W(C, R, O, 1); break;                                                                     \
-        case 2: DCLL_LAUNCH_W3W(C, R, O, 2); break;                                                                     \
-        case 3: DCLL_LAUNCH_W3W(C, R, O, 3); break;                                                                     \
-        case 4: DCLL_LAUNCH_W3W(C, R, O, 4); break;                                                                     \
-        default: DCLL_LAUNCH_W3W(C, R, O, 5); break;                                                                    \
+        case 1: DCLL_LAUNCH_W3W(R, O, 1); break;                                                                        \
+        case 2: DCLL_LAUNCH_W3W(R, O, 2); break;                                                                        \
+        case 3: DCLL_LAUNCH_W3W(R, O, 3); break;                                                                        \
+        case 4: DCLL_LAUNCH_W3W(R, O, 4); break;                                                                        \
+        default: DCLL_LAUNCH_W3W(R, O, 5); break;                                                                       \
         }                                                                                                               \
     } while (0)
-#define DCLL_LAUNCH_W3O(C, R)                                                                                           \
+#define DCLL_LAUNCH_W3O(R)                                                                                              \
     switch (out) {                                                                                                      \
-    case 0: DCLL_LAUNCH_W3(C, R, 0); break;                                                                              \
-    case 1: DCLL_LAUNCH_W3(C, R, 1); break;                                                                              \
-    case 2: DCLL_LAUNCH_W3(C, R, 2); break;                                                                              \
-    case 3: DCLL_LAUNCH_W3(C, R, 3); break;                                                                              \
-    case 5: DCLL_LAUNCH_W3(C, R, 5); break;                                                                              \
-    default: DCLL_LAUNCH_W3(C, R, 7); break;                                                                             \
+    case 0: DCLL_LAUNCH_W3(R, 0); break;                                                                                \
+    case 1: DCLL_LAUNCH_W3(R, 1); break;                                                                                \
+    case 2: DCLL_LAUNCH_W3(R, 2); break;                                                                                \
+    case 3: DCLL_LAUNCH_W3(R, 3); break;                                                                                \
+    case 5: DCLL_LAUNCH_W3(R, 5); break;                                                                                \
+    default: DCLL_LAUNCH_W3(R, 7); break;                                                                               \
     }
-    if (d->c_in == 1) {
-        if (d->refractory) { DCLL_LAUNCH_W3O(1, true) } else { DCLL_LAUNCH_W3O(1, false) }
-    } else {
-        if (d->refractory) { DCLL_LAUNCH_W3O(64, true) } else { DCLL_LAUNCH_W3O(64, false) }
-    }
+    if (d->refractory) { DCLL_LAUNCH_W3O(true) } else { DCLL_LAUNCH_W3O(false) }
 #undef DCLL_LAUNCH_W3O
 #undef DCLL_LAUNCH_W3
 #undef DCLL_LAUNCH_W3W

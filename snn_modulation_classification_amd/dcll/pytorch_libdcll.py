@@ -484,7 +484,7 @@ class Conv2dDCLLlayer(nn.Module):
                 return 'packed'
         if i.kernel_size == (1, 3) and i.padding == (0, 1) and self.pooling == (1, 2) and i.out_channels == 64 and \
                 2 <= W <= 256 and (W & (W - 1)) == 0 and (H * W) % 32 == 0:
-            if i.in_channels == 1 and (H * W) % 256 == 0:
+            if i.in_channels == 1 and (H * W) % 128 == 0:
                 return 'cells'
             if i.in_channels == 64:
                 return 'packed'

@@ -886,7 +886,9 @@ def test_readout_direct_forms(dev, rows, K, N):
                                                        (64, (4, 32), 1.0, 5, 3, False), (64, (16, 8), 1.0, 7, 5, False), (64, (16, 16), 0.0, 9, 2, False),
                                                        (64, (16, 8), 1.0, 5, 4, False), (64, (16, 4), 1.0, 5, 4, False), (64, (16, 2), 1.0, 5, 8, False),
                                                        (1, (16, 128), 1.0, 9, 2, False),
-                                                       (1, (2, 128), 0.0, 6, 3, True)])
+                                                       (1, (2, 128), 0.0, 6, 3, True),
+                                                       (1, (1, 128), 1.0, 7, 5, False), (1, (8, 32), 1.0, 8, 3, False),
+                                                       (1, (4, 256), 1.0, 6, 3, False), (1, (64, 2), 0.0, 6, 2, False)])
 def test_sequence_w3_vs_oracle(dev, cin, hw, wrp, T, B, zero_state):
     """k_lif_seq_w3 — the fused all-T kernel of the radio_ml_conv_ref.yaml geometry (64 channels, (1,3) kernel, pad
     (0,1), max-pool (1,2); pixel tiles over the flattened plane, pooling pairs in lanes j / j+16) — == C oracle
