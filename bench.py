@@ -250,8 +250,8 @@ def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
                 "algorithmic_flop_per_step": flop_w3 / steps}
     if roof:
         # HBM traffic of the six launches: PMC counters cannot be read from inside this process — the summary of the separate
-        # `rocprofv3 --pmc` passes of this command (profiles/collect_r03.sh ref) is used when it is for this batch
-        for rnd in (4, 3):
+        # `rocprofv3 --pmc` passes of this command (profiles/collect_r05.sh ref) is used when it is for this batch
+        for rnd in (5, 4, 3):
             name = "r%02d_pmc_ref_b%d.json" % (rnd, B)
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)) as f:
@@ -268,9 +268,9 @@ def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
     kernel_ms = {k: float(np.sum([s_.elapsed_time(e_) for s_, e_ in v])) / steps for k, v in prof.items()}
     hbm = {}
     if kernel_ms.get("lif_c1"):
-        # first layer (k_lif_seq_w3<1>): an HBM write stream — pooled pv / v (T*B*64*16*64 floats) + packed pooled spikes
+        # first layer (k_lif_seq_w3f): an HBM write stream — pooled pv / v (T*B*64*16*64 floats) + packed pooled spikes
         byt = T_STEPS * B * 64 * H * (W // 2) * 4 * (1 + 1 / 32.0)
-        hbm["first_layer (k_lif_seq_w3<1> + statistics pass)"] = {
+        hbm["first_layer (k_lif_seq_w3f + statistics pass)"] = {
             "bytes_per_launch": byt, "ms": kernel_ms["lif_c1"], "GBps": byt / kernel_ms["lif_c1"] / 1e6,
             "frac_of_peak": byt / kernel_ms["lif_c1"] / 1e6 / PEAK_HBM_GBS}
     if kernel_ms.get("readout"):

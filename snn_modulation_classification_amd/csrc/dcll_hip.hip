@@ -1184,10 +1184,7 @@ __global__ __launch_bounds__(256, 3) void k_lif_seq_c1(int c_out, const int32_t 
     __shared__ float plane[2 * PLANE];
     __shared__ float sbias[32];
     __shared__ int scell[IQ ? C1_MAXT : 1];
-    // XCD-aware order (workgroup ids go round-robin over the 8 XCDs): neighbouring samples — neighbours in every output
-    // array — run on the same XCD, so their 32 KB pv rows of a step leave through one L2 (see k_lif_seq_w3f)
-    const int b = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-    const int pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63;
+    const int b = blockIdx.x, pix = threadIdx.x, y = pix >> 4, x = pix & 15, lane = pix & 63;
     const int w = __builtin_amdgcn_readfirstlane(pix >> 6);
     const int h = lane >> 5, j = lane & 31;
     const float alpha = tau4[0], tau_m = tau4[1], alphas = tau4[2], tau_s = tau4[3];

@@ -39,6 +39,9 @@ constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
 #ifndef W3_EPG
 #define W3_EPG 2                    // register pairs per epilogue group
 #endif
+#ifndef W3_EPI
+#define W3_EPI 1                    // epilogue form: 0 pair by pair, 1 two pairs in lockstep (experiments/ablate_w3)
+#endif
 #ifndef W3_ORDER
 #define W3_ORDER 0                  // 0: chain A, epilogue A, chain B, epilogue B; 1: both chains, then both epilogues
 #endif
@@ -266,6 +269,70 @@ __global__ __launch_bounds__(512, 2) void k_lif_seq_w3(const uint32_t *__restric
             int d2p = 8 * HW2, d6p = 24 * HW2, d1v = 4 * HW, d5v = 20 * HW, pp = 0, vp = 0;
             asm volatile("" : "+v"(lp), "+v"(lv), "+s"(d2p), "+s"(d6p), "+s"(d1v), "+s"(d5v), "+s"(pp), "+s"(vp));
             const auto prs = tile_rsrc(pv_out + row * HW2), vrs = tile_rsrc(v_out + row * HW);
+#if W3_EPI == 1
+            // Second form of the epilogue (round 5): on gfx950 a packed-fp32 result cannot be consumed by the NEXT vector
+            // instruction (one wait state: the compiler fills it with s_nop 0), and the first read of an accumulator waits 15
+            // states behind the chain's last MFMA.  Written pair by pair the update was a serial chain — 134 wait states per
+            // wave and step sat in s_nop.  Here (i) alpharp * arp of all 16 values comes first, in place (independent of the
+            // accumulators: 8 instructions inside the last MFMA's shadow), (ii) two register pairs advance in lockstep, so
+            // every packed instruction has an independent neighbour.
+            if (REFRACTORY) {
+                const f32x2 al2 = {alpharp, alpharp};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 a2 = al2 * f32x2{arp[r], arp[r + 1]};
+                    arp[r] = a2[0], arp[r + 1] = a2[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            static_for<0, 4>([&](auto gc) {
+                constexpr int r0 = 4 * decltype(gc)::value;
+                const f32x2 wrp2 = {wrp, wrp}, big = {0x1p127f, 0x1p127f};
+                f32x2 v0 = {acc[r0], acc[r0 + 1]}, v1 = {acc[r0 + 2], acc[r0 + 3]};
+                if (REFRACTORY) {
+                    const f32x2 a0 = {arp[r0], arp[r0 + 1]}, a1 = {arp[r0 + 2], arp[r0 + 3]};
+                    v0 = v0 + a0, v1 = v1 + a1;
+                    f32x2 s0, s1;
+                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(s0) : "v"(v0), "s"(big));
+                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(s1) : "v"(v1), "s"(big));
+                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(s0) : "v"(s0), "s"(big));
+                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(s1) : "v"(s1), "s"(big));
+                    const f32x2 n0 = __builtin_elementwise_fma(-s0, wrp2, a0), n1 = __builtin_elementwise_fma(-s1, wrp2, a1);
+                    arp[r0] = n0[0], arp[r0 + 1] = n0[1], arp[r0 + 2] = n1[0], arp[r0 + 3] = n1[1];
+                }
+                float vx0 = v0[0], vy0 = v0[1], vx1 = v1[0], vy1 = v1[1];
+                // pinned at the group: the new arp is not read before the next step (see the first form)
+                asm volatile("" : "+v"(arp[r0]), "+v"(arp[r0 + 1]), "+v"(arp[r0 + 2]), "+v"(arp[r0 + 3]), "+v"(vx0), "+v"(vy0), "+v"(vx1), "+v"(vy1));
+                if ((OUT & 2) && valid) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vx0), vrs, lv, vp, 0);
+                    vp += d1v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vy0), vrs, lv, vp, 0);
+                    vp += d1v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vx1), vrs, lv, vp, 0);
+                    vp += d1v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vy1), vrs, lv, vp, 0);
+                    vp += d5v;
+                }
+                const u32x2 sw0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(vx0), __float_as_uint(vy0), false, false);
+                const u32x2 sw1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(vx1), __float_as_uint(vy1), false, false);
+                float pm0, pm1;
+                asm("v_max_f32 %0, %1, %2" : "=v"(pm0) : "v"(__uint_as_float(sw0[0])), "v"(__uint_as_float(sw0[1])));
+                asm("v_max_f32 %0, %1, %2" : "=v"(pm1) : "v"(__uint_as_float(sw1[0])), "v"(__uint_as_float(sw1[1])));
+                const unsigned long long mk0 = __ballot(pm0 > 0.0f), mk1 = __ballot(pm1 > 0.0f);
+                int &vwr = vw;
+                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\t"
+                    "v_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8"
+                    : "+v"(vwr) : "s"((uint32_t)mk0), "s"((uint32_t)(mk0 >> 32)), "s"((uint32_t)mk1), "s"((uint32_t)(mk1 >> 32)),
+                      "n"(r0 / 2), "n"(32 + r0 / 2), "n"(r0 / 2 + 1), "n"(33 + r0 / 2));
+                if ((OUT & 1) && valid) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((OUT & 4) ? pm0 : sigmoidf_dev(pm0)), prs, lp, pp, 0);
+                    pp += d2p;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((OUT & 4) ? pm1 : sigmoidf_dev(pm1)), prs, lp, pp, 0);
+                    pp += d6p;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#else
             static_for<0, 16 / (2 * W3_EPG)>([&](auto gc) {             // W3_EPG pairs at a time: keeps the temporaries few
                 constexpr int r0 = 2 * W3_EPG * decltype(gc)::value;
                 float pm[W3_EPG];
@@ -341,6 +408,7 @@ __global__ __launch_bounds__(512, 2) void k_lif_seq_w3(const uint32_t *__restric
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+#endif
             W3_STAMP(st0);
         };
         f32x16 accA, accB;
