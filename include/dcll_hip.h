@@ -257,7 +257,8 @@ int dcll_dense_lif_sequence(const dcll_dense_desc *d, const float *x, const floa
  * (one sample per workgroup) or on any plane with h % 8 == 0 and w % 32 == 0 — e.g. the 128x128 default of
  * test_radio_ml.py:52 — (one workgroup per 8x32 tile; no fused readout there).
  * Also served: the layers of networks/radio_ml_conv_ref.yaml — c_in==64 (first layer: dcll_conv_lif_sequence_cells, c_in==1),
- * c_out==64, kernel (1,3), padding (0,1), pooling (1,2), w a power of two <= 256, h*w % 32 == 0 (k_lif_seq_w3).  For this
+ * c_out==64, kernel (1,3), padding (0,1), pooling (1,2), w a power of two <= 256, h*w % 32 == 0 (k_lif_seq_w3; the first
+ * layer, k_lif_seq_w3f: h*w % 128 == 0, state and output pointers 8-byte aligned).  For this
  * POOLING geometry the outputs are the pooled maps: spk_out (T,B,64,h*(w/2)/32) [needs h*w % 64 == 0], pv_out
  * (T,B,64,h,w/2); v_out stays un-pooled (T,B,64,h,w); state_scratch is not used.
  *   spk_in   (T,B,c_in,h*w/32) uint32   packed input spikes: bit (y*w+x)%32 of word (y*w+x)/32

@@ -617,6 +617,9 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
     if (nwg > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x tiles exceeds the grid limit");
     const int out = (pv_out ? 1 : 0) | (v_out ? 2 : 0) | ((pv_out && presigmoid) ? 4 : 0);
     if (d->c_in == 1) {     // first layer: k_lif_seq_w3f, one wave per (sample, 128-pixel segment, group of W3F_NCH channels)
+        // (its state, un-pooled v and spike words move as 8-byte pairs)
+        if ((((uintptr_t)eps0 | (uintptr_t)eps1 | (uintptr_t)arp | (uintptr_t)spk_out | (uintptr_t)v_out) & 7) != 0)
+            return fail(DCLL_ERR_INVALID, "sequence kernel (1,3), first layer: state / spike / v pointers must be 8-byte aligned");
         const long nitems = (long)B * (HW / 128) * (64 / W3F_NCH);
         const long nblk = (nitems + W3F_WPB - 1) / W3F_WPB;
         if (nblk > 0x7fffffffL) return fail(DCLL_ERR_INVALID, "sequence kernel (1,3): batch x segments exceeds the grid limit");
