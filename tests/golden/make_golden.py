@@ -18,6 +18,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-variants # only the arp 0 / scalar-tau rollouts at 16x16 (added in round 5)
     python tests/golden/make_golden.py --only-g7b # only the dense sequences (added in round 5)
     python tests/golden/make_golden.py --only-carry # only the two-batch state carry-over run (added in round 5)
+    python tests/golden/make_golden.py --only-refyaml-variants # only the arp 0 / scalar-tau runs of radio_ml_conv_ref.yaml (round 5)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -270,6 +271,27 @@ def g2_ref_yaml(lib, nets, du):
             r[k] = np.ascontiguousarray(a[:, 0, 0])
     np.savez_compressed(os.path.join(OUT, "g2_ref_yaml_h16_w128_t64_b2.npz"), **r)
     return dict(H=16, W=128, T=64, B=2, layers=7)
+
+
+def g2_ref_yaml_variants(lib, nets, du, seeds=(1, 1)):
+    """networks/radio_ml_conv_ref.yaml through the DCLL builder (g2_ref_yaml's network and plane) in the two settings the scripts
+    do not use: `--arp 0` (the NON-refractory ContinuousConv2D, :407-426) with random_tau, and `random_tau=False` (scalar time
+    constants, :349-356) with arp 1.  B = 2, T = 32.  Pins the REFRACTORY = false instantiations of the (1,3) kernels — the
+    streaming first layer k_lif_seq_w3f included — and their scalar-tau use against the reference itself."""
+    out = {}
+    for tag, kw, sd_ in (("norp", dict(arp=0.0), seeds[0]), ("scalar_tau", dict(random_tau=False), seeds[1])):
+        r = rollout(lib, nets, du, "radio_ml_conv_ref.yaml", R=None, T=32, B=2, args=make_args(**kw), full_traces=False,
+                    store_readouts=False, hw=(16, 128), store_final=False, iq_seed=sd_)
+        r.pop("minabs_v")
+        for k in list(r):       # time constants broadcast over the plane (:398-405): stored per channel
+            if k.startswith("sd/") and k.split(".")[-1] in ("alpha", "tau_m__dt", "alphas", "tau_s__dt") and r[k].ndim == 3:
+                a = r[k]
+                assert np.array_equal(a, np.broadcast_to(a[:, :1, :1], a.shape))
+                r[k] = np.ascontiguousarray(a[:, 0, 0])
+        out.update({tag + "/" + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(OUT, "g2_ref_yaml_h16_w128_t32_b2_variants.npz"), **out)
+    return dict(H=16, W=128, T=32, B=2, layers=7, iq_seeds=list(seeds),
+                variants=["norp (arp 0, random_tau)", "scalar_tau (arp 1, random_tau False)"])
 
 
 def g2_r16_variants(lib, nets, du):
@@ -752,6 +774,13 @@ def main():
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, default=lambda o: list(o))
         return
+    if "--only-refyaml-variants" in sys.argv:
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["g2_ref_yaml_variants"] = g2_ref_yaml_variants(lib, nets, du)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, default=lambda o: list(o))
+        return
     if "--only-refyaml" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -793,6 +822,7 @@ def main():
         "g2_ref_yaml": g2_ref_yaml(lib, nets, du),
         "g2_r128": g2_r128(lib, nets, du),
         "g2_r16_variants": g2_r16_variants(lib, nets, du),
+        "g2_ref_yaml_variants": g2_ref_yaml_variants(lib, nets, du),
         "g5": {k: [{kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in d.items()} for d in v]
                for k, v in g5_specs(nets).items()},
     }

@@ -240,6 +240,50 @@ def test_seeded_ref_yaml_network_and_both_oracles_on_the_reference_run(golden, c
         assert np.array_equal(np.array(ref.clout[i]), g["clout/%d" % i]) and np.array_equal(ref.votes()[i], g["vote/%d" % i])
 
 
+@pytest.mark.parametrize("tag,arp,rtau", [("norp", 0.0, True), ("scalar_tau", 1.0, False)])
+def test_seeded_ref_yaml_network_and_both_oracles_on_the_arp0_and_scalar_tau_runs(golden, cpu_device, tag, arp, rtau):
+    """Fixture g2_ref_yaml_h16_w128_t32_b2_variants (from the imported reference): radio_ml_conv_ref.yaml through the
+    reference's DCLL builder with `--arp 0` (non-refractory ContinuousConv2D, dcll/pytorch_libdcll.py:407-426) and with scalar
+    time constants (`random_tau=False`, :349-356), B = 2, T = 32.  Seeded constructor == the reference's network, torch oracle
+    == the run bit for bit, C oracle == every pooled spike of all seven layers (0 flips), readouts within 1e-4."""
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from oracle import c_oracle as C
+    from oracle import torch_ref as R
+    g = _Sub(golden("g2_ref_yaml_h16_w128_t32_b2_variants.npz"), tag + "/")
+    convs = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv_ref.yaml"))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    net = ConvNetwork(_args(arp=arp, random_tau=rtau), (1, 16, 128), 2, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None,
+                      opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True)
+    assert len(net.dcll_slices) == 7 and net.sequence_supported()
+    _check_against_r32_fixture(net, g, n_layers=7)
+    sds = [{k: v.detach().clone() for k, v in s.dclllayer.state_dict().items()} for s in net.dcll_slices]
+    ref = R.RefConvNetwork(sds, convs, arp)
+    orc = C.OracleConvNetwork([{k: v.numpy() for k, v in sd.items()} for sd in sds], convs, (16, 128), arp)
+    cells = g["cells"]
+    T, B = cells.shape
+    torch.set_num_threads(1)
+    worst = 0.0
+    for step in range(T):
+        x = torch.zeros(B, 1, 16 * 128)
+        x[torch.arange(B), 0, torch.from_numpy(cells[step]).long()] = 1.0
+        x = x.reshape(B, 1, 16, 128)
+        outs = ref.test(x)
+        oo = orc.step(x.numpy())
+        for i, (o, p, pv, v) in enumerate(outs):
+            bits = np.unpackbits(g["spikes/%d" % i][step], axis=-1, bitorder="little")
+            pooled = R.max_pool((v > 0).float(), convs[i]["pooling"]).reshape(B, -1).numpy()
+            assert np.array_equal(pooled, bits[:, :pooled.shape[1]]), ("torch oracle", step, i)
+            assert np.array_equal(p.numpy(), g["p/%d" % i][step]), (step, i)
+            assert np.array_equal(oo[i]["s"].reshape(B, -1), bits[:, :pooled.shape[1]]), ("C oracle: spike flip", step, i)
+            worst = max(worst, float(np.abs(oo[i]["p"] - g["p/%d" % i][step]).max()))
+        assert np.array_equal(outs[-1][0].numpy(), g["o_last"][step])
+    assert worst <= 1e-4
+    for i in range(7):
+        assert np.array_equal(np.array(ref.clout[i]), g["clout/%d" % i]) and np.array_equal(ref.votes()[i], g["vote/%d" % i])
+
+
 def test_seeded_network_and_both_oracles_on_the_default_128x128_plane(golden, cpu_device):
     """Fixture g2_radio_r128_t12_b2: the reference on its ARGPARSE-DEFAULT I/Q plane (128x128; train.py:37-40), B = 2, T = 12.
     Seeded constructor == the reference's network (conv tensors element for element, the 50 MB readout matrices by
