@@ -151,7 +151,9 @@ int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, 
 /*
  * Backward of one Conv2dDCLLlayer step for local learning — what loss.backward() reaches in DCLLBase.train_dcll
  * (dcll/pytorch_libdcll.py:690-704).  Call after dcll_conv_lif_step of the same step, before the next one.
- *   eps1 (B,c_in,h,w) state after the step ; v = out_v of the step ; pv_pooled = out_pv of the step
+ *   eps1 (B,c_in,h,w) state after the step ; v = out_v of the step ; pv_pooled = out_pv of the step.  v may be NULL for a
+ *   layer WITHOUT pooling and target <= 32 whose pv_pooled is given: sigmoid'(v) = pv (1 - pv) is then taken from the stored pv —
+ *   the bits the kernel would recompute from v (what torch's sigmoid backward does, too) — and the step need not write out_v
  *   incoming gradients (each may be NULL): g_p (B,target) of pvoutput, g_o (B,target) of the output_ logits,
  *   g_pv (B,c_out,ph,pw) of pv, g_v (B,c_out,ch,cw) of pvmem
  *   results: dW (c_out,c_in,kh,kw), db (c_out) [may be NULL]; d_outW (target, c_out*ph*pw), d_outb (target) iff g_o

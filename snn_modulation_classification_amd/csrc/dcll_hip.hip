@@ -678,7 +678,9 @@ __global__ __launch_bounds__(128) void k_bwd_wgrad_c1(const float *__restrict__ 
 constexpr int DV_MAXPB = 16;            // samples per workgroup of k_bwd_dv_nopool (its per_block argument), at most
 // NP: N rounded up to a multiple of 8 — the sum over the readout weights runs over NP terms without a test per term (the
 // padding terms are 0 * 0); with the test the loop was a chain of branch, LDS read, wait, FMA (24 us at B = 512)
-template <int NP>
+// FROM_PV: `v` holds the layer's pv = sigmoid(v) as its forward wrote it (a layer without pooling: same shape, and the same
+// bits this kernel would recompute): the learning forward then does not have to store the membrane map at all
+template <int NP, bool FROM_PV>
 __global__ __launch_bounds__(256) void k_bwd_dv_nopool(int K, int N, const float *__restrict__ v,
                                                         const float *__restrict__ g_p, const float *__restrict__ g_pv,
                                                         const float *__restrict__ g_v, const float *__restrict__ i2o_W,
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256) void k_bwd_dv_nopool(int K, int N, const float
                 }
                 g += acc;
             }
-            const float pv = sigmoidf_dev(vv[q]);
+            const float pv = FROM_PV ? vv[q] : sigmoidf_dev(vv[q]);
             float out = g * pv * (1.0f - pv);
             if (g_v) out += ga[q];
             if (bg + q < b1) gvf[(long)b * K + k] = out;
@@ -3066,7 +3068,10 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
 {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!eps1 || !v || (!dW && !open_part) || !scratch) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: null pointer");
+    const bool nopool = d->pool_h == 1 && d->pool_w == 1 && d->target <= 32;
+    if (!eps1 || (!dW && !open_part) || !scratch) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: null pointer");
+    if (!v && !(nopool && pv_pooled))
+        return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: v may be NULL only for a layer without pooling whose pv is given");
     if (g_p && !i2o_W) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: g_p needs i2o_W");
     if (g_o && (!pv_pooled || !d_outW || !d_outb)) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: g_o needs pv_pooled, d_outW, d_outb");
     if (d->kh * d->kw > WG_MAXTAPS) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: kernels up to 64 taps");
@@ -3075,11 +3080,18 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
     int ch, cw, ph, pw;
     conv_shape(d, &ch, &cw, &ph, &pw);
     const long nconv = (long)B * d->c_out * ch * cw;
-    if (d->pool_h == 1 && d->pool_w == 1 && d->target <= 32) {
+    if (nopool) {
         const int Kmap = d->c_out * ch * cw, per_block = 16;
         const dim3 grid(nblk(Kmap, 256), nblk(B, per_block));
-#define DCLL_DV(NP_) hipLaunchKernelGGL(k_bwd_dv_nopool<NP_>, grid, dim3(256), 0, st, Kmap, d->target, v, g_p, g_pv, g_v, \
-                                        i2o_W, scratch, B, per_block)
+#define DCLL_DV(NP_)                                                                                                    \
+    do {                                                                                                                \
+        if (v)                                                                                                          \
+            hipLaunchKernelGGL((k_bwd_dv_nopool<NP_, false>), grid, dim3(256), 0, st, Kmap, d->target, v, g_p, g_pv, g_v,   \
+                               i2o_W, scratch, B, per_block);                                                           \
+        else        /* sigmoid' from the stored pv (bit-identical: the forward's own sigmoid of the same v) */           \
+            hipLaunchKernelGGL((k_bwd_dv_nopool<NP_, true>), grid, dim3(256), 0, st, Kmap, d->target, pv_pooled, g_p, g_pv, \
+                               g_v, i2o_W, scratch, B, per_block);                                                      \
+    } while (0)
         if (d->target <= 8) DCLL_DV(8);
         else if (d->target <= 16) DCLL_DV(16);
         else if (d->target <= 24) DCLL_DV(24);

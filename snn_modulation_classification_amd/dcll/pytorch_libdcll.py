@@ -896,10 +896,12 @@ class DCLLBase(nn.Module):
         loss = self._learn_tail(ctx)
         return ctx['out'] + (loss, ctx['learned'])
 
-    def _learn_forward(self, input, target, want_loss=True, clout_out=None, defer=False):
+    def _learn_forward(self, input, target, want_loss=True, clout_out=None, defer=False, want_v=True):
         """The layer kernel of one learning step (+ its readout tail unless `defer`): -> ctx for _learn_tail.  With `defer`
         the readouts, loss gradients and the backward are ALL left to _learn_tail: ConvNetwork.learn launches the layer
-        kernels of every slice first — slice l+1 needs slice l's spikes, not its readouts — and the tails behind them."""
+        kernels of every slice first — slice l+1 needs slice l's spikes, not its readouts — and the tails behind them.
+        `want_v=False` (the caller discards the returned tuple): a layer without pooling does not store its membrane map —
+        the backward takes sigmoid' from the stored pv, the same bits (dcll_conv_lif_backward with v == NULL)."""
         L = self.dclllayer
         i2h = L.i2h
         bufs = self.__dict__.setdefault('_learn_bufs', {})
@@ -917,11 +919,16 @@ class DCLLBase(nn.Module):
                 fin = dict(clout=None)
             s, p, o, pv, v = i2h._step(input, L.pooling, L.i2o, L.output_ if L.output_layer else None, out=bufs,
                                        stacked=L.stacked_readout() if L.output_layer else None, finish=fin,
-                                       defer_ro=defer)
+                                       defer_ro=defer, want_v=want_v or not self._backward_from_pv())
             if self.collect_stats and (self.iter % 20) == 0:
                 self.activity_hist.append((ops.pv_lowhigh(pv, 1, self.iter - 1)[0], pv.numel()))
         return dict(out=((o if L.output_layer else s), p, pv, v), fin=fin, learned=learned, rec=rec, input=input,
                     target=target, want_loss=want_loss, clout_out=clout_out, p=p, o=o, pv=pv, v=v)
+
+    def _backward_from_pv(self):
+        """True if this slice's backward can take sigmoid' from pv: no pooling, <= 32 readout rows (k_bwd_dv_nopool)."""
+        L = self.dclllayer
+        return tuple(L.pooling) == (1, 1) and L.i2o.weight.shape[0] <= 32
 
     def _learn_tail(self, ctx, open_reduce=False):
         """What follows the layer kernel of a learning step: the (deferred) readout tail, then — once iter >= burnin — the

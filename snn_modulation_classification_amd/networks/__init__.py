@@ -135,7 +135,8 @@ class ConvNetwork(torch.nn.Module):
         spikes, ctxs = x, []
         for i, s in enumerate(self.dcll_slices):
             ctx = s._learn_forward(spikes, labels, want_loss=False, defer=True,              # (nobody reads the loss value)
-                                   clout_out=None if clout_rows is None else clout_rows[i])
+                                   clout_out=None if clout_rows is None else clout_rows[i],
+                                   want_v=False)                                     # (nor the returned tuple's pvmem)
             spikes = ctx['out'][0]
             ctxs.append(ctx)
         return ctxs

@@ -708,6 +708,17 @@ def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
     dW3.fill_(7.0)
     ops.grad_reduce_adam([dict(out3['parts'])], [])
     assert torch.equal(dW3, dW) and torch.equal(db3, db)
+    # v == NULL (a layer without pooling): sigmoid' from the stored pv — the bits the kernel recomputes from v, so the
+    # learning forward need not write the membrane map at all (ConvNetwork.learn: want_v=False)
+    if d.pool_h == 1 and d.pool_w == 1 and d.target <= 32:
+        dW4, db4, doW4, dob4 = ops.conv_lif_backward(d, eps1, None, pv, r_p.to(dev), None if r_o is None else r_o.to(dev), None,
+                                                     None, t["i2o.weight"], want_out=out_layer)
+        assert torch.equal(dW4, dW) and torch.equal(db4, db)
+        if out_layer:
+            assert torch.equal(doW4, doW) and torch.equal(dob4, dob)
+    else:
+        with pytest.raises(Exception):
+            ops.conv_lif_backward(d, eps1, None, pv, r_p.to(dev), None, None, None, t["i2o.weight"], want_out=False)
 
 
 def test_edge_cases_empty_and_single(dev):
