@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCLL_ABI_VERSION 5
+#define DCLL_ABI_VERSION 6
 
 enum {
     DCLL_OK = 0,
@@ -394,6 +394,27 @@ int64_t dcll_step_readouts_scratch(int64_t rows, int32_t K, int32_t N1, int32_t 
 int dcll_step_readouts(const float *pv, const float *Wt, const float *bias, float *scratch, int64_t scratch_floats,
                        int64_t rows, int32_t K, int32_t N1, int32_t N2, float *p, float *o, int32_t *clout,
                        const float *target, float *g_p, float *g_o, int32_t kind, void *stream);
+
+/*
+ * The readout tails of SEVERAL layer steps — the slices of one network timestep (ConvNetwork.test / .learn,
+ * networks/__init__.py:175-185: slice l+1 consumes slice l's spikes, nobody's readouts) — in TWO launches instead of two per
+ * layer (ABI 6): one split-K pass over all items' pv, one finishing launch.  Each field is the argument of that name of
+ * dcll_step_readouts; per item the results are those of dcll_step_readouts, bit for bit.  1 <= n <= 8; every item must be one
+ * dcll_step_readouts serves, with rows >= 1 and a scratch area of its own; either every item has a target (learning step) or
+ * none.  reserved must be 0.
+ */
+typedef struct dcll_step_ro {
+    const float *pv, *Wt, *bias;
+    float *scratch;
+    int64_t scratch_floats, rows;
+    int32_t K, N1, N2, kind;
+    float *p, *o;
+    int32_t *clout;
+    const float *target;
+    float *g_p, *g_o;
+    int64_t reserved;
+} dcll_step_ro;
+int dcll_step_readouts_multi(const dcll_step_ro *items, int32_t n, void *stream);
 
 /*
  * Per-step argmax + vote (DCLLClassification.forward :724-728, get_predictions_by_vote :44-56):

@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("DCLL_HIP_SO") or os.path.join(_PKG, "libdcll_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class DCLLHipError(RuntimeError):
@@ -51,6 +51,18 @@ class GradParts(ctypes.Structure):
     """dcll_grad_parts"""
     _fields_ = [("part", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("rowlen", ctypes.c_int64),
                 ("nchunk", ctypes.c_int32), ("c_out", ctypes.c_int32), ("adam_w", ctypes.c_int32), ("adam_b", ctypes.c_int32)]
+
+
+class StepRo(ctypes.Structure):
+    """dcll_step_ro (ABI 6): the arguments of one dcll_step_readouts call, as an item of dcll_step_readouts_multi"""
+    _fields_ = [("pv", ctypes.c_void_p), ("Wt", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("scratch", ctypes.c_void_p),
+                ("scratch_floats", ctypes.c_int64), ("rows", ctypes.c_int64), ("K", ctypes.c_int32), ("N1", ctypes.c_int32),
+                ("N2", ctypes.c_int32), ("kind", ctypes.c_int32), ("p", ctypes.c_void_p), ("o", ctypes.c_void_p),
+                ("clout", ctypes.c_void_p), ("target", ctypes.c_void_p), ("g_p", ctypes.c_void_p), ("g_o", ctypes.c_void_p),
+                ("reserved", ctypes.c_int64)]
+
+
+STEP_RO_MAX = 8
 
 
 class LayerOpts(ctypes.Structure):
@@ -109,6 +121,7 @@ SIGNATURES = {
     "dcll_vote_tallies": (_I32, [_P, _I32, _P, _P, _I32, _I32, _P]),
     "dcll_step_readouts_scratch": (_I64, [_I64, _I32, _I32, _I32]),
     "dcll_step_readouts": (_I32, [_P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "dcll_step_readouts_multi": (_I32, [ctypes.POINTER(StepRo), _I32, _P]),
     "dcll_argmax_vote": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "dcll_iq_encode": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "dcll_unpack_spikes": (_I32, [_P, _P, _I64, _P]),

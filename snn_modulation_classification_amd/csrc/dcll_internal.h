@@ -138,6 +138,11 @@ __attribute__((visibility("hidden")))
 int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
                             int kslice, hipStream_t st, int act = DCLL_ACT_NONE);
 
+// the split-K passes of several per-step readouts in one launch (k_readout_t16m)
+__attribute__((visibility("hidden")))
+int dcll_launch_readout_t16_multi(const float *const *pv, const float *const *Wt, float *const *out, const long *rows,
+                                  const int *K, const int *N, const int *kslice, int n, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------------------
 // shared device helpers
 // ------------------------------------------------------------------------------------------------------------

@@ -99,17 +99,16 @@ extern "C" int dcll_local_loss_grad(const float *p, const float *o, const float 
 // k_loss_grad (mean reduction over rows * N1 logits each).
 // ------------------------------------------------------------------------------------------------------------
 template <bool LEARN>
-__global__ __launch_bounds__(256) void k_step_readout_finish(const float *__restrict__ part, const float *__restrict__ bias,
-                                                              long rows, int N1, int N2, int nslice,
-                                                              float *__restrict__ p, float *__restrict__ o,
-                                                              int32_t *__restrict__ clout, const float *__restrict__ target,
-                                                              float *__restrict__ g_p, float *__restrict__ g_o, int kind)
+__device__ __forceinline__ void step_readout_finish_row(const long r, const float *__restrict__ part, const float *__restrict__ bias,
+                                                         const long rows, const int N1, const int N2, const int nslice,
+                                                         float *__restrict__ p, float *__restrict__ o,
+                                                         int32_t *__restrict__ clout, const float *__restrict__ target,
+                                                         float *__restrict__ g_p, float *__restrict__ g_o, const int kind)
 {
     // one workgroup per batch row: wave g adds quarter g of the slices for column `lane` (eight loads in flight, added in
     // slice order), wave 0 combines the four quarters in k_readout_sum's order and does the row's tail
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long r = blockIdx.x;
     const int N = N1 + N2;
     const long n_out = rows * N, i = r * N + lane;
     float acc = 0.0f;
@@ -159,6 +158,33 @@ __global__ __launch_bounds__(256) void k_step_readout_finish(const float *__rest
     if (lane == 0) clout[r] = bi == 0x7fffffff ? 0 : bi;
 }
 
+template <bool LEARN>
+__global__ __launch_bounds__(256) void k_step_readout_finish(const float *__restrict__ part, const float *__restrict__ bias,
+                                                              long rows, int N1, int N2, int nslice,
+                                                              float *__restrict__ p, float *__restrict__ o,
+                                                              int32_t *__restrict__ clout, const float *__restrict__ target,
+                                                              float *__restrict__ g_p, float *__restrict__ g_o, int kind)
+{
+    step_readout_finish_row<LEARN>(blockIdx.x, part, bias, rows, N1, N2, nslice, p, o, clout, target, g_p, g_o, kind);
+}
+// the finishing launches of several layer steps in one (dcll_step_readouts_multi): blockIdx.y selects the item
+constexpr int STEP_RO_MAX = 8;
+struct step_ro_items {
+    const float *part[STEP_RO_MAX], *bias[STEP_RO_MAX], *target[STEP_RO_MAX];
+    float *p[STEP_RO_MAX], *o[STEP_RO_MAX], *g_p[STEP_RO_MAX], *g_o[STEP_RO_MAX];
+    int32_t *clout[STEP_RO_MAX];
+    long rows[STEP_RO_MAX];
+    int N1[STEP_RO_MAX], N2[STEP_RO_MAX], nslice[STEP_RO_MAX], kind[STEP_RO_MAX];
+};
+template <bool LEARN>
+__global__ __launch_bounds__(256) void k_step_readout_finish_m(const step_ro_items it)
+{
+    const int z = blockIdx.y;
+    if ((long)blockIdx.x >= it.rows[z]) return;             // (whole workgroups: before the barrier)
+    step_readout_finish_row<LEARN>(blockIdx.x, it.part[z], it.bias[z], it.rows[z], it.N1[z], it.N2[z], it.nslice[z], it.p[z],
+                                   it.o[z], it.clout[z], it.target[z], it.g_p[z], it.g_o[z], it.kind[z]);
+}
+
 extern "C" int64_t dcll_step_readouts_scratch(int64_t rows, int32_t K, int32_t N1, int32_t N2)
 {
     if (K >= 65536 || N1 + N2 > 64 || N1 < 1 || N2 < 0) return 0;          // (long rows: dcll_readout_splitk's 4096-column form)
@@ -193,6 +219,56 @@ extern "C" int dcll_step_readouts(const float *pv, const float *Wt, const float 
         hipLaunchKernelGGL(k_step_readout_finish<false>, grid, dim3(256), 0, st, scratch, bias, (long)rows, N1, N2, K / ks, p, o,
                            clout, target, g_p, g_o, kind);
     HIP_CHECK_LAUNCH("k_step_readout_finish");
+    return DCLL_OK;
+}
+
+// The readout tails of n layer steps (the slices of one network timestep) in TWO launches instead of 2 n: one split-K pass over
+// all pv maps (k_readout_t16m), one finishing launch (k_step_readout_finish_m).  Results per item = dcll_step_readouts on it,
+// bit for bit (same slice widths, same summation order).
+extern "C" int dcll_step_readouts_multi(const dcll_step_ro *items, int32_t n, void *stream)
+{
+    if (n == 0) return DCLL_OK;
+    if (!items || n < 0 || n > STEP_RO_MAX) return fail(DCLL_ERR_INVALID, "dcll_step_readouts_multi: 1 .. 8 items");
+    const float *pv[STEP_RO_MAX], *Wt[STEP_RO_MAX];
+    float *out[STEP_RO_MAX];
+    long rows[STEP_RO_MAX];
+    int K[STEP_RO_MAX], N[STEP_RO_MAX], ks[STEP_RO_MAX];
+    step_ro_items it;
+    memset(&it, 0, sizeof(it));
+    long maxrows = 0;
+    const bool learn = items[0].target != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const dcll_step_ro &a = items[i];
+        if (a.reserved != 0) return fail(DCLL_ERR_INVALID, "dcll_step_readouts_multi: dcll_step_ro.reserved must be 0");
+        if (a.rows < 1) return fail(DCLL_ERR_INVALID, "dcll_step_readouts_multi: empty item (call dcll_step_readouts for it)");
+        const int Nn = a.N1 + a.N2;
+        if (!a.pv || !a.Wt || !a.scratch || !a.p || a.K < 1 || a.N1 < 1 || a.N2 < 0 || (a.N2 > 0 && (!a.o || a.N2 != a.N1)) ||
+            (a.target && (!a.g_p || (a.N2 > 0 && !a.g_o))))
+            return fail(DCLL_ERR_INVALID, "dcll_step_readouts_multi: bad argument");
+        if ((a.target != nullptr) != learn)
+            return fail(DCLL_ERR_INVALID, "dcll_step_readouts_multi: either every item has a target or none");
+        if (a.target && a.kind != DCLL_LOSS_SMOOTH_L1 && a.kind != DCLL_LOSS_MSE)
+            return fail(DCLL_ERR_UNSUPPORTED, "dcll_step_readouts_multi: SmoothL1Loss (beta 1) and MSELoss, mean reduction");
+        const int64_t need = dcll_step_readouts_scratch(a.rows, a.K, a.N1, a.N2);
+        if (need == 0 || ((((uintptr_t)a.pv | (uintptr_t)a.Wt)) & 15) != 0)
+            return fail(DCLL_ERR_UNSUPPORTED, "dcll_step_readouts_multi: an item dcll_step_readouts does not serve");
+        if (a.scratch_floats < need) return fail(DCLL_ERR_INVALID, "dcll_step_readouts_multi: scratch too small (dcll_step_readouts_scratch)");
+        for (int j = 0; j < i; ++j)
+            if (items[j].scratch == a.scratch) return fail(DCLL_ERR_INVALID, "dcll_step_readouts_multi: items must not share scratch");
+        pv[i] = a.pv, Wt[i] = a.Wt, out[i] = a.scratch, rows[i] = a.rows, K[i] = a.K, N[i] = Nn;
+        ks[i] = (int)((int64_t)a.K * a.rows * Nn / need);       // the slice width dcll_readout_splitk uses for this shape
+        it.part[i] = a.scratch, it.bias[i] = a.bias, it.target[i] = a.target, it.p[i] = a.p, it.o[i] = a.o, it.g_p[i] = a.g_p;
+        it.g_o[i] = a.g_o, it.clout[i] = a.clout, it.rows[i] = a.rows, it.N1[i] = a.N1, it.N2[i] = a.N2, it.nslice[i] = a.K / ks[i];
+        it.kind[i] = a.kind;
+        maxrows = max(maxrows, (long)a.rows);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dcll_launch_readout_t16_multi(pv, Wt, out, rows, K, N, ks, n, st);
+    if (rc) return rc;
+    const dim3 grid((unsigned)maxrows, (unsigned)n);
+    if (learn) hipLaunchKernelGGL(k_step_readout_finish_m<true>, grid, dim3(256), 0, st, it);
+    else hipLaunchKernelGGL(k_step_readout_finish_m<false>, grid, dim3(256), 0, st, it);
+    HIP_CHECK_LAUNCH("k_step_readout_finish_m");
     return DCLL_OK;
 }
 

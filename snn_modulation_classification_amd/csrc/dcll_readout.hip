@@ -139,17 +139,19 @@ constexpr int T16_ROWS = 128, T16_KC = 32, T16_LD = 36;
 // SIG (dcll_readout_act, DCLL_ACT_SIGMOID): the staged pv values are v (dcll_layer_opts pv_presigmoid) and the sigmoid is
 // applied here, once per value, between the global load and the LDS write — the kernel is HBM-bound and has the vector
 // slots that the layer kernels (which share their vector pipe with the fp32 MFMAs) do not.
+// (the body as a device function of the workgroup's coordinates: k_readout_t16 calls it with its block index, k_readout_t16m —
+//  several readouts in ONE launch — with the coordinates of the item its blockIdx.z selects)
 template <int NT, bool SIG>
-__global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ pv, const float *__restrict__ Wt,
-                                                      const float *__restrict__ bias, float *__restrict__ out,
-                                                      long rows, int K, int N, int kslice)
+__device__ __forceinline__ void readout_t16_body(const float *__restrict__ pv, const float *__restrict__ Wt,
+                                                  const float *__restrict__ bias, float *__restrict__ out, const long rows,
+                                                  const int K, const int N, const int kslice, const unsigned bx, const unsigned by)
 {
     constexpr int NBF = (NT * 16 * 8 + 255) / 256;          // float4 loads of the weight chunk per thread
     __shared__ __attribute__((aligned(16))) float sA[T16_ROWS * T16_LD];
     __shared__ __attribute__((aligned(16))) float sB[NBF * 32 * T16_LD];     // (rows >= NT * 16: staged zeros nobody reads)
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long row0 = (long)blockIdx.x * T16_ROWS;
+    const long row0 = (long)bx * T16_ROWS;
     const int kc = (tid & 7) * 4, rsub = tid >> 3;          // 8 threads x float4 = one 32-float K-chunk of a row
     f32x4 acc[2][NT];
 #pragma unroll
@@ -175,8 +177,8 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
 #pragma unroll
         for (int q = 0; q < NBF; ++q) rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, bvo[q], 4u * k0, 0));
     };
-    const int kbeg = kslice > 0 ? blockIdx.y * kslice : 0, kend = kslice > 0 ? kbeg + kslice : K;
-    if (kslice > 0) { out += (long)blockIdx.y * rows * N; bias = nullptr; }
+    const int kbeg = kslice > 0 ? by * kslice : 0, kend = kslice > 0 ? kbeg + kslice : K;
+    if (kslice > 0) { out += (long)by * rows * N; bias = nullptr; }
     fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += T16_KC) {
 #pragma unroll
@@ -225,6 +227,34 @@ __global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ p
     }
 }
 
+template <int NT, bool SIG>
+__global__ __launch_bounds__(256) void k_readout_t16(const float *__restrict__ pv, const float *__restrict__ Wt,
+                                                      const float *__restrict__ bias, float *__restrict__ out,
+                                                      long rows, int K, int N, int kslice)
+{
+    readout_t16_body<NT, SIG>(pv, Wt, bias, out, rows, K, N, kslice, blockIdx.x, blockIdx.y);
+}
+// k_readout_t16m — the split-K passes of SEVERAL per-step readouts (the slices of one network timestep: rows = batch) in one
+// launch: blockIdx.z selects the item, whose own grid (row tiles x K slices) is a corner of the launch grid.  Each of these
+// passes alone is one workgroup generation of 256 workgroups whose time is its latency (8.8 us for 16.8 MB at 512 rows, the
+// same at 128): three of them side by side cost little more than one.  Arithmetic per item = k_readout_t16<NT> on it.
+constexpr int T16M_MAX = 8;
+struct readout_t16_items {
+    const float *pv[T16M_MAX];
+    const float *Wt[T16M_MAX];
+    float *out[T16M_MAX];
+    long rows[T16M_MAX];
+    int K[T16M_MAX], N[T16M_MAX], kslice[T16M_MAX];
+};
+template <int NT>
+__global__ __launch_bounds__(256) void k_readout_t16m(const readout_t16_items it)
+{
+    const int z = blockIdx.z;
+    const long rows = it.rows[z];
+    const int K = it.K[z], ks = it.kslice[z];
+    if ((long)blockIdx.x * T16_ROWS >= rows || (int)blockIdx.y * ks >= K) return;        // (whole workgroups: before any barrier)
+    readout_t16_body<NT, false>(it.pv[z], it.Wt[z], nullptr, it.out[z], rows, K, it.N[z], ks, blockIdx.x, blockIdx.y);
+}
 // Requires K % 32 == 0, N <= 64, 16-byte aligned pv / Wt rows (the caller checked).  kslice > 0: split-K launch (K %
 // kslice == 0, kslice % 32 == 0), `out` = the partial tiles (K / kslice) x rows x N.
 int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias, float *out, long rows, int K, int N,
@@ -245,5 +275,34 @@ int dcll_launch_readout_t16(const float *pv, const float *Wt, const float *bias,
     else DCLL_T16(4);
 #undef DCLL_T16
     HIP_CHECK_LAUNCH("k_readout_t16");
+    return DCLL_OK;
+}
+// Split-K passes of n <= T16M_MAX readouts in one launch (dcll_step_readouts_multi): item i writes its partial tiles
+// (K[i] / kslice[i]) x rows[i] x N[i] to out[i].  Same requirements per item as dcll_launch_readout_t16 with kslice > 0.
+int dcll_launch_readout_t16_multi(const float *const *pv, const float *const *Wt, float *const *out, const long *rows,
+                                  const int *K, const int *N, const int *kslice, int n, hipStream_t st)
+{
+    if (n < 1 || n > T16M_MAX) return fail(DCLL_ERR_INVALID, "readout GEMM (multi): 1 .. 8 items");
+    readout_t16_items it;
+    unsigned gx = 1, gy = 1;
+    int nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (K[i] >= (1 << 22)) return fail(DCLL_ERR_UNSUPPORTED, "readout GEMM: K above 4 M features per row");
+        if (kslice[i] < 1 || K[i] % kslice[i] != 0) return fail(DCLL_ERR_INVALID, "readout GEMM (multi): split-K items only");
+        it.pv[i] = pv[i], it.Wt[i] = Wt[i], it.out[i] = out[i], it.rows[i] = rows[i], it.K[i] = K[i], it.N[i] = N[i];
+        it.kslice[i] = kslice[i];
+        gx = max(gx, (unsigned)((rows[i] + T16_ROWS - 1) / T16_ROWS));
+        gy = max(gy, (unsigned)(K[i] / kslice[i]));
+        nmax = max(nmax, N[i]);
+    }
+    for (int i = n; i < T16M_MAX; ++i) it.pv[i] = it.Wt[i] = nullptr, it.out[i] = nullptr, it.rows[i] = 0, it.K[i] = it.N[i] = 0, it.kslice[i] = 1;
+    const dim3 g(gx, gy, (unsigned)n);
+    // one instantiation for the launch: the widest item's column tiles (an item with fewer columns computes the spare tiles
+    // on zeros and does not store them: its stored columns are the same chains)
+    if (nmax <= 16) hipLaunchKernelGGL(k_readout_t16m<1>, g, dim3(256), 0, st, it);
+    else if (nmax <= 32) hipLaunchKernelGGL(k_readout_t16m<2>, g, dim3(256), 0, st, it);
+    else if (nmax <= 48) hipLaunchKernelGGL(k_readout_t16m<3>, g, dim3(256), 0, st, it);
+    else hipLaunchKernelGGL(k_readout_t16m<4>, g, dim3(256), 0, st, it);
+    HIP_CHECK_LAUNCH("k_readout_t16m");
     return DCLL_OK;
 }

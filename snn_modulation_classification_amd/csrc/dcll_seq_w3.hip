@@ -35,7 +35,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // tile's first output row, in SGPRs) + 32-bit scalar offset (channel plane, walks by scalar adds) + 32-bit lane byte offset —
 // no 64-bit address per store (left to the compiler, the flat form cost two scalar adds per store or, in some
 // instantiations, a 64-bit VECTOR sum: v_mad_i64_i32 + v_lshl_add_u64).  Offsets stay below 2^31: 64 planes of < 2^24 pixels.
-constexpr int W3_NT = 8, W3_PX = 32 * W3_NT;
+constexpr int W3_NT = 8;
 #ifndef W3_EPG
 #define W3_EPG 2                    // register pairs per epilogue group
 #endif

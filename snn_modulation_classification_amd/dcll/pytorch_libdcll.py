@@ -448,10 +448,12 @@ class Conv2dDCLLlayer(nn.Module):
             return s, self._drop(p), pv, v
         # (`_finish`: a slice asks for the step's fused tail — the recorded argmax — DCLLClassification.forward;
         #  `_skip_vmem`: ConvNetwork.test discards the tuple, so the un-pooled membrane map is not written: pvmem = None)
+        #  `_defer_sink` (with `_finish`): ConvNetwork.test launches the readout tails of all slices together, later)
+        fin = self.__dict__.get('_finish')
         s, p, o, pv, v = self.i2h._step(input, self.pooling, self.i2o, self.output_ if self.output_layer else None,
                                         stacked=self.stacked_readout() if self.output_layer else None,
-                                        finish=self.__dict__.get('_finish'),
-                                        want_v=not self.__dict__.get('_skip_vmem', False))
+                                        finish=fin, want_v=not self.__dict__.get('_skip_vmem', False),
+                                        defer_ro=fin is not None and self.__dict__.get('_defer_sink') is not None)
         return (o if self.output_layer else s), self._drop(p), pv, v
 
     def _drop(self, p):
@@ -1089,7 +1091,11 @@ class DCLLClassification(DCLLBase):
             fin = L.__dict__.pop('_finish', None) if fused else None
         if record:
             # kept on the device (no sync per step, unlike the reference's .cpu() at :726-728); converted on demand
-            if fin is not None and fin.get('done') and fin.get('clout') is not None:
+            if fin is not None and 'run_readouts' in fin:
+                # deferred readout tail (ConvNetwork.test): the caller runs it with the other slices' and fills this entry in
+                self._clout.append(None)
+                L._defer_sink.append((self, fin, len(self._clout) - 1))
+            elif fin is not None and fin.get('done') and fin.get('clout') is not None:
                 self._clout.append(fin['clout'])
             else:
                 logits = o if L.output_layer else p

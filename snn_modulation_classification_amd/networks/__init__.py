@@ -148,6 +148,7 @@ class ConvNetwork(torch.nn.Module):
         together with the optimizer step.  -> (slices that learned, pending slab handles)"""
         from .. import parallel
         learned, pending = [], []
+        ops.run_deferred_readouts([ctx['fin'] for ctx in ctxs])        # all slices' readout tails: two launches
         for s, ctx in zip(self.dcll_slices, ctxs):
             s._learn_tail(ctx, open_reduce=not ranks)
             if ctx['learned']:
@@ -436,13 +437,31 @@ class ConvNetwork(torch.nn.Module):
             if self._test_graphed(x):
                 return
             self._graph_interrupted('test', tuple(x.shape))
-        spikes = x
-        with self._no_vmem():
-            for s in self.dcll_slices:
-                spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
+        self._test_slices(x)
         if isinstance(x, torch.Tensor):
             key = tuple(x.shape)
             self._test_eager_steps[key] = self._test_eager_steps.get(key, 0) + 1
+
+    def _test_slices(self, x):
+        """The layer steps of one inference timestep, slice after slice, with the readout tails DEFERRED: slice l+1 consumes
+        slice l's spikes, nobody's readouts, so the split-K passes and finishing launches of all slices run behind the layer
+        kernels as ONE dcll_step_readouts_multi call (two launches for the timestep instead of two per slice; results bit
+        for bit those of the per-slice calls).  The recorded argmax of every slice is appended to its `clout` afterwards."""
+        spikes, pend = x, []
+        layers = [s.dclllayer for s in self.dcll_slices]
+        with self._no_vmem():
+            try:
+                for L in layers:
+                    L._defer_sink = pend
+                for s in self.dcll_slices:
+                    spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
+            finally:
+                for L in layers:
+                    L.__dict__.pop('_defer_sink', None)
+            ops.run_deferred_readouts([fin for _, fin, _ in pend])
+            for s, fin, pos in pend:
+                s._clout[pos] = fin['clout']
+        return spikes
 
     # -- the inference timestep as a captured hipGraph ------------------------------------------------------------------
     # Same idea as _learn_graphed, without an optimizer: the launches of `net.test(x[t])` (three layer steps, readouts,
@@ -496,12 +515,9 @@ class ConvNetwork(torch.nn.Module):
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(x.device)
             try:
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'), self._no_vmem():
-                    spikes, rows = g['x'], []
-                    for s in self.dcll_slices:
-                        spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
-                        rows.append(s._clout[-1])
-                    g['clout'] = torch.stack(rows)
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    self._test_slices(g['x'])
+                    g['clout'] = torch.stack([s._clout[-1] for s in self.dcll_slices])
             except RuntimeError as e:
                 import logging
                 logging.getLogger(__name__).warning('hipGraph capture of the inference step failed (%s): running the '

@@ -3,6 +3,7 @@
 PyTorch is only the owner of device memory and streams here; all arithmetic happens in libdcll_hip.so.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -149,6 +150,7 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
         if defer_ro and finish is not None:
             finish['run_readouts'] = lambda: step_readouts(pv.reshape(B, -1), Wt, bias, desc.target, n2, p, o, scratch=out,
                                                            finish=finish)
+            finish['ro_call'] = (pv.reshape(B, -1), Wt, bias, desc.target, n2, p, o, out)      # (for run_deferred_readouts)
             return s, p, o, pv, v
         step_readouts(pv.reshape(B, -1), Wt, bias, desc.target, n2, p, o, scratch=out, finish=finish)
         return s, p, o, pv, v
@@ -440,11 +442,9 @@ def conv_lif_sequence_iq(desc, iq, thr_i, thr_q, t0, W, b, tau4, eps0, eps1, arp
 READOUT_AUTO, READOUT_CORESIDENT, READOUT_LDS, READOUT_T16 = 0, 1, 2, 3       # dcll_readout_mode (include/dcll_hip.h)
 
 
-def step_readouts(pv2d, Wt, bias, N1, N2, p, o, scratch=None, finish=None):
-    """dcll_step_readouts: the readouts of one layer step (rows = batch) against the N1 + N2 stacked rows Wt / bias in one
-    split-K pass + one finishing launch that writes p (rows, N1), o (rows, N2) and — `finish` (see conv_lif_step) — the
-    recorded argmax and the local-loss gradients.  `scratch`: dict keeping the partial-sum area ('step_ro') and the
-    gradient buffers between calls."""
+def _step_readouts_prepare(pv2d, Wt, bias, N1, N2, p, o, scratch=None, finish=None):
+    """Argument checks and buffers of one dcll_step_readouts call -> (dcll_step_ro item, tensors it points to, what `finish`
+    learns once the call is enqueued)."""
     rows, K = pv2d.shape
     _expect(Wt, "Wt", torch.float32, (N1 + N2, K))
     _expect(bias, "bias", torch.float32, (N1 + N2,))
@@ -479,11 +479,46 @@ def step_readouts(pv2d, Wt, bias, N1, N2, p, o, scratch=None, finish=None):
                 return t
             g_p = gbuf('g_p', N1)
             g_o = gbuf('g_o', N2) if N2 else None
-    check(lib.dcll_step_readouts(ptr(pv2d), ptr(Wt), ptr(bias), ptr(area), need, rows, K, N1, N2, ptr(p), ptr(o), ptr(clout),
-                                 ptr(target), ptr(g_p), ptr(g_o), kind, stream_ptr()), "dcll_step_readouts")
+    item = _lib.StepRo(ptr(pv2d), ptr(Wt), ptr(bias), ptr(area), need, rows, K, N1, N2, kind, ptr(p), ptr(o), ptr(clout),
+                       ptr(target), ptr(g_p), ptr(g_o), 0)
+    return item, (pv2d, Wt, bias, area, p, o, clout, target, g_p, g_o), dict(done=True, clout=clout, g_p=g_p, g_o=g_o)
+
+
+def step_readouts(pv2d, Wt, bias, N1, N2, p, o, scratch=None, finish=None):
+    """dcll_step_readouts: the readouts of one layer step (rows = batch) against the N1 + N2 stacked rows Wt / bias in one
+    split-K pass + one finishing launch that writes p (rows, N1), o (rows, N2) and — `finish` (see conv_lif_step) — the
+    recorded argmax and the local-loss gradients.  `scratch`: dict keeping the partial-sum area ('step_ro') and the
+    gradient buffers between calls."""
+    it, _keep, res = _step_readouts_prepare(pv2d, Wt, bias, N1, N2, p, o, scratch, finish)
+    check(_lib.get().dcll_step_readouts(it.pv, it.Wt, it.bias, it.scratch, it.scratch_floats, it.rows, it.K, it.N1, it.N2, it.p,
+                                        it.o, it.clout, it.target, it.g_p, it.g_o, it.kind, stream_ptr()), "dcll_step_readouts")
     if finish is not None:
-        finish.update(done=True, clout=clout, g_p=g_p, g_o=g_o)
+        finish.update(res)
     return p, o
+
+
+def run_deferred_readouts(finishes):
+    """The deferred readout tails of several layer steps (conv_lif_step(defer_ro=True) left them in finish['run_readouts'] /
+    finish['ro_call']): ONE dcll_step_readouts_multi call — two launches for the whole timestep — where there are several of one
+    kind (all with a target = learning steps, or none), else one dcll_step_readouts each.  Results are bit-identical."""
+    pend = [f for f in finishes if f is not None and 'run_readouts' in f]
+    if not pend:
+        return
+    learn = [f.get('target') is not None for f in pend]
+    if (len(pend) < 2 or len(pend) > _lib.STEP_RO_MAX or any('ro_call' not in f for f in pend) or
+            any(l != learn[0] for l in learn) or os.environ.get('DCLL_STEP_RO_MULTI', '1') == '0'):      # ('0': the control)
+        for f in pend:
+            f.pop('ro_call', None)
+            f.pop('run_readouts')()
+        return
+    prepared = []
+    for f in pend:
+        f.pop('run_readouts')
+        prepared.append(_step_readouts_prepare(*f.pop('ro_call'), finish=f))
+    arr = (_lib.StepRo * len(prepared))(*[it for it, _, _ in prepared])
+    check(_lib.get().dcll_step_readouts_multi(arr, len(prepared), stream_ptr()), "dcll_step_readouts_multi")
+    for f, (_, _keep, res) in zip(pend, prepared):
+        f.update(res)
 
 
 def readout(pv2d, Wt, bias, out=None, mode=READOUT_AUTO, scratch=None):

@@ -1107,6 +1107,66 @@ def test_step_readouts_fused_tail_equals_the_separate_calls(dev, rows, K, N2, le
         assert fin['g_p'] is None
 
 
+@pytest.mark.parametrize("learn", [False, True])
+@pytest.mark.parametrize("shapes", [[(512, 8192, 0), (512, 8192, 0), (512, 8192, 24)],         # the slices of radio_ml_conv.yaml
+                                    [(37, 8192, 24), (300, 2048, 0)], [(5, 4096, 24), (1024, 8192, 0), (70, 8192, 0), (512, 2048, 24)]])
+def test_step_readouts_multi_equals_the_per_layer_calls(dev, shapes, learn):
+    """dcll_step_readouts_multi (ABI 6): the readout tails of several layer steps in TWO launches (k_readout_t16m +
+    k_step_readout_finish_m; asserted from the launch log) == dcll_step_readouts per item, bit for bit: p, o, the recorded
+    argmax, the local-loss gradients — items of different row counts, K and stacked widths in one call.  Argument checks:
+    a refused call launches nothing."""
+    import ctypes
+    from snn_modulation_classification_amd import ops, _lib
+    rng = np.random.RandomState(len(shapes) + 7 * learn)
+    N1 = 24
+    single, multi, calls = [], [], []
+    for rows, K, N2 in shapes:
+        pv = cu(rng.uniform(0, 1, size=(rows, K)).astype(np.float32), dev)
+        Wt = cu(rng.uniform(-.0055, .0055, size=(N1 + N2, K)).astype(np.float32), dev)
+        bias = cu(rng.uniform(-.0055, .0055, size=(N1 + N2,)).astype(np.float32), dev)
+        target = torch.zeros(rows, N1, device=dev)
+        target[torch.arange(rows), torch.from_numpy(rng.randint(0, N1, rows))] = 1
+
+        def fin():
+            f = dict(clout=True)
+            if learn:
+                f.update(target=target, kind=ops.LOSS_KINDS['SmoothL1Loss'])
+            return f
+        mk = lambda: (torch.full((rows, N1), 7.0, device=dev), torch.full((rows, N2), 7.0, device=dev) if N2 else None)
+        p1, o1 = mk()
+        f1 = fin()
+        ops.step_readouts(pv, Wt, bias, N1, N2, p1, o1, scratch={}, finish=f1)
+        single.append((p1, o1, f1))
+        p2, o2 = mk()
+        f2 = fin()
+        f2['run_readouts'] = lambda: (_ for _ in ()).throw(AssertionError("the per-layer call ran"))
+        f2['ro_call'] = (pv, Wt, bias, N1, N2, p2, o2, {})
+        multi.append((p2, o2, f2))
+    with ops.kernel_trace() as tr:
+        ops.run_deferred_readouts([f for _, _, f in multi])
+    assert tr.names == ["k_readout_t16m", "k_step_readout_finish_m"], tr.names
+    for (p1, o1, f1), (p2, o2, f2) in zip(single, multi):
+        assert f2['done'] and 'run_readouts' not in f2 and 'ro_call' not in f2
+        assert torch.equal(p1, p2) and (o1 is None or torch.equal(o1, o2))
+        assert torch.equal(f1['clout'], f2['clout'])
+        if learn:
+            assert torch.equal(f1['g_p'], f2['g_p']) and (o1 is None or torch.equal(f1['g_o'], f2['g_o']))
+        else:
+            assert f2['g_p'] is None
+    # refused: more than 8 items, a non-zero reserved field, items with and without a target mixed, shared scratch
+    lib = _lib.get()
+    it, keep, _ = ops._step_readouts_prepare(cu(rng.uniform(0, 1, size=(8, 2048)).astype(np.float32), dev),
+                                             cu(np.zeros((N1, 2048), np.float32), dev), cu(np.zeros(N1, np.float32), dev), N1, 0,
+                                             torch.empty(8, N1, device=dev), None, {}, finish=None)
+    arr = (_lib.StepRo * 9)(*[it] * 9)
+    assert lib.dcll_step_readouts_multi(arr, 9, None) == -1 and b"1 .. 8" in lib.dcll_last_error()
+    assert lib.dcll_step_readouts_multi(arr, 2, None) == -1 and b"share scratch" in lib.dcll_last_error()
+    bad = _lib.StepRo.from_buffer_copy(it)
+    bad.reserved = 1
+    assert lib.dcll_step_readouts_multi((_lib.StepRo * 1)(bad), 1, None) == -1 and b"reserved" in lib.dcll_last_error()
+    assert lib.dcll_step_readouts_multi(None, 0, None) == 0
+
+
 @pytest.mark.parametrize("B,L,n", [(4096, 3, 24), (37, 1, 24), (1, 2, 10), (5000, 7, 24)])
 def test_vote_tallies_equal_the_torch_construction(dev, B, L, n):
     """dcll_vote_tallies (one launch; parallel.tallies on device tensors) == the torch construction it replaced: per layer
