@@ -230,6 +230,24 @@ int dcll_conv_lif_backward_open(const dcll_conv_desc *d, const float *eps1, cons
 int dcll_grad_reduce_adam(const dcll_grad_parts *layers, int32_t n_layers, const dcll_adam_tensor *tensors,
                           int32_t n_tensors, const float *dyn, void *stream);
 
+/*
+ * dcll_conv_lif_backward_open for SEVERAL layers — the slices of one learning timestep — in one call (ABI 6): where all of
+ * them are layers without pooling with the same readout-width class their dv launches (max-pool routing / i2o^T / sigmoid')
+ * run as ONE launch, then the weight / output_ gradient kernels layer by layer.  Each field is the argument of that name of
+ * dcll_conv_lif_backward_open; `part` / `nchunk` are written (its outputs).  Per item the results are those of the single
+ * call, bit for bit.  1 <= n <= 8, reserved must be 0.
+ */
+typedef struct dcll_bwd_item {
+    const dcll_conv_desc *d;
+    const float *eps1, *v, *pv_pooled, *g_p, *g_o, *g_pv, *g_v, *i2o_W;
+    float *d_outW, *d_outb, *scratch;
+    int64_t scratch_floats;
+    int32_t B, reserved;
+    const float *part;          /* out */
+    int32_t nchunk, reserved2;  /* out; 0 */
+} dcll_bwd_item;
+int dcll_conv_lif_backward_open_multi(dcll_bwd_item *items, int32_t n, void *stream);
+
 int dcll_cells_to_planes(const int32_t *cells, float *planes, int64_t n_samples, int32_t hw, void *stream);
 
 /* One timestep of DenseDCLLlayer.forward — drop-in for dcll/pytorch_libdcll.py:250-255 (dropout = identity). */

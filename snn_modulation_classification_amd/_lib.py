@@ -65,6 +65,18 @@ class StepRo(ctypes.Structure):
 STEP_RO_MAX = 8
 
 
+class BwdItem(ctypes.Structure):
+    """dcll_bwd_item (ABI 6): the arguments of one dcll_conv_lif_backward_open call, as an item of ..._open_multi"""
+    _fields_ = [("d", ctypes.POINTER(ConvDesc))] + \
+               [(n, ctypes.c_void_p) for n in ("eps1", "v", "pv_pooled", "g_p", "g_o", "g_pv", "g_v", "i2o_W", "d_outW", "d_outb",
+                                               "scratch")] + \
+               [("scratch_floats", ctypes.c_int64), ("B", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("part", ctypes.c_void_p), ("nchunk", ctypes.c_int32), ("reserved2", ctypes.c_int32)]
+
+
+BWD_MULTI_MAX = 8
+
+
 class LayerOpts(ctypes.Structure):
     """dcll_layer_opts (ABI v3): int8 conv weights + per-output-channel scale, pv written before the sigmoid"""
     _fields_ = [("w_q8", ctypes.c_void_p), ("w_scale", ctypes.c_void_p), ("pv_presigmoid", ctypes.c_int32),
@@ -102,6 +114,7 @@ SIGNATURES = {
     "dcll_adam_step_dyn": (_I32, [ctypes.POINTER(AdamTensor), _I32, _P, _P]),
     "dcll_conv_lif_backward_open": (_I32, [_DP] + [_P] * 11 + [_I64, _I32, ctypes.POINTER(ctypes.c_void_p), _IP, _P]),
     "dcll_grad_reduce_adam": (_I32, [ctypes.POINTER(GradParts), _I32, ctypes.POINTER(AdamTensor), _I32, _P, _P]),
+    "dcll_conv_lif_backward_open_multi": (_I32, [ctypes.POINTER(BwdItem), _I32, _P]),
     "dcll_cells_to_planes": (_I32, [_P, _P, _I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
     "dcll_dense_lif_sequence": (_I32, [_DDP] + [_P] * 16 + [_I32, _I32, _P]),

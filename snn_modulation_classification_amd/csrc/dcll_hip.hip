@@ -681,21 +681,22 @@ constexpr int DV_MAXPB = 16;            // samples per workgroup of k_bwd_dv_nop
 // FROM_PV: `v` holds the layer's pv = sigmoid(v) as its forward wrote it (a layer without pooling: same shape, and the same
 // bits this kernel would recompute): the learning forward then does not have to store the membrane map at all
 template <int NP, bool FROM_PV>
-__global__ __launch_bounds__(256) void k_bwd_dv_nopool(int K, int N, const float *__restrict__ v,
-                                                        const float *__restrict__ g_p, const float *__restrict__ g_pv,
-                                                        const float *__restrict__ g_v, const float *__restrict__ i2o_W,
-                                                        float *__restrict__ gvf, int B, int per_block)
+__device__ __forceinline__ void bwd_dv_nopool_body(const int K, const int N, const float *__restrict__ v,
+                                                    const float *__restrict__ g_p, const float *__restrict__ g_pv,
+                                                    const float *__restrict__ g_v, const float *__restrict__ i2o_W,
+                                                    float *__restrict__ gvf, const int B, const int per_block,
+                                                    const unsigned bx, const unsigned by)
 {
     // the chunk's g_p rows through LDS (read back as broadcasts): as scalar loads from global memory they were a chain
     // of ~400 dependent s_load latencies per thread
     __shared__ __attribute__((aligned(16))) float gp[DV_MAXPB][32];
-    const int b0 = blockIdx.y * per_block, b1 = min(B, b0 + per_block);
+    const int b0 = (int)by * per_block, b1 = min(B, b0 + per_block);
     for (int e = threadIdx.x; e < per_block * 32; e += 256) {
         const int bb = b0 + (e >> 5), n = e & 31;
         gp[e >> 5][n] = (g_p && n < N && bb < b1) ? g_p[(long)bb * N + n] : 0.0f;
     }
     __syncthreads();
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)bx * 256 + threadIdx.x;
     if (k >= K) return;
     float wk[NP];
 #pragma unroll
@@ -733,6 +734,31 @@ __global__ __launch_bounds__(256) void k_bwd_dv_nopool(int K, int N, const float
             if (bg + q < b1) gvf[(long)b * K + k] = out;
         }
     }
+}
+
+template <int NP, bool FROM_PV>
+__global__ __launch_bounds__(256) void k_bwd_dv_nopool(int K, int N, const float *__restrict__ v,
+                                                        const float *__restrict__ g_p, const float *__restrict__ g_pv,
+                                                        const float *__restrict__ g_v, const float *__restrict__ i2o_W,
+                                                        float *__restrict__ gvf, int B, int per_block)
+{
+    bwd_dv_nopool_body<NP, FROM_PV>(K, N, v, g_p, g_pv, g_v, i2o_W, gvf, B, per_block, blockIdx.x, blockIdx.y);
+}
+// the dv launches of several layers (the slices of one learning timestep) in one: blockIdx.z selects the item
+// (dcll_conv_lif_backward_open_multi)
+constexpr int BWD_MULTI_MAX = 8;
+struct bwd_dv_items {
+    const float *v[BWD_MULTI_MAX], *g_p[BWD_MULTI_MAX], *g_pv[BWD_MULTI_MAX], *g_v[BWD_MULTI_MAX], *i2o_W[BWD_MULTI_MAX];
+    float *gvf[BWD_MULTI_MAX];
+    int K[BWD_MULTI_MAX], N[BWD_MULTI_MAX], B[BWD_MULTI_MAX];
+};
+template <int NP, bool FROM_PV>
+__global__ __launch_bounds__(256) void k_bwd_dv_nopool_m(const bwd_dv_items it, int per_block)
+{
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x * 256 >= it.K[z] || (int)blockIdx.y * per_block >= it.B[z]) return;     // (whole workgroups)
+    bwd_dv_nopool_body<NP, FROM_PV>(it.K[z], it.N[z], it.v[z], it.g_p[z], it.g_pv[z], it.g_v[z], it.i2o_W[z], it.gvf[z], it.B[z],
+                                    per_block, blockIdx.x, blockIdx.y);
 }
 
 // The same sum with four threads per output (64 outputs x 4 groups of partial rows per workgroup), the four group sums
@@ -3064,7 +3090,7 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
                                   const float *g_p, const float *g_o, const float *g_pv, const float *g_v,
                                   const float *i2o_W, float *dW, float *db, float *d_outW, float *d_outb,
                                   float *scratch, int64_t scratch_floats, int32_t B, void *stream,
-                                  const float **open_part, int32_t *open_nchunk)
+                                  const float **open_part, int32_t *open_nchunk, bool dv_done = false)
 {
     int rc = check_desc(d);
     if (rc) return rc;
@@ -3080,7 +3106,9 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
     int ch, cw, ph, pw;
     conv_shape(d, &ch, &cw, &ph, &pw);
     const long nconv = (long)B * d->c_out * ch * cw;
-    if (nopool) {
+    if (dv_done) {
+        // (dcll_conv_lif_backward_open_multi ran this layer's dv with the other layers': the gradient map is in scratch)
+    } else if (nopool) {
         const int Kmap = d->c_out * ch * cw, per_block = 16;
         const dim3 grid(nblk(Kmap, 256), nblk(B, per_block));
 #define DCLL_DV(NP_)                                                                                                    \
@@ -3101,7 +3129,7 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
         hipLaunchKernelGGL(k_bwd_dv, dim3(nblk(nconv, 256)), dim3(256), 0, st, *d, ch, cw, ph, pw, v, g_p, g_pv, g_v, i2o_W,
                            scratch, nconv);
     }
-    HIP_CHECK_LAUNCH("k_bwd_dv");
+    if (!dv_done) HIP_CHECK_LAUNCH("k_bwd_dv");
     // weight gradient: partial sums over batch chunks (after the g_v_full plane in scratch), then a fixed-order reduce
     const long rowlen = (long)d->c_in * d->kh * d->kw + 1;
     const long per_chunk = (long)d->c_out * rowlen;
@@ -3216,6 +3244,66 @@ extern "C" int dcll_conv_lif_backward_open(const dcll_conv_desc *d, const float 
     if (!part || !nchunk) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward_open: null part / nchunk");
     return conv_lif_backward_impl(d, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, nullptr, nullptr, d_outW, d_outb, scratch,
                                   scratch_floats, B, stream, part, nchunk);
+}
+
+// dcll_conv_lif_backward_open for n layers — the slices of one learning timestep — with their dv launches as ONE launch
+// (k_bwd_dv_nopool_m) where all of them are layers without pooling of one readout-width class; the weight / output_ gradient
+// kernels follow layer by layer as in the single call.  Results per item = dcll_conv_lif_backward_open on it.
+extern "C" int dcll_conv_lif_backward_open_multi(dcll_bwd_item *items, int32_t n, void *stream)
+{
+    const char *who = "dcll_conv_lif_backward_open_multi";
+    if (n == 0) return DCLL_OK;
+    if (!items || n < 0 || n > BWD_MULTI_MAX) return fail(DCLL_ERR_INVALID, "1 .. 8 items", who);
+    bool joint = n > 1;
+    int npc = -1, frompv = -1;
+    bwd_dv_items it;
+    memset(&it, 0, sizeof(it));
+    unsigned gx = 1, gy = 1;
+    for (int i = 0; i < n; ++i) {
+        const dcll_bwd_item &a = items[i];
+        if (a.reserved != 0) return fail(DCLL_ERR_INVALID, "dcll_bwd_item.reserved must be 0", who);
+        if (!a.d || !a.eps1 || !a.scratch || a.B < 1) return fail(DCLL_ERR_INVALID, "null pointer / empty batch", who);
+        int rc = check_desc(a.d);
+        if (rc) return rc;
+        const bool nopool = a.d->pool_h == 1 && a.d->pool_w == 1 && a.d->target <= 32;
+        if (!a.v && !(nopool && a.pv_pooled))
+            return fail(DCLL_ERR_INVALID, "v may be NULL only for a layer without pooling whose pv is given", who);
+        if (a.g_p && !a.i2o_W) return fail(DCLL_ERR_INVALID, "g_p needs i2o_W", who);
+        int ch, cw, ph, pw;
+        conv_shape(a.d, &ch, &cw, &ph, &pw);
+        const long Kmap = (long)a.d->c_out * ch * cw;
+        if ((long)a.B * Kmap > a.scratch_floats) return fail(DCLL_ERR_INVALID, "scratch too small", who);
+        const int cls = a.d->target <= 8 ? 8 : a.d->target <= 16 ? 16 : a.d->target <= 24 ? 24 : 32, fp = a.v ? 0 : 1;
+        if (!nopool || Kmap >= (1L << 31) || (npc >= 0 && (cls != npc || fp != frompv))) joint = false;
+        npc = cls, frompv = fp;
+        if (joint) {
+            it.v[i] = a.v ? a.v : a.pv_pooled, it.g_p[i] = a.g_p, it.g_pv[i] = a.g_pv, it.g_v[i] = a.g_v, it.i2o_W[i] = a.i2o_W;
+            it.gvf[i] = a.scratch, it.K[i] = (int)Kmap, it.N[i] = a.d->target, it.B[i] = a.B;
+            gx = max(gx, (unsigned)nblk(Kmap, 256)), gy = max(gy, (unsigned)nblk(a.B, 16));
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (joint) {
+        const dim3 grid(gx, gy, (unsigned)n);
+#define DCLL_DVM(NP_)                                                                                                   \
+    do {                                                                                                                \
+        if (frompv) hipLaunchKernelGGL((k_bwd_dv_nopool_m<NP_, true>), grid, dim3(256), 0, st, it, 16);                  \
+        else hipLaunchKernelGGL((k_bwd_dv_nopool_m<NP_, false>), grid, dim3(256), 0, st, it, 16);                        \
+    } while (0)
+        if (npc == 8) DCLL_DVM(8);
+        else if (npc == 16) DCLL_DVM(16);
+        else if (npc == 24) DCLL_DVM(24);
+        else DCLL_DVM(32);
+#undef DCLL_DVM
+        HIP_CHECK_LAUNCH("k_bwd_dv_nopool_m");
+    }
+    for (int i = 0; i < n; ++i) {
+        dcll_bwd_item &a = items[i];
+        int rc = conv_lif_backward_impl(a.d, a.eps1, a.v, a.pv_pooled, a.g_p, a.g_o, a.g_pv, a.g_v, a.i2o_W, nullptr, nullptr,
+                                        a.d_outW, a.d_outb, a.scratch, a.scratch_floats, a.B, stream, &a.part, &a.nchunk, joint);
+        if (rc) return rc;
+    }
+    return DCLL_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -932,11 +932,13 @@ class DCLLBase(nn.Module):
         L = self.dclllayer
         return tuple(L.pooling) == (1, 1) and L.i2o.weight.shape[0] <= 32
 
-    def _learn_tail(self, ctx, open_reduce=False):
+    def _learn_tail(self, ctx, open_reduce=False, defer_backward=None):
         """What follows the layer kernel of a learning step: the (deferred) readout tail, then — once iter >= burnin — the
         local-loss gradients (from the readouts' finishing launch where it served them, else dcll_local_loss_grad) and
         dcll_conv_lif_backward into the parameters' .grad.  `open_reduce`: the weight gradient's last reduction is left to
-        the caller's ops.grad_reduce_adam (self._learn_bufs['grads']['parts']).  -> loss (1,) device tensor or None"""
+        the caller's ops.grad_reduce_adam (self._learn_bufs['grads']['parts']); `defer_backward` (a list, with open_reduce): the
+        backward is not launched here but appended for ops.conv_lif_backward_open_multi (all slices' dv in one launch).
+        -> loss (1,) device tensor or None"""
         L = self.dclllayer
         i2h = L.i2h
         fin, rec, clout_out = ctx['fin'], ctx['rec'], ctx['clout_out']
@@ -967,7 +969,8 @@ class DCLLBase(nn.Module):
             if L.output_layer:
                 gb.update(d_outW=prm[2].grad, d_outb=prm[3].grad)
             ops.conv_lif_backward(desc, i2h.state.eps1, v, pv, g_p, g_o, None, None, L.i2o.weight,
-                                  want_out=L.output_layer, out=gb, open_reduce=open_reduce)
+                                  want_out=L.output_layer, out=gb, open_reduce=open_reduce,
+                                  defer=defer_backward if open_reduce else None)
         return loss
 
     def _grads_into_slab(self):

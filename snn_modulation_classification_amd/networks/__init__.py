@@ -149,12 +149,16 @@ class ConvNetwork(torch.nn.Module):
         from .. import parallel
         learned, pending = [], []
         ops.run_deferred_readouts([ctx['fin'] for ctx in ctxs])        # all slices' readout tails: two launches
+        # single rank: the slices' backward as one call (their dv launches as one launch; DCLL_BWD_MULTI=0: the control)
+        bwd = None if (ranks or os.environ.get('DCLL_BWD_MULTI', '1') == '0') else []
         for s, ctx in zip(self.dcll_slices, ctxs):
-            s._learn_tail(ctx, open_reduce=not ranks)
+            s._learn_tail(ctx, open_reduce=not ranks, defer_backward=bwd)
             if ctx['learned']:
                 learned.append(s)
                 if ranks:
                     pending.append(parallel.allreduce_slab_begin(s._grad_slab, local_n, global_batch))
+        if bwd:
+            ops.conv_lif_backward_open_multi(bwd)
         return learned, pending
 
     @staticmethod

@@ -26,6 +26,22 @@ def make_conv_desc(c_in, c_out, hw, kernel_size, padding, pooling, target, outpu
                     int(wrp > 0), float(alpharp), float(wrp))
 
 
+def conv_lif_backward_open_multi(deferred):
+    """The open backward of several layers (conv_lif_backward(..., defer=list)) in one dcll_conv_lif_backward_open_multi call:
+    their dv launches as ONE launch where the layers allow it, then weight / output_ gradients layer by layer.  Fills each
+    layer's out['parts'] for grad_reduce_adam.  Per layer bit-identical to conv_lif_backward(open_reduce=True)."""
+    if not deferred:
+        return
+    if len(deferred) > _lib.BWD_MULTI_MAX:
+        raise ValueError("conv_lif_backward_open_multi: at most %d layers" % _lib.BWD_MULTI_MAX)
+    arr = (_lib.BwdItem * len(deferred))(*[e['item'] for e in deferred])
+    check(_lib.get().dcll_conv_lif_backward_open_multi(arr, len(deferred), stream_ptr()), "dcll_conv_lif_backward_open_multi")
+    for e, a in zip(deferred, arr):
+        d = e['desc']
+        e['out']['parts'] = dict(part=a.part, nchunk=a.nchunk, c_out=d.c_out, rowlen=d.c_in * d.kh * d.kw + 1, dW=e['dW'],
+                                 db=e['db'], keep=e['scratch'])
+
+
 def conv_out_shape(desc):
     v = [ctypes.c_int32() for _ in range(4)]
     check(_lib.get().dcll_conv_out_shape(ctypes.byref(desc), *[ctypes.byref(i) for i in v]), "dcll_conv_out_shape")
@@ -179,11 +195,12 @@ def conv_lif_step(desc, x, W, b, alpha, tau_m, alphas, tau_s, eps0, eps1, arp, i
     return s, p, o, pv, v
 
 
-def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want_out, out=None, open_reduce=False):
+def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want_out, out=None, open_reduce=False, defer=None):
     """Gradients of one layer step (dcll_conv_lif_backward) -> (dW, db, d_outW, d_outb).  `out`: optional dict with
     preallocated 'dW', 'db', 'd_outW', 'd_outb', 'bwd_scratch' (the learning loop writes into the parameters' .grad).
     `open_reduce`: dcll_conv_lif_backward_open — dW / db are NOT written yet; the partial rows of the weight gradient stay
-    in out['bwd_scratch'] and out['parts'] describes them for grad_reduce_adam, which finishes several layers in one launch."""
+    in out['bwd_scratch'] and out['parts'] describes them for grad_reduce_adam, which finishes several layers in one launch.
+    `defer` (a list; open form): nothing is launched — the prepared call is appended for conv_lif_backward_open_multi."""
     B = eps1.shape[0]
     dev = eps1.device
     out = {} if out is None else out
@@ -215,6 +232,13 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
     if scratch is None or scratch.numel() != n_scratch:
         scratch = out['bwd_scratch'] = torch.empty((n_scratch,), device=dev, dtype=torch.float32)
     c = lambda t: None if t is None else _f32(t, "grad").contiguous()
+    if defer is not None:       # (open form, launched later with other layers': conv_lif_backward_open_multi)
+        gp_, go_, gpv_, gv_ = c(g_p), (c(g_o) if want_out else None), c(g_pv), c(g_v)
+        item = _lib.BwdItem(ctypes.pointer(desc), ptr(eps1), ptr(v), ptr(pv_pooled), ptr(gp_), ptr(go_), ptr(gpv_), ptr(gv_),
+                            ptr(i2o_W), ptr(d_outW), ptr(d_outb), ptr(scratch), n_scratch, B, 0, None, 0, 0)
+        defer.append(dict(item=item, out=out, desc=desc, dW=dW, db=db, scratch=scratch,
+                          keep=(eps1, v, pv_pooled, gp_, go_, gpv_, gv_, i2o_W, d_outW, d_outb)))
+        return dW, db, d_outW, d_outb
     if open_reduce:
         part, nchunk = ctypes.c_void_p(), ctypes.c_int32()
         rc = _lib.get().dcll_conv_lif_backward_open(

@@ -721,6 +721,59 @@ def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
             ops.conv_lif_backward(d, eps1, None, pv, r_p.to(dev), None, None, None, t["i2o.weight"], want_out=False)
 
 
+@pytest.mark.parametrize("B,from_pv", [(70, True), (300, False), (5, True)])
+def test_backward_open_multi_equals_the_per_layer_calls(dev, B, from_pv):
+    """dcll_conv_lif_backward_open_multi (ABI 6): the open backward of the three slices of radio_ml_conv.yaml in one call — their
+    dv launches as ONE launch (k_bwd_dv_nopool_m; launch log) — == dcll_conv_lif_backward_open per layer, bit for bit: the
+    reduced weight / bias gradients and the output_ gradients; with and without the membrane map (v == NULL: sigmoid' from pv).
+    A pooling layer among the items: the call falls back to one dv launch per layer, same results."""
+    from snn_modulation_classification_amd import ops
+    rng = np.random.RandomState(B)
+
+    def layer(cin, out_layer, pool=(1, 1)):
+        d = ops.make_conv_desc(cin, 32, (16, 16), (7, 7), (3, 3), pool, 24, out_layer, True, 1.0)
+        ch, cw, ph, pw = ops.conv_out_shape(d)
+        K = 32 * ph * pw
+        v = cu(rng.randn(B, 32, ch, cw).astype(np.float32), dev)
+        pv = torch.sigmoid(v) if pool == (1, 1) else cu(rng.uniform(0, 1, size=(B, 32, ph, pw)).astype(np.float32), dev)
+        return dict(d=d, eps1=cu(rng.uniform(0, 3, size=(B, cin, 16, 16)).astype(np.float32), dev), v=v, pv=pv,
+                    g_p=cu(rng.randn(B, 24).astype(np.float32) * 1e-3, dev),
+                    g_o=cu(rng.randn(B, 24).astype(np.float32) * 1e-3, dev) if out_layer else None,
+                    W=cu(rng.uniform(-.005, .005, size=(24, K)).astype(np.float32), dev), out_layer=out_layer)
+
+    def run(layers, multi):
+        outs, deferred = [], ([] if multi else None)
+        for L in layers:
+            out = {}
+            v = None if (from_pv and L['d'].pool_h == 1) else L['v']
+            ops.conv_lif_backward(L['d'], L['eps1'], v, L['pv'], L['g_p'], L['g_o'], None, None, L['W'], want_out=L['out_layer'],
+                                  out=out, open_reduce=True, defer=deferred)
+            outs.append(out)
+        if multi:
+            ops.conv_lif_backward_open_multi(deferred)
+        for out in outs:
+            out['dW'].fill_(7.0)
+            ops.grad_reduce_adam([dict(out['parts'])], [])
+        return outs
+    layers = [layer(1, False), layer(32, False), layer(32, True)]
+    single = run(layers, False)
+    with ops.kernel_trace() as tr:
+        multi = run(layers, True)
+    assert tr.count("k_bwd_dv_nopool_m") == 1 and tr.count("k_bwd_dv") == 0, tr.names
+    assert tr.count("k_bwd_wgrad_c32") == 2 and tr.count("k_bwd_wgrad_c1") == 1 and tr.count("k_bwd_outgrad_mfma") == 1
+    for a, b in zip(single, multi):
+        assert torch.equal(a['dW'], b['dW']) and torch.equal(a['db'], b['db'])
+    assert torch.equal(single[2]['d_outW'], multi[2]['d_outW']) and torch.equal(single[2]['d_outb'], multi[2]['d_outb'])
+    # a pooling layer among the items: no joint dv launch, same results
+    mixed = [layer(32, False), layer(32, False, pool=(2, 2))]
+    single = run(mixed, False)
+    with ops.kernel_trace() as tr:
+        multi = run(mixed, True)
+    assert tr.count("k_bwd_dv_nopool_m") == 0 and tr.count("k_bwd_dv") == 2, tr.names
+    for a, b in zip(single, multi):
+        assert torch.equal(a['dW'], b['dW']) and torch.equal(a['db'], b['db'])
+
+
 def test_edge_cases_empty_and_single(dev):
     """Empty batch / zero timesteps are no-ops, B = 1 and T = 1 work (the reference itself breaks at B = 1 in
     iq2spiketrain's squeeze), invalid windows are rejected with ValueError."""
