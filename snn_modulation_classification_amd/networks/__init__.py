@@ -459,12 +459,17 @@ class ConvNetwork(torch.nn.Module):
                     L._defer_sink = pend
                 for s in self.dcll_slices:
                     spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
+                ops.run_deferred_readouts([fin for _, fin, _ in pend])
+                for s, fin, pos in pend:
+                    s._clout[pos] = fin['clout']
+            except BaseException:
+                for s, _, pos in reversed(pend):           # (no placeholder of an unfinished step stays behind)
+                    if pos < len(s._clout) and s._clout[pos] is None:
+                        del s._clout[pos]
+                raise
             finally:
                 for L in layers:
                     L.__dict__.pop('_defer_sink', None)
-            ops.run_deferred_readouts([fin for _, fin, _ in pend])
-            for s, fin, pos in pend:
-                s._clout[pos] = fin['clout']
         return spikes
 
     # -- the inference timestep as a captured hipGraph ------------------------------------------------------------------
