@@ -253,7 +253,13 @@ __global__ __launch_bounds__(256) void k_readout_t16m(const readout_t16_items it
     const long rows = it.rows[z];
     const int K = it.K[z], ks = it.kslice[z];
     if ((long)blockIdx.x * T16_ROWS >= rows || (int)blockIdx.y * ks >= K) return;        // (whole workgroups: before any barrier)
-    readout_t16_body<NT, false>(it.pv[z], it.Wt[z], nullptr, it.out[z], rows, K, it.N[z], ks, blockIdx.x, blockIdx.y);
+    // an item narrower than the launch's widest runs the instantiation of its own width (wave-uniform branch; its column
+    // tiles, its LDS staging — not the widest item's with spare tiles computed on zeros)
+    const int N = it.N[z];
+    if (NT >= 3 && N <= 32)
+        readout_t16_body<(NT >= 3 ? 2 : NT), false>(it.pv[z], it.Wt[z], nullptr, it.out[z], rows, K, N, ks, blockIdx.x, blockIdx.y);
+    else
+        readout_t16_body<NT, false>(it.pv[z], it.Wt[z], nullptr, it.out[z], rows, K, N, ks, blockIdx.x, blockIdx.y);
 }
 // Requires K % 32 == 0, N <= 64, 16-byte aligned pv / Wt rows (the caller checked).  kslice > 0: split-K launch (K %
 // kslice == 0, kslice % 32 == 0), `out` = the partial tiles (K / kslice) x rows x N.
@@ -297,8 +303,7 @@ int dcll_launch_readout_t16_multi(const float *const *pv, const float *const *Wt
     }
     for (int i = n; i < T16M_MAX; ++i) it.pv[i] = it.Wt[i] = nullptr, it.out[i] = nullptr, it.rows[i] = 0, it.K[i] = it.N[i] = 0, it.kslice[i] = 1;
     const dim3 g(gx, gy, (unsigned)n);
-    // one instantiation for the launch: the widest item's column tiles (an item with fewer columns computes the spare tiles
-    // on zeros and does not store them: its stored columns are the same chains)
+    // one kernel for the launch, instantiated for the widest item (narrower items branch to their own width inside it)
     if (nmax <= 16) hipLaunchKernelGGL(k_readout_t16m<1>, g, dim3(256), 0, st, it);
     else if (nmax <= 32) hipLaunchKernelGGL(k_readout_t16m<2>, g, dim3(256), 0, st, it);
     else if (nmax <= 48) hipLaunchKernelGGL(k_readout_t16m<3>, g, dim3(256), 0, st, it);

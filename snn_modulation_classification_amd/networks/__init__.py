@@ -149,8 +149,12 @@ class ConvNetwork(torch.nn.Module):
         from .. import parallel
         learned, pending = [], []
         ops.run_deferred_readouts([ctx['fin'] for ctx in ctxs])        # all slices' readout tails: two launches
-        # single rank: the slices' backward as one call (their dv launches as one launch; DCLL_BWD_MULTI=0: the control)
-        bwd = None if (ranks or os.environ.get('DCLL_BWD_MULTI', '1') == '0') else []
+        # single rank, small batches: the slices' backward as one call, their dv launches as one launch — where the timestep is
+        # launch-bound (captured timesteps at B = 64: +5 %); at B = 512 the three gradient maps written together (50 MB) and read
+        # back later cost more than the two launches (0.556 -> 0.56-0.58 ms per timestep), so each slice's dv stays in front of
+        # its weight gradient there.  DCLL_BWD_MULTI_MAX_BATCH (default 128; 0: never) moves the limit.
+        batch = ctxs[0]['input'].shape[0] if ctxs else 0
+        bwd = [] if (not ranks and batch <= int(os.environ.get('DCLL_BWD_MULTI_MAX_BATCH', '128'))) else None
         for s, ctx in zip(self.dcll_slices, ctxs):
             s._learn_tail(ctx, open_reduce=not ranks, defer_backward=bwd)
             if ctx['learned']:
