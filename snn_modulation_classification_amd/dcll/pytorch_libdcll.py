@@ -449,11 +449,14 @@ class Conv2dDCLLlayer(nn.Module):
         # (`_finish`: a slice asks for the step's fused tail — the recorded argmax — DCLLClassification.forward;
         #  `_skip_vmem`: ConvNetwork.test discards the tuple, so the un-pooled membrane map is not written: pvmem = None)
         #  `_defer_sink` (with `_finish`): ConvNetwork.test launches the readout tails of all slices together, later)
+        #  `_step_bufs`: ConvNetwork.test keeps one set of output maps per layer instead of allocating five tensors per step —
+        #  it discards the tuple; a direct caller of forward() gets fresh tensors, like the reference's)
         fin = self.__dict__.get('_finish')
         s, p, o, pv, v = self.i2h._step(input, self.pooling, self.i2o, self.output_ if self.output_layer else None,
                                         stacked=self.stacked_readout() if self.output_layer else None,
                                         finish=fin, want_v=not self.__dict__.get('_skip_vmem', False),
-                                        defer_ro=fin is not None and self.__dict__.get('_defer_sink') is not None)
+                                        defer_ro=fin is not None and self.__dict__.get('_defer_sink') is not None,
+                                        out=self.__dict__.get('_step_bufs'))
         return (o if self.output_layer else s), self._drop(p), pv, v
 
     def _drop(self, p):
@@ -1087,7 +1090,7 @@ class DCLLClassification(DCLLBase):
         fused = (record and isinstance(L, Conv2dDCLLlayer) and not L.dropout_active() and    # (a masked p: argmax after the mask)
                  not (getattr(L, 'build_graph', False) and torch.is_grad_enabled()))      # (not the autograd node)
         if fused:
-            L._finish = {'clout': True}         # the step's finishing launch also writes the argmax recorded below
+            L.__dict__['_finish'] = {'clout': True}     # the step's finishing launch also writes the argmax recorded below
         try:
             o, p, pv, pvmem = super().forward(input)
         finally:
@@ -1097,7 +1100,7 @@ class DCLLClassification(DCLLBase):
             if fin is not None and 'run_readouts' in fin:
                 # deferred readout tail (ConvNetwork.test): the caller runs it with the other slices' and fills this entry in
                 self._clout.append(None)
-                L._defer_sink.append((self, fin, len(self._clout) - 1))
+                L.__dict__['_defer_sink'].append((self, fin, len(self._clout) - 1))
             elif fin is not None and fin.get('done') and fin.get('clout') is not None:
                 self._clout.append(fin['clout'])
             else:

@@ -430,7 +430,7 @@ class ConvNetwork(torch.nn.Module):
         def ctx():
             layers = [s.dclllayer for s in self.dcll_slices if isinstance(s.dclllayer, Conv2dDCLLlayer)]
             for L in layers:
-                L._skip_vmem = True
+                L.__dict__['_skip_vmem'] = True         # (plain attribute: not through nn.Module.__setattr__)
             try:
                 yield
             finally:
@@ -459,8 +459,11 @@ class ConvNetwork(torch.nn.Module):
         layers = [s.dclllayer for s in self.dcll_slices]
         with self._no_vmem():
             try:
-                for L in layers:
-                    L._defer_sink = pend
+                bufs = self.__dict__.setdefault('_test_step_bufs', {})
+                for i, L in enumerate(layers):
+                    L.__dict__['_defer_sink'] = pend
+                    if isinstance(L, Conv2dDCLLlayer):      # (one set of output maps per layer, reused from step to step)
+                        L.__dict__['_step_bufs'] = bufs.setdefault((i, tuple(x.shape)), {})   # (per geometry: a capture bakes them in)
                 for s in self.dcll_slices:
                     spikes, _, _, _ = s.forward(spikes, ignore_burnin=True)
                 ops.run_deferred_readouts([fin for _, fin, _ in pend])
@@ -474,6 +477,7 @@ class ConvNetwork(torch.nn.Module):
             finally:
                 for L in layers:
                     L.__dict__.pop('_defer_sink', None)
+                    L.__dict__.pop('_step_bufs', None)
         return spikes
 
     # -- the inference timestep as a captured hipGraph ------------------------------------------------------------------

@@ -42,10 +42,20 @@ def conv_lif_backward_open_multi(deferred):
                                  db=e['db'], keep=e['scratch'])
 
 
+_OUT_SHAPES = {}
+
+
 def conv_out_shape(desc):
-    v = [ctypes.c_int32() for _ in range(4)]
-    check(_lib.get().dcll_conv_out_shape(ctypes.byref(desc), *[ctypes.byref(i) for i in v]), "dcll_conv_out_shape")
-    return tuple(i.value for i in v)      # conv_h, conv_w, pool_h, pool_w
+    """(conv_h, conv_w, pool_h, pool_w) of a descriptor, as the library computes them (dcll_conv_out_shape; remembered per
+    geometry: the per-step paths ask several times per layer step)."""
+    key = (desc.c_in, desc.c_out, desc.h, desc.w, desc.kh, desc.kw, desc.pad_h, desc.pad_w, desc.stride, desc.dilation,
+           desc.groups, desc.pool_h, desc.pool_w, desc.target)      # (everything the library's descriptor check looks at)
+    got = _OUT_SHAPES.get(key)
+    if got is None:
+        v = [ctypes.c_int32() for _ in range(4)]
+        check(_lib.get().dcll_conv_out_shape(ctypes.byref(desc), *[ctypes.byref(i) for i in v]), "dcll_conv_out_shape")
+        got = _OUT_SHAPES[key] = tuple(i.value for i in v)
+    return got
 
 
 def _f32(t, name):
