@@ -24,4 +24,4 @@ print("host enqueue %.1f us per timestep, + %.1f us drain per timestep" % (1e6 *
 pr = cProfile.Profile(); pr.enable()
 for t in range(200): net.test(x)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(34)

@@ -202,5 +202,10 @@ def ptr(t):
 
 
 def stream_ptr():
+    """The current stream of the current device as a hipStream_t (queried per call: a graph capture runs on a side stream).
+    torch's raw accessor where it exists — torch.cuda.current_stream() builds a Stream object, ~6 us, four times per timestep."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return ctypes.c_void_p(raw(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
