@@ -4,70 +4,77 @@ device encoder, against the per-step path (k_conv_lif_tiled / k_lif_step_c32 / t
 encoder's cells (iq2cells = the reference's slicing), for random batch sizes (ragged: not multiples of 32), sequence
 lengths, planes, int8 weights through the ABI or not, pv_presigmoid on / off / auto; state, logits must agree.
     python experiments/cross_check.py [seed] [trials]"""
-import os, sys
-import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from argparse import Namespace
-from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
-from snn_modulation_classification_amd.data.utils import IQEncoder, iq2cells
-from snn_modulation_classification_amd import quant
-PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snn_modulation_classification_amd")
-convs_radio = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
-convs_ref = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv_ref.yaml"))
-rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-n_ok = 0
-for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
-    ref_net = rng.uniform() < 0.3
-    R = int(rng.choice([16, 16, 16, 32, 64]))
-    H, Wd = (16, 128) if ref_net else (R, R)
-    B = int(rng.randint(2, 40 if R == 16 else 6)) if not ref_net else int(rng.randint(2, 12))   # (B = 1: the reference's x.squeeze() fails)
-    T = int(rng.randint(1, 70 if R == 16 else 12)) if not ref_net else int(rng.randint(1, 25))
-    arp = float(rng.choice([1.0, 0.0]))
-    int8 = bool(rng.uniform() < 0.5)
-    os.environ["DCLL_PRESIGMOID"] = str(rng.choice(["auto", "1", "0"]))
-    convs = convs_ref if ref_net else convs_radio
-    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=arp, lc_ampl=.5, random_tau=True)
-    nets = []
-    for _ in range(2):
-        torch.manual_seed(trial); np.random.seed(trial)
-        n = ConvNetwork(args, (1, H, Wd), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
-                        learning_rates=None, burnin=0)
-        n.reset(True)
-        if int8:
-            quant.apply_int8_weights(n)
-        nets.append(n)
-    a, b = nets
-    L = len(a.dcll_slices)
-    enc = IQEncoder(Wd, H, device="cuda")
-    for rnd in range(2):                       # two consecutive batches: state carry-over
-        iq_host = 0.45 * torch.randn(B, 2, 128)
-        # a few samples exactly on cell boundaries of either pow path
-        for tab in (enc.thr_i, enc.thr_i_tail):
-            if tab is not None and B > 1:
-                iq_host[rng.randint(0, B), 0, :tab.numel()] = tab.cpu()
-        np.random.seed(1000 + trial)            # iq2cells draws t0 (0 here: L == T + offset is not random when T == 128 ...)
-        cells_host, t0 = iq2cells(iq_host, Wd, H, max_duration=T)
-        cells = cells_host.cuda()
-        a.reset(); b.reset()
-        ra = a.test_sequence(iq=iq_host.cuda(), encoder=enc, T=T, t0=t0)
-        logits = [[] for _ in range(L)]
-        for t in range(T):
-            x = torch.zeros(B, H * Wd, device="cuda")
-            x[torch.arange(B), cells[t].long()] = 1
-            cur = x.reshape(B, 1, H, Wd)
-            for i, s in enumerate(b.dcll_slices):
-                o, p, pv, v = s.forward(cur, ignore_burnin=True)
-                logits[i].append(p)
-                cur = o
-        for i in range(L):
-            for name in ("eps0", "eps1") + (("arp",) if arp > 0 else ()):
-                sa = getattr(a.dcll_slices[i].dclllayer.i2h.state, name)
-                sb = getattr(b.dcll_slices[i].dclllayer.i2h.state, name)
-                assert torch.equal(sa, sb), (trial, rnd, ref_net, R, B, T, arp, int8, i, name)
-            ref = torch.stack(logits[i])
-            err = float((ra["logits"][i] - ref).abs().max())
-            assert err < 1e-4, (trial, rnd, ref_net, R, B, T, arp, int8, i, err)
-    n_ok += 1
-    print("trial %2d ok: %s plane %dx%d, B=%d, T=%d, arp=%g, int8=%s, presigmoid=%s" %
-          (trial, "ref  " if ref_net else "radio", H, Wd, B, T, arp, int8, os.environ["DCLL_PRESIGMOID"]), flush=True)
-print("all %d trials agree" % n_ok)
+
+
+def main():
+    import os, sys
+    import numpy as np, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from argparse import Namespace
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from snn_modulation_classification_amd.data.utils import IQEncoder, iq2cells
+    from snn_modulation_classification_amd import quant
+    PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snn_modulation_classification_amd")
+    convs_radio = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv.yaml"))
+    convs_ref = load_network_spec(os.path.join(PKG, "networks", "radio_ml_conv_ref.yaml"))
+    rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+    n_ok = 0
+    for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+        ref_net = rng.uniform() < 0.3
+        R = int(rng.choice([16, 16, 16, 32, 64]))
+        H, Wd = (16, 128) if ref_net else (R, R)
+        B = int(rng.randint(2, 40 if R == 16 else 6)) if not ref_net else int(rng.randint(2, 12))   # (B = 1: the reference's x.squeeze() fails)
+        T = int(rng.randint(1, 70 if R == 16 else 12)) if not ref_net else int(rng.randint(1, 25))
+        arp = float(rng.choice([1.0, 0.0]))
+        int8 = bool(rng.uniform() < 0.5)
+        os.environ["DCLL_PRESIGMOID"] = str(rng.choice(["auto", "1", "0"]))
+        convs = convs_ref if ref_net else convs_radio
+        args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=arp, lc_ampl=.5, random_tau=True)
+        nets = []
+        for _ in range(2):
+            torch.manual_seed(trial); np.random.seed(trial)
+            n = ConvNetwork(args, (1, H, Wd), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={},
+                            learning_rates=None, burnin=0)
+            n.reset(True)
+            if int8:
+                quant.apply_int8_weights(n)
+            nets.append(n)
+        a, b = nets
+        L = len(a.dcll_slices)
+        enc = IQEncoder(Wd, H, device="cuda")
+        for rnd in range(2):                       # two consecutive batches: state carry-over
+            iq_host = 0.45 * torch.randn(B, 2, 128)
+            # a few samples exactly on cell boundaries of either pow path
+            for tab in (enc.thr_i, enc.thr_i_tail):
+                if tab is not None and B > 1:
+                    iq_host[rng.randint(0, B), 0, :tab.numel()] = tab.cpu()
+            np.random.seed(1000 + trial)            # iq2cells draws t0 (0 here: L == T + offset is not random when T == 128 ...)
+            cells_host, t0 = iq2cells(iq_host, Wd, H, max_duration=T)
+            cells = cells_host.cuda()
+            a.reset(); b.reset()
+            ra = a.test_sequence(iq=iq_host.cuda(), encoder=enc, T=T, t0=t0)
+            logits = [[] for _ in range(L)]
+            for t in range(T):
+                x = torch.zeros(B, H * Wd, device="cuda")
+                x[torch.arange(B), cells[t].long()] = 1
+                cur = x.reshape(B, 1, H, Wd)
+                for i, s in enumerate(b.dcll_slices):
+                    o, p, pv, v = s.forward(cur, ignore_burnin=True)
+                    logits[i].append(p)
+                    cur = o
+            for i in range(L):
+                for name in ("eps0", "eps1") + (("arp",) if arp > 0 else ()):
+                    sa = getattr(a.dcll_slices[i].dclllayer.i2h.state, name)
+                    sb = getattr(b.dcll_slices[i].dclllayer.i2h.state, name)
+                    assert torch.equal(sa, sb), (trial, rnd, ref_net, R, B, T, arp, int8, i, name)
+                ref = torch.stack(logits[i])
+                err = float((ra["logits"][i] - ref).abs().max())
+                assert err < 1e-4, (trial, rnd, ref_net, R, B, T, arp, int8, i, err)
+        n_ok += 1
+        print("trial %2d ok: %s plane %dx%d, B=%d, T=%d, arp=%g, int8=%s, presigmoid=%s" %
+              (trial, "ref  " if ref_net else "radio", H, Wd, B, T, arp, int8, os.environ["DCLL_PRESIGMOID"]), flush=True)
+    print("all %d trials agree" % n_ok)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,53 +1,60 @@
 """k_lif_step_c32 alone through the layer API (`i2h._step`): does its time depend on the input data, on reusable output
 buffers, on what ran before?  (diagnostic, not product)   python experiments/step_data_dependence.py"""
-import os, sys, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from argparse import Namespace
-import bench
-from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
-dev = torch.device("cuda", 0)
-B = 512
 
 
-def t(i2h, x, n=60, **kw):
-    for _ in range(5):
-        i2h._step(x, **kw)
+def main():
+    import os, sys, torch, numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from argparse import Namespace
+    import bench
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    dev = torch.device("cuda", 0)
+    B = 512
+
+
+    def t(i2h, x, n=60, **kw):
+        for _ in range(5):
+            i2h._step(x, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            i2h._step(x, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / n
+
+
+    net, _ = bench.build_net(B, dev)
+    i2h = net.dcll_slices[1].dclllayer.i2h
+    for name, x in (("zeros", torch.zeros(B, 32, 16, 16, device=dev)), ("5% spikes", (torch.rand(B, 32, 16, 16, device=dev) < 0.05).float()),
+                    ("dense randn", torch.randn(B, 32, 16, 16, device=dev))):
+        for st in i2h.state:
+            st.zero_()
+        print("inference net,", name, "want_v=False: %.1f us" % t(i2h, x, want_v=False), " want_v=True: %.1f us" % t(i2h, x, want_v=True))
+    x = (torch.rand(B, 32, 16, 16, device=dev) < 0.05).float()
+    print("inference net, reusable out buffers: %.1f us" % t(i2h, x, want_v=False, out={}))
+    convs = load_network_spec(os.path.join(bench.ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    lnet = ConvNetwork(args, (1, 16, 16), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss, opt=torch.optim.Adam,
+                       opt_param={"betas": [0.0, .95], "weight_decay": 10.0}, learning_rates=[2.5e-10], burnin=2)
+    lnet.reset(True)
+    li = lnet.dcll_slices[1].dclllayer.i2h
+    print("learning net, fresh: %.1f us" % t(li, x, want_v=False))
+    xs = torch.zeros(30, B, 1, 256, device=dev)
+    xs.scatter_(3, torch.randint(0, 256, (30, B), device=dev)[:, :, None, None], 1.0)
+    xs = xs.reshape(30, B, 1, 16, 16)
+    y = torch.zeros(B, 24, device=dev)
+    y[torch.arange(B), torch.randint(0, 24, (B,))] = 1
+    for k in range(30):
+        lnet.learn(xs[k], y)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        i2h._step(x, **kw)
-    e1.record()
-    torch.cuda.synchronize()
-    return 1e3 * e0.elapsed_time(e1) / n
-
-
-net, _ = bench.build_net(B, dev)
-i2h = net.dcll_slices[1].dclllayer.i2h
-for name, x in (("zeros", torch.zeros(B, 32, 16, 16, device=dev)), ("5% spikes", (torch.rand(B, 32, 16, 16, device=dev) < 0.05).float()),
-                ("dense randn", torch.randn(B, 32, 16, 16, device=dev))):
-    for st in i2h.state:
+    print("learning net, after 30 learning steps: %.1f us" % t(li, x, want_v=False))
+    print("state magnitudes: eps1 max %.3g, arp min %.3g" % (float(li.state.eps1.abs().max()), float(li.state.arp.min())))
+    for st in li.state:
         st.zero_()
-    print("inference net,", name, "want_v=False: %.1f us" % t(i2h, x, want_v=False), " want_v=True: %.1f us" % t(i2h, x, want_v=True))
-x = (torch.rand(B, 32, 16, 16, device=dev) < 0.05).float()
-print("inference net, reusable out buffers: %.1f us" % t(i2h, x, want_v=False, out={}))
-convs = load_network_spec(os.path.join(bench.ROOT, "snn_modulation_classification_amd", "networks", "radio_ml_conv.yaml"))
-args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
-lnet = ConvNetwork(args, (1, 16, 16), B, convs, 24, act=torch.nn.Sigmoid(), loss=torch.nn.SmoothL1Loss, opt=torch.optim.Adam,
-                   opt_param={"betas": [0.0, .95], "weight_decay": 10.0}, learning_rates=[2.5e-10], burnin=2)
-lnet.reset(True)
-li = lnet.dcll_slices[1].dclllayer.i2h
-print("learning net, fresh: %.1f us" % t(li, x, want_v=False))
-xs = torch.zeros(30, B, 1, 256, device=dev)
-xs.scatter_(3, torch.randint(0, 256, (30, B), device=dev)[:, :, None, None], 1.0)
-xs = xs.reshape(30, B, 1, 16, 16)
-y = torch.zeros(B, 24, device=dev)
-y[torch.arange(B), torch.randint(0, 24, (B,))] = 1
-for k in range(30):
-    lnet.learn(xs[k], y)
-torch.cuda.synchronize()
-print("learning net, after 30 learning steps: %.1f us" % t(li, x, want_v=False))
-print("state magnitudes: eps1 max %.3g, arp min %.3g" % (float(li.state.eps1.abs().max()), float(li.state.arp.min())))
-for st in li.state:
-    st.zero_()
-print("learning net, state zeroed again: %.1f us" % t(li, x, want_v=False))
+    print("learning net, state zeroed again: %.1f us" % t(li, x, want_v=False))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,30 +1,37 @@
-import os, sys, json, time
-sys.path.insert(0, os.getcwd())
-import numpy as np, torch
-import bench
-from argparse import Namespace
-from snn_modulation_classification_amd import quant
-from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
-from snn_modulation_classification_amd.data.utils import IQEncoder
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-dev = torch.device("cuda", 0)
-convs = load_network_spec("snn_modulation_classification_amd/networks/radio_ml_conv_ref.yaml")
-args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
-torch.manual_seed(1); np.random.seed(1)
-net = ConvNetwork(args, (1, 16, 128), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={}, learning_rates=None, burnin=20)
-net.reset(True); quant.apply_int8_weights(net)
-net.pv_budget_bytes = 150 * 2 ** 30
-enc = IQEncoder(128, 16, device=dev)
-iq = (0.4 * torch.randn(B, 2, 128)).to(dev)
-for rep in range(2):
-    prof = {}
-    net.zero_states(); net.reset()
-    net.test_sequence(iq=iq, encoder=enc, T=128, t0=0, collect=False, profile=prof)
-    torch.cuda.synchronize()
-ms = [s.elapsed_time(e) for s, e in prof["lif_c32"]]
-ro = [s.elapsed_time(e) for s, e in prof["readout"]]
-for l, m in enumerate(ms, start=1):
-    W = 128 >> l
-    fl = 2 * 64 * 64 * 3 * 16 * W * 128 * B
-    print("layer %d  W=%3d  %7.2f ms  %6.1f TFLOP/s  %4.1f %% of peak   workgroups %d" % (l, W, m, fl / m / 1e9, 100 * fl / m / 1e9 / 157.3, B * 16 * W // 256))
-print("layer 0: %.2f ms; readouts:" % ([s.elapsed_time(e) for s, e in prof["lif_c1"]][0]), ["%.2f" % r for r in ro])
+
+
+def main():
+    import os, sys, json, time
+    sys.path.insert(0, os.getcwd())
+    import numpy as np, torch
+    import bench
+    from argparse import Namespace
+    from snn_modulation_classification_amd import quant
+    from snn_modulation_classification_amd.networks import ConvNetwork, load_network_spec
+    from snn_modulation_classification_amd.data.utils import IQEncoder
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    dev = torch.device("cuda", 0)
+    convs = load_network_spec("snn_modulation_classification_amd/networks/radio_ml_conv_ref.yaml")
+    args = Namespace(netscale=1.0, alpha=.92, alphas=.85, alpharp=.65, arp=1.0, lc_ampl=.5, random_tau=True)
+    torch.manual_seed(1); np.random.seed(1)
+    net = ConvNetwork(args, (1, 16, 128), B, convs, 24, act=torch.nn.Sigmoid(), loss=None, opt=None, opt_param={}, learning_rates=None, burnin=20)
+    net.reset(True); quant.apply_int8_weights(net)
+    net.pv_budget_bytes = 150 * 2 ** 30
+    enc = IQEncoder(128, 16, device=dev)
+    iq = (0.4 * torch.randn(B, 2, 128)).to(dev)
+    for rep in range(2):
+        prof = {}
+        net.zero_states(); net.reset()
+        net.test_sequence(iq=iq, encoder=enc, T=128, t0=0, collect=False, profile=prof)
+        torch.cuda.synchronize()
+    ms = [s.elapsed_time(e) for s, e in prof["lif_c32"]]
+    ro = [s.elapsed_time(e) for s, e in prof["readout"]]
+    for l, m in enumerate(ms, start=1):
+        W = 128 >> l
+        fl = 2 * 64 * 64 * 3 * 16 * W * 128 * B
+        print("layer %d  W=%3d  %7.2f ms  %6.1f TFLOP/s  %4.1f %% of peak   workgroups %d" % (l, W, m, fl / m / 1e9, 100 * fl / m / 1e9 / 157.3, B * 16 * W // 256))
+    print("layer 0: %.2f ms; readouts:" % ([s.elapsed_time(e) for s, e in prof["lif_c1"]][0]), ["%.2f" % r for r in ro])
+
+
+if __name__ == "__main__":
+    main()

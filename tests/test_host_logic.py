@@ -67,6 +67,23 @@ def test_product_never_imports_the_oracle():
             assert not re.search(r"^\s*(from|import)\s+oracle\b", open(p).read(), flags=re.M), fn
 
 
+def test_pytest_from_the_repo_root_collects_only_tests():
+    """`pytest` issued from the repo root (no path argument) must collect tests/ and nothing else: experiments/ holds
+    scripts, some of which build a network on the GPU (round-5 verdict, weak #1)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", "--collect-only", "-q", "-p", "no:cacheprovider"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    items = [l for l in r.stdout.splitlines() if "::" in l]
+    assert len(items) > 100
+    assert all(l.startswith("tests/") for l in items), [l for l in items if not l.startswith("tests/")][:5]
+    for fn in os.listdir(os.path.join(ROOT, "experiments")):
+        assert not (fn.startswith("test_") or fn.endswith("_test.py")), "experiments/%s would be collected" % fn
+        if fn.endswith(".py"):
+            assert '__name__ == "__main__"' in open(os.path.join(ROOT, "experiments", fn)).read(), fn
+
+
 # ---------------------------------------------------------------------------------------------- encoders
 @pytest.mark.parametrize("R_,T", [(16, 64), (16, 32), (28, 64), (28, 32), (128, 64), (128, 32)])
 def test_iq2spiketrain_matches_reference(golden, R_, T):
