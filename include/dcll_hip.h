@@ -158,7 +158,10 @@ int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const float *W, 
  *   g_pv (B,c_out,ph,pw) of pv, g_v (B,c_out,ch,cw) of pvmem
  *   results: dW (c_out,c_in,kh,kw), db (c_out) [may be NULL]; d_outW (target, c_out*ph*pw), d_outb (target) iff g_o
  *   scratch: scratch_floats >= B*c_out*ch*cw + k*c_out*(c_in*kh*kw + 1) floats with k >= 1 batch chunks for the weight
- *   gradient's partial sums (more chunks = more parallelism; up to 256 are used).
+ *   gradient's partial sums (more chunks = more parallelism; up to 256 are used).  An output_ layer with target <= 32 whose
+ *   K = c_out*ph*pw is not a multiple of 32 sums its gradient over min(B, 16, m) batch chunks of target*(K+1) floats, m = what
+ *   fits into the partial-sum area (closed form: the area is reused) or behind the rows in use (dcll_conv_lif_backward_open):
+ *   with room for min(B, 16) chunks in either place both forms give the same bits.
  *   i2o is frozen, neuron state detached, output_ sees pv.detach() (:570,:504,:606).
  */
 int dcll_conv_lif_backward(const dcll_conv_desc *d, const float *eps1, const float *v, const float *pv_pooled,

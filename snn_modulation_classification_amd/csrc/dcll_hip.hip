@@ -3203,9 +3203,12 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
     }
     if (g_o) {
         const int K = d->c_out * ph * pw, N = d->target;
-        // the partial-sum area of the weight gradient is free again (stream order): reuse it for the batch chunks —
-        // unless the partial rows are still wanted (open form): then only the forms without partial sums serve
-        long nsplit = open_part ? 0 : (scratch_floats - nconv) / ((long)N * (K + 1));
+        // closed form: the partial-sum area of the weight gradient is free again (stream order) and holds the batch chunks.
+        // Open form: the partial rows are still wanted, the batch chunks go BEHIND the nchunk rows in use.  With scratch for
+        // min(B, 16) chunks in either place (what ops.conv_lif_backward provides) both forms split the batch alike, so
+        // d_outW / d_outb are the same bits from dcll_conv_lif_backward and dcll_conv_lif_backward_open.
+        float *opart = open_part ? part + nchunk * per_chunk : part;
+        long nsplit = (scratch_floats - (opart - scratch)) / ((long)N * (K + 1));
         if (nsplit > 16) nsplit = 16;
         if (nsplit > B) nsplit = B;
         if (N <= 32 && K % 32 == 0) {
@@ -3213,9 +3216,9 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
             HIP_CHECK_LAUNCH("k_bwd_outgrad_mfma");
         } else if (N <= 32 && nsplit >= 1) {
             hipLaunchKernelGGL(k_bwd_outgrad_part, dim3(nblk((long)K + N, 256), (unsigned)nsplit), dim3(256), 0, st, g_o,
-                               pv_pooled, part, B, N, K);
+                               pv_pooled, opart, B, N, K);
             HIP_CHECK_LAUNCH("k_bwd_outgrad_part");
-            hipLaunchKernelGGL(k_bwd_outgrad_reduce, dim3(nblk((long)N * (K + 1), 256)), dim3(256), 0, st, part, d_outW,
+            hipLaunchKernelGGL(k_bwd_outgrad_reduce, dim3(nblk((long)N * (K + 1), 256)), dim3(256), 0, st, opart, d_outW,
                                d_outb, (int)nsplit, N, K);
             HIP_CHECK_LAUNCH("k_bwd_outgrad_reduce");
         } else {

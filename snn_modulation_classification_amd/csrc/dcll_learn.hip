@@ -450,6 +450,9 @@ extern "C" int dcll_grad_reduce_adam(const dcll_grad_parts *layers, int32_t n_la
     if (n_layers == 0 && n_tensors == 0) return DCLL_OK;
     if (n_layers < 0 || n_layers > DCLL_REDUCE_MAX_LAYERS || (n_layers > 0 && !layers))
         return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: bad argument (0..4 layers)");
+    // (the layer loop below reads tensors[adam_w / adam_b]: checked here, before adam_fill's own check is reached)
+    if (n_tensors < 0 || n_tensors > DCLL_ADAM_MAX_TENSORS || (n_tensors > 0 && !tensors))
+        return fail(DCLL_ERR_INVALID, "dcll_grad_reduce_adam: bad argument (0..8 tensors, non-NULL when n_tensors > 0)");
     reduce_adam_args ra;
     bool taken[DCLL_ADAM_MAX_TENSORS] = {false};
     long blocks = 0;

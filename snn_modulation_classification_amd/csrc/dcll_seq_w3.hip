@@ -485,7 +485,7 @@ constexpr int W3F_NCH = 8, W3F_WPB = 4;      // channels per wave, waves per wor
 template <bool REFRACTORY, int OUT, int NCH>
 __global__ __launch_bounds__(64 * W3F_WPB) void k_lif_seq_w3f(const int32_t *__restrict__ cells, const dcll_wsrc W,
                                                       const float *__restrict__ bias, const float *__restrict__ tau4,
-                                                      float *__restrict__ eps0_g, float *__restrict__ eps1_g,
+                                                      const float *__restrict__ eps0_g, const float *__restrict__ eps1_g,
                                                       float *__restrict__ arp_g, uint32_t *__restrict__ spk_out,
                                                       float *__restrict__ pv_out, float *__restrict__ v_out, int T, int B, int HW,
                                                       int logW, long nitems, float alpharp, float wrp)
@@ -580,15 +580,42 @@ __global__ __launch_bounds__(64 * W3F_WPB) void k_lif_seq_w3f(const int32_t *__r
             *(u32x2 *)wp = u32x2{wlo, whi};
         }
     }
-    // ---- state back to HBM: traces by the wave of channel group 0 (every group holds the same), arp by its owner ----------
-    if (cg == 0) {
-        *(f32x2 *)(eps0_g + sb) = f32x2{e0LA[1], e0BR[0]};
-        *(f32x2 *)(eps1_g + sb) = f32x2{e1LA[1], e1BR[0]};
-    }
+    // ---- state back to HBM: arp by its owner.  The input traces are NOT written here: every wave of a sample (all channel
+    // groups, and the neighbouring segments through their halo pixels) reads them at its start, the grid is far larger than
+    // residency and workgroup start order is not defined — a wave that started after an in-place writer had retired would
+    // take end-of-sequence traces as its initial state.  k_w3f_traces_advance, launched behind this kernel, advances them.
     if (REFRACTORY) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) *(f32x2 *)(arp_g + (b * 64 + ch0 + c) * HW + pA) = arp[c];
     }
+}
+
+// The first layer's input traces after T steps, in place: thread = one pixel pair of one sample; reads and writes ITS two
+// elements only, and runs behind k_lif_seq_w3f on the same stream (which only reads them) — no launch ever reads trace
+// memory another wave of the same launch writes.  The same packed IEEE operations, in the same order, as the trace block
+// of k_lif_seq_w3f, so the state equals what the per-step kernels leave, bit for bit.  Cost: B * HW / 2 threads x T steps
+// of four packed instructions — under 1 % of k_lif_seq_w3f's time.
+__global__ __launch_bounds__(256) void k_w3f_traces_advance(const int32_t *__restrict__ cells, const float *__restrict__ tau4,
+                                                             float *__restrict__ eps0_g, float *__restrict__ eps1_g, int T,
+                                                             int B, int HW, long npair)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npair) return;
+    const int hp = HW >> 1;                              // pairs per sample plane: a multiple of 64, so b is wave-uniform
+    const long b = uniform_long(i / hp);
+    const int qA = 2 * (int)(i - b * hp);
+    const float ta = tau4[0], tm = tau4[1], tas = tau4[2], ts = tau4[3];
+    const f32x2 ta2 = {ta, ta}, tm2 = {tm, tm}, tas2 = {tas, tas};
+    f32x2 e0 = *(const f32x2 *)(eps0_g + 2 * i), e1 = *(const f32x2 *)(eps1_g + 2 * i);
+    int cell = cells[b];
+    for (int t = 0; t < T; ++t) {
+        const f32x2 x = {cell == qA ? ts : 0.0f, cell == qA + 1 ? ts : 0.0f};
+        e0 = x + tas2 * e0;
+        e1 = ta2 * e1 + e0 * tm2;
+        if (t + 1 < T) cell = cells[(long)(t + 1) * B + b];
+    }
+    *(f32x2 *)(eps0_g + 2 * i) = e0;
+    *(f32x2 *)(eps1_g + 2 * i) = e1;
 }
 
 // geometry served: c_in 1 or 64, c_out 64, kernel (1,3), padding (0,1), pooling (1,2), w a power of two <= 256,
@@ -639,6 +666,10 @@ int dcll_launch_seq_w3(const dcll_conv_desc *d, const uint32_t *spk_in, const in
 #undef DCLL_LAUNCH_W3FO
 #undef DCLL_LAUNCH_W3F
         HIP_CHECK_LAUNCH("k_lif_seq_w3f");
+        const long npair = (long)B * (HW / 2);
+        hipLaunchKernelGGL(k_w3f_traces_advance, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, st, cells, tau4, eps0, eps1,
+                           T, B, (int)HW, npair);
+        HIP_CHECK_LAUNCH("k_w3f_traces_advance");
         return DCLL_OK;
     }
 #define DCLL_LAUNCH_W3W(R, O, WD)                                                                                       \

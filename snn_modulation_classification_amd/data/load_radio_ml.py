@@ -82,19 +82,13 @@ def _split_done(data_dir):
 
 def ensure_split(data_dir):
     """The reference's trigger (:23): the monolithic file is there and no class23_snr30 block yet -> split it.  ONE process
-    does it: under ranks (`--gpus N`: every rank builds its loader) rank 0 splits and the others wait at a barrier; plain
-    processes that share the directory serialise on a lock file and look again once they hold it.  (Unguarded, N ranks made
-    N passes over the 20 GB file at once, each rewriting the same blocks under the others' np.load.)"""
-    if not os.path.exists(os.path.join(data_dir, GOLD_2018)):
-        return
-    from .. import parallel
-    if parallel.is_distributed():
-        import torch.distributed as dist
-        if dist.get_rank() == 0 and not _split_done(data_dir):
-            split_gold_file(data_dir)
-        parallel.barrier()
-        return
-    if _split_done(data_dir):
+    per directory does it: every process — plain ones that share the directory, and every rank under `--gpus N` — takes
+    the directory's lock file and looks again once it holds it.  No collective is involved: a multi-minute pass over the
+    20 GB file cannot run into the backend's collective timeout, node-local data directories each get their split (from
+    whichever local rank arrives first), and a failing split raises on the rank that ran it while the next holder of the
+    lock tries — and fails — itself instead of waiting at a barrier nobody reaches.  (Unguarded, N ranks made N passes over
+    the file at once, each rewriting the same blocks under the others' np.load.)"""
+    if not os.path.exists(os.path.join(data_dir, GOLD_2018)) or _split_done(data_dir):
         return
     import fcntl
     with open(os.path.join(data_dir, ".split.lock"), "w") as lock:

@@ -170,14 +170,27 @@ class ConvNetwork(torch.nn.Module):
         """Single rank: ONE launch reduces the open weight gradients of the slices that learned (fixed order: the gradients
         in .grad are bit-identical to the per-slice reduction) and applies torch.optim.Adam's update to all their tensors
         (ops.grad_reduce_adam; output_.* get the plain elementwise update in the same launch)."""
-        tensors, layers = [], []
+        from .. import _lib
+        tensors, layers, done = [], [], 0
+
+        def flush():
+            nonlocal tensors, layers, done
+            if layers:
+                ops.grad_reduce_adam(layers, tensors, dyn=None if dyn is None else dyn[3 * done:3 * (done + len(tensors))])
+            done += len(tensors)
+            tensors, layers = [], []
+        # the ABI takes DCLL_REDUCE_MAX_LAYERS layers / DCLL_ADAM_MAX_TENSORS tensors per launch: the default three slices
+        # are one launch, a deeper spec (radio_ml_conv_ref.yaml: 7 slices, 16 tensors) goes out in groups, slice order kept
+        # (dyn holds 3 floats per tensor in that same order)
         for s in learned:
-            base = len(tensors)
-            tensors += s._adam_tensors(advance=advance)
+            mine = s._adam_tensors(advance=advance)
+            if len(layers) + 1 > _lib.REDUCE_MAX_LAYERS or len(tensors) + len(mine) > _lib.ADAM_MAX_TENSORS:
+                flush()
             parts = dict(s._learn_bufs['grads']['parts'])
-            parts.update(adam_w=base, adam_b=base + 1)         # (_adam_tensors: i2h.weight, i2h.bias first)
+            parts.update(adam_w=len(tensors), adam_b=len(tensors) + 1)     # (_adam_tensors: i2h.weight, i2h.bias first)
+            tensors += mine
             layers.append(parts)
-        ops.grad_reduce_adam(layers, tensors, dyn=dyn)
+        flush()
 
     # -- the learning timestep as a captured hipGraph ------------------------------------------------------------------
     # At the reference's small batches (argparse default 64) a learning timestep is ~25 kernel launches of a few

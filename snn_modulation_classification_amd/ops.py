@@ -235,8 +235,10 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
     per_chunk = desc.c_out * (desc.c_in * desc.kh * desc.kw + 1)
     nchunk = min(jobs, 1024 if desc.c_in == 1 else 256)      # (first layer: 128-thread workgroups, 6 KB partial rows)
     part = nchunk * per_chunk
-    if want_out:
-        part = max(part, min(B, 8) * desc.target * (K + 1))
+    if want_out and desc.target <= 32 and K % 32 != 0:
+        # the output_ gradient's batch chunks (k_bwd_outgrad_part; K % 32 == 0 runs the MFMA form without them): BEHIND the
+        # weight gradient's rows — the open form keeps those — and for min(B, 16) chunks, the split both forms then take
+        part += min(B, 16) * desc.target * (K + 1)
     n_scratch = B * desc.c_out * ch * cw + part
     scratch = out.get('bwd_scratch')
     if scratch is None or scratch.numel() != n_scratch:

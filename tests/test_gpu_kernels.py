@@ -619,7 +619,10 @@ def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
                                                      (32, 32, False, (32, 48), 2), (32, 32, True, (128, 128), 2),
                                                      (1, 32, False, (16, 16), 300), (32, 32, True, (16, 16), 5),
                                                      (32, 32, False, (16, 16), 70), (32, 32, False, (16, 16), 130),
-                                                     (32, 32, True, (16, 16), 300)])
+                                                     (32, 32, True, (16, 16), 300),
+                                                     # K = 3 * 60 = 180, not a multiple of 32: the output_ gradient over batch
+                                                     # chunks (k_bwd_outgrad_part) — open and closed form must split alike
+                                                     (2, 3, True, (6, 10), 20)])
 def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
     """dcll_conv_lif_backward on large planes incl. the argparse default 128x128 (train.py:40-41): the generic
     weight-gradient kernel stages the eps1 plane in LDS in row bands (two bands at 128 rows), the 32 -> 32 layers use the
@@ -1022,6 +1025,80 @@ def test_sequence_w3_vs_oracle(dev, cin, hw, wrp, T, B, zero_state):
         assert bits_equal(arp.cpu().numpy(), orc.state[2])
     assert 0.005 < nspk / (T * B * cout * H * Wd / 2) < 0.95, "degenerate test"
 
+
+
+def test_sequence_w3_first_layer_grid_beyond_residency_with_carried_state(dev):
+    """k_lif_seq_w3f reads the input traces of a sample from 8 channel-group waves per segment (and from the neighbouring
+    segments' halo lanes); until round 6 the channel-group-0 wave wrote the advanced traces back IN PLACE, so on a grid
+    larger than residency a wave that started after that writer had retired took end-of-sequence traces as its initial
+    state (round-5 advisor, high).  Measured with experiments/w3f_race_check.py on the round-5 library: 128 of 2 048 samples
+    wrong at T = 32 (none at B = 384, T = 6 — hence this size: 262 144 waves against ~5 000 resident).  The traces are now
+    advanced by k_w3f_traces_advance behind the kernel.  Non-zero initial state; EVERY sample of the batch against the
+    same sample run in a co-resident pair (membrane map and final state, bit for bit), samples spread over the batch
+    against the C oracle (v, pooled spikes, state), the whole batch's final traces against the pinned recurrence in
+    numpy fp32, and the launch log."""
+    from snn_modulation_classification_amd import ops
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(77)
+    H, Wd, cin, cout, wrp, T, B = 16, 128, 1, 64, 1.0, 32, 2048
+    hw = (H, Wd)
+    stdv = 1.0 / np.sqrt(3) / 250
+    W = (rng.uniform(-stdv * 1e-2, stdv * 1e-2, size=(cout, cin, 1, 3)) * 3.0).astype(np.float32)
+    b = rng.uniform(-stdv, stdv, size=(cout,)).astype(np.float32)
+    alpha, alphas = np.float32([1 - 1e-3 / 20e-3]), np.float32([1 - 1e-3 / 7e-3])
+    tau_m = (np.float32(1) / (np.float32(1) - alpha)).astype(np.float32)
+    tau_s = (np.float32(1) / (np.float32(1) - alphas)).astype(np.float32)
+    bc = lambda a: np.ascontiguousarray(np.broadcast_to(a[:, None, None], (cin,) + hw)).astype(np.float32)
+    K = cout * H * (Wd // 2)
+    sd = {"i2h.weight": W, "i2h.bias": b, "i2h.alpha": bc(alpha), "i2h.tau_m__dt": bc(tau_m), "i2h.alphas": bc(alphas),
+          "i2h.tau_s__dt": bc(tau_s), "i2o.weight": np.zeros((24, K), np.float32), "i2o.bias": np.zeros(24, np.float32)}
+    e0 = rng.uniform(0, 5, size=(B, 1, H, Wd)).astype(np.float32)
+    e1 = rng.uniform(0, 50, size=(B, 1, H, Wd)).astype(np.float32)
+    ar = -rng.uniform(0, 2, size=(B, cout, H, Wd)).astype(np.float32)
+    cells = rng.randint(0, H * Wd, size=(T, B)).astype(np.int32)
+    eps0, eps1, arp = cu(e0, dev), cu(e1, dev), cu(ar, dev)
+    d = ops.make_conv_desc(cin, cout, hw, (1, 3), (0, 1), (1, 2), 24, False, True, wrp)
+    tau4 = cu(np.stack([alpha, tau_m, alphas, tau_s]), dev)
+    dW, db, dcells = cu(W, dev), cu(b, dev), cu(cells, dev)
+    with ops.kernel_trace() as launched:
+        spk, pv, v = ops.conv_lif_sequence_cells(d, dcells, dW, db, tau4, eps0, eps1, arp, T, B, want_spikes=True, want_v=True)
+    torch.cuda.synchronize()
+    assert launched.names == ["k_lif_seq_w3f", "k_w3f_traces_advance"], launched.names
+    # every sample == the same sample in a pair of its own (all waves co-resident: what the small oracle tests cover)
+    de0, de1, dar = cu(e0, dev), cu(e1, dev), cu(ar, dev)
+    bad = []
+    for k in range(0, B, 2):
+        q0, q1, q2 = de0[k:k + 2].clone(), de1[k:k + 2].clone(), dar[k:k + 2].clone()
+        _, _, vk = ops.conv_lif_sequence_cells(d, dcells[:, k:k + 2].contiguous(), dW, db, tau4, q0, q1, q2, T, 2,
+                                               want_spikes=True, want_v=True)
+        if not (torch.equal(vk, v[:, k:k + 2]) and torch.equal(q0, eps0[k:k + 2]) and torch.equal(q1, eps1[k:k + 2]) and
+                torch.equal(q2, arp[k:k + 2])):
+            bad.append(k)
+    assert not bad, "%d sample pairs differ from their co-resident run, first %s" % (len(bad), bad[:8])
+    pick = np.array([0, 1, 255, 256, 511, 1023, 1024, 1500, 2046, 2047])
+    orc = C.OracleConvLayer(sd, hw, (0, 1), (1, 2), wrp)
+    orc.init_state(len(pick))
+    orc.state[0][...], orc.state[1][...], orc.state[2][...] = e0[pick], e1[pick], ar[pick]
+    idx = torch.from_numpy(pick).to(dev)
+    v_p = v[:, idx].cpu().numpy()
+    spk_p = ops.unpack_spikes(spk[:, idx].contiguous()).cpu().numpy().reshape(T, len(pick), cout, H, Wd // 2)
+    for t in range(T):
+        x = np.zeros((len(pick), 1, H * Wd), np.float32)
+        x[np.arange(len(pick)), 0, cells[t, pick]] = 1
+        oo, op, opv, ov, os_ = orc.forward(x.reshape(len(pick), 1, H, Wd))
+        assert bits_equal(v_p[t], ov), (t, np.argwhere(v_p[t] != ov)[:5])
+        assert np.array_equal(spk_p[t], os_), (t, np.argwhere(spk_p[t] != os_)[:5])
+    g0, g1 = eps0.cpu().numpy(), eps1.cpu().numpy()
+    assert bits_equal(g0[pick], orc.state[0]) and bits_equal(g1[pick], orc.state[1])
+    assert bits_equal(arp[idx].cpu().numpy(), orc.state[2])
+    # every sample's final traces: the pinned recurrence, each operation rounded to fp32 (dcll/pytorch_libdcll.py:493-494)
+    w0, w1 = e0.reshape(B, -1).copy(), e1.reshape(B, -1).copy()
+    for t in range(T):
+        x = np.zeros_like(w0)
+        x[np.arange(B), cells[t]] = 1
+        w0 = x * tau_s[0] + alphas[0] * w0
+        w1 = alpha[0] * w1 + w0 * tau_m[0]
+    assert w0.dtype == np.float32 and bits_equal(g0.reshape(B, -1), w0) and bits_equal(g1.reshape(B, -1), w1)
 
 
 @pytest.mark.parametrize("case", ["radio_l1", "radio_l2_out", "radio_norp", "scalar_tau", "mnist_l2", "ref_tuple", "pool3"])
