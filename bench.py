@@ -652,23 +652,8 @@ def main():
         # collective (allreduce_ms_per_step), or the host (wall >> device_busy on every rank)
         ar_ms = float(np.sum([s_.elapsed_time(e_) for s_, e_ in prof.get("allreduce", [])])) / max(1, a.steps)
         busy_ms = float(np.sum([s_.elapsed_time(e_) for k_, v_ in prof.items() if k_ != "allreduce" for s_, e_ in v_])) / max(1, a.steps)
-        own = 1e3 * dt / a.steps
-        tmax = torch.tensor([dt, dt_up, -own, own, -ar_ms, ar_ms, -busy_ms, busy_ms], device=dev, dtype=torch.float64)
-        parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
-        dt, dt_up = float(tmax[0].item()), float(tmax[1].item())
-        multi = {"per_rank_ms_per_step": {"min": -float(tmax[2]), "max": float(tmax[3]), "this_rank0": own},
-                 "allreduce_ms_per_step": {"min": -float(tmax[4]), "max": float(tmax[5]),
-                                           "what": "HIP events around the tally all-reduce (the step's only collective), per step"},
-                 "device_busy_ms_per_step": {"min": -float(tmax[6]), "max": float(tmax[7]),
-                                             "what": "sum of the HIP-event times of a rank's layer kernels, readouts and votes per step"},
-                 "ranks_seen": dist.get_world_size(), "backend": dist.get_backend()}
-        try:
-            ids = [None] * dist.get_world_size()
-            dist.all_gather_object(ids, "%s/cuda:%d/%s" % (os.uname().nodename, dev.index, parallel.device_identity(dev.index)))
-            multi["rank_devices"] = ids
-            multi["distinct_devices"] = len(set(ids))
-        except Exception as e:                      # noqa: BLE001  (diagnostics must never cost the line)
-            multi["rank_devices"] = "%s: %s" % (type(e).__name__, e)
+        dt, dt_up, multi = parallel.job_timing(dt, dt_up, ar_ms, busy_ms, a.steps, dev, "%s/cuda:%d/%s" % (
+            os.uname().nodename, dev.index, parallel.device_identity(dev.index)))
     log("upload-inclusive region done: %.3f s for %d steps" % (dt_up, a.steps))
 
     # dominant kernel: HIP-event time of every k_lif_seq_c32d launch of the timed region (same stream as the launch)

@@ -184,6 +184,35 @@ def barrier():
         dist.barrier()
 
 
+def job_timing(dt, dt_up, allreduce_ms, busy_ms, steps, device, device_label):
+    """The timing part of a multi-rank bench line (bench.py; contract: the job's time is the MAX over the ranks' clocks).
+    dt / dt_up: this rank's wall time of the K timed steps (device-resident / upload-inclusive), allreduce_ms / busy_ms:
+    its per-step HIP-event time of the tally all-reduce / of its kernels.  -> (dt, dt_up, report): the maxima over the ranks
+    and a dict with the min / max of every rank's own figures — a scaling loss can then be put on a straggler rank (per-rank
+    spread), on the collective, or on the host (wall >> device busy on every rank) — the ranks seen, the backend, and what is
+    behind every rank's device.  ONE fp64 MAX all-reduce (minima travel negated) + one all_gather_object; `device` is where
+    the reduced vector lives (the rank's GPU under RCCL; the CPU in the gloo rehearsals of tests/test_parallel_gloo.py)."""
+    own = 1e3 * dt / max(1, steps)
+    vec = torch.tensor([dt, dt_up, -own, own, -allreduce_ms, allreduce_ms, -busy_ms, busy_ms], device=device,
+                       dtype=torch.float64)
+    all_reduce_(vec, op=dist.ReduceOp.MAX)
+    vec = vec.cpu()
+    rep = {"per_rank_ms_per_step": {"min": -float(vec[2]), "max": float(vec[3]), "this_rank0": own},
+           "allreduce_ms_per_step": {"min": -float(vec[4]), "max": float(vec[5]),
+                                     "what": "HIP events around the tally all-reduce (the step's only collective), per step"},
+           "device_busy_ms_per_step": {"min": -float(vec[6]), "max": float(vec[7]),
+                                       "what": "sum of the HIP-event times of a rank's layer kernels, readouts and votes per step"},
+           "ranks_seen": dist.get_world_size(), "backend": dist.get_backend()}
+    try:
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, device_label)
+        rep["rank_devices"] = ids
+        rep["distinct_devices"] = len(set(ids))
+    except Exception as e:                      # noqa: BLE001  (diagnostics must never cost the line)
+        rep["rank_devices"] = "%s: %s" % (type(e).__name__, e)
+    return float(vec[0]), float(vec[1]), rep
+
+
 def shard_range(total, rank, world):
     """Contiguous, balanced [start, stop) of `total` samples for `rank` (first total % world ranks get one more)."""
     base, extra = divmod(total, world)

@@ -143,6 +143,70 @@ def test_bench_strong_scaling_flag_fixes_the_global_batch():
     assert len(m["rank_devices"]) == 4 and m["distinct_devices"] == 1         # the rehearsal: four ranks, one GPU
 
 
+def _no_process_carries(mark):
+    """No live process of ours still has DCLL_TEST_MARK=<mark> in its environment (the ranks and their launcher are gone)."""
+    left = []
+    for pid in os.listdir("/proc"):
+        if not pid.isdigit() or int(pid) == os.getpid():
+            continue
+        try:
+            with open("/proc/%s/environ" % pid, "rb") as f:
+                if ("DCLL_TEST_MARK=%s" % mark).encode() in f.read():
+                    left.append(int(pid))
+        except OSError:
+            continue
+    return left
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_the_drivers_torchrun_command():
+    """The driver's multi-GPU command, verbatim — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — rehearsed on the one GPU with N = 4 (the box admits six
+    processes on the card: four ranks + this test; the EIGHT-rank form of the same command runs on CPU in
+    tests/test_parallel_gloo.py::test_eight_ranks_under_the_drivers_exact_command_on_cpu), DCLL_DIST_BACKEND=gloo:
+      * the default (weak-scaling) line: one JSON line on stdout, n_gpus 4, all four ranks seen on ONE distinct device and the
+        line says REHEARSAL, `roofline` from rank 0's kernel events, every N = 1-only extra absent, exit code 0, no rank or
+        launcher process left behind;
+      * north_star's literal "batch 4096 ... at 1/2/4/8 GPUs": `--global-batch 4096` over the four ranks (1 024 windows each)
+        -> the all-reduced tallies equal the single-process run's digest."""
+    import uuid
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    bench = os.path.join(ROOT, "bench.py")
+    quiet = ["--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--live-traffic", "0", "--batch-sweep", "0",
+             "--trained", "0", "--t1024", "0"]
+
+    def torchrun(n, extra):
+        mark = uuid.uuid4().hex
+        env = dict(base, DCLL_DIST_BACKEND="gloo", DCLL_TEST_MARK=mark, OMP_NUM_THREADS="2")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), bench, "--gpus", str(n)] + extra,
+                           env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(out) == 1, r.stdout
+        assert _no_process_carries(mark) == []
+        return json.loads(out[0])
+    line = torchrun(4, ["--steps", "1", "--warmup", "0", "--batch", "64", "--live-traffic", "0"])
+    m = line["multi_gpu"]
+    assert line["n_gpus"] == 4 and line["steps"] == 1 and line["warmup"] == 0 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 256 and line["config"]["batch_per_gpu"] == 64
+    assert m["ranks_seen"] == 4 and m["backend"] == "gloo" and m["distinct_devices"] == 1 and len(m["rank_devices"]) == 4
+    assert "REHEARSAL" in line["config"]["parallelism"]
+    assert line["value"] > 0 and abs(line["value"] - 256 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    roof = line["roofline"]
+    assert roof["kernel"] == "k_lif_seq_c32d" and roof["launches"] == 2 and 0 < roof["frac"] < 1.2 and roof["avg_launch_ms"] > 0
+    for extra in ("cpu_baseline", "speedup_vs_cpu_baseline", "per_step_paths", "config5", "t1024", "batch_sweep", "trained_top1"):
+        assert extra not in line, extra
+    four = torchrun(4, ["--steps", "1", "--warmup", "0", "--global-batch", "4096"] + quiet)
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "1", "--warmup", "0", "--global-batch", "4096"] + quiet,
+                       env=base, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert four["scaling"] == "strong" and four["config"]["batch_per_gpu"] == 1024 and four["config"]["global_batch"] == 4096
+    assert four["tallies"] == one["tallies"] and [ct[1] for ct in four["tallies"]["correct_total"]] == [4096] * 3
+
+
 @pytest.mark.timeout(900)
 def test_entry_points_shard_over_ranks(tmp_path):
     """`test_radio_ml.py --gpus 2` and `train.py --gpus 2` started plainly: each launches two ranks (sharing cuda:0 here,

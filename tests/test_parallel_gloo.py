@@ -233,6 +233,88 @@ def test_launcher_starts_ranks_and_relays_rank0(tmp_path):
     assert r.returncode == 7
 
 
+_DRIVER_FORM = '''
+"""The rank logic of bench.py with the device work replaced by fixed numbers: what an 8-rank job does on the HOST side."""
+import argparse, hashlib, json, os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from snn_modulation_classification_amd import parallel
+ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--global-batch", type=int, default=4096)
+a = ap.parse_args()
+if a.gpus > 1 and not parallel.under_launcher():
+    sys.exit(parallel.spawn_local_ranks(a.gpus))
+rank, local_rank, world = parallel.init_process_group(backend="gloo")
+assert world == a.gpus, (world, a.gpus)
+lo, hi = parallel.shard_range(a.global_batch, rank, world)
+g = torch.Generator().manual_seed(1)
+votes = [torch.randint(0, 24, (a.global_batch,), generator=g).to(torch.int32) for _ in range(3)]
+labels = torch.randint(0, 24, (a.global_batch,), generator=g)
+tal = parallel.allreduce_tallies(parallel.tallies([v[lo:hi] for v in votes], labels[lo:hi], 24))
+cm, acc = parallel.split_tallies(tal, 24)
+parallel.barrier()
+dt = 0.010 * (rank + 1) * a.steps
+multi = None
+if parallel.is_distributed():
+    dt, dt_up, multi = parallel.job_timing(dt, 2 * dt, 0.1 * (rank + 1), 1.0 * (rank + 1), a.steps, "cpu", "host/cpu/%%d" %% (rank %% 4))
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+                      "value": a.global_batch * a.steps / dt, "shard": [lo, hi], "multi_gpu": multi,
+                      "tallies": {"correct_total": [[int(v) for v in row] for row in tal[:, -2:]],
+                                  "confusion_sha1": hashlib.sha1(cm.numpy().astype(np.int64).tobytes()).hexdigest()}}))
+parallel.barrier()
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_under_the_drivers_exact_command_on_cpu(tmp_path):
+    """The driver's multi-GPU command, verbatim — `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr
+    127.0.0.1 --master-port P <script> --gpus 8 --steps K --warmup W` — with EIGHT ranks, on CPU over gloo (eight ranks may not
+    share the one GPU of a test box: at most six processes on the card).  The script is bench.py's rank logic with the device
+    work replaced by fixed numbers: the torchrun environment is picked up (no second launcher), 4096 windows shard into
+    8 x 512, the all-reduced tallies equal the single-process tallies, the job's time is the MAX over the ranks' clocks, the
+    per-rank spread / ranks seen / distinct devices arrive in the line, ONE JSON line leaves on stdout, exit code 0.  The
+    same script started plainly (`--gpus 8`) launches its own eight ranks and prints the same line."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "job.py"
+    script.write_text(_DRIVER_FORM % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["OMP_NUM_THREADS"] = "1"
+    single = subprocess.run([sys.executable, str(script), "--gpus", "1", "--steps", "3", "--warmup", "1"], capture_output=True,
+                            text=True, env=env, timeout=200)
+    assert single.returncode == 0, single.stderr[-2000:]
+    one = json.loads(single.stdout.strip().splitlines()[-1])
+    lines = {}
+    for form, cmd in (("torchrun", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                                    "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script),
+                                    "--gpus", "8", "--steps", "3", "--warmup", "1"]),
+                      ("plain", [sys.executable, str(script), "--gpus", "8", "--steps", "3", "--warmup", "1"])):
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=400)
+        assert r.returncode == 0, (form, r.stderr[-3000:])
+        out = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(out) == 1, (form, r.stdout)
+        lines[form] = json.loads(out[0])
+    for form, line in lines.items():
+        m = line["multi_gpu"]
+        assert line["n_gpus"] == 8 and m["ranks_seen"] == 8 and m["backend"] == "gloo", form
+        assert line["shard"] == [0, 512]
+        assert line["tallies"] == one["tallies"] and [ct[1] for ct in line["tallies"]["correct_total"]] == [4096] * 3
+        assert abs(line["ms_per_step"] - 80.0) < 1e-9                     # the slowest rank's clock
+        assert abs(m["per_rank_ms_per_step"]["min"] - 10.0) < 1e-9 and abs(m["per_rank_ms_per_step"]["max"] - 80.0) < 1e-9
+        assert abs(m["allreduce_ms_per_step"]["min"] - 0.1) < 1e-12 and abs(m["allreduce_ms_per_step"]["max"] - 0.8) < 1e-12
+        assert abs(m["device_busy_ms_per_step"]["max"] - 8.0) < 1e-12
+        assert len(m["rank_devices"]) == 8 and m["distinct_devices"] == 4
+    assert one["multi_gpu"] is None and one["n_gpus"] == 1 and one["shard"] == [0, 4096]
+
+
 def test_visible_gpu_count_agrees_with_torch_and_honours_visible_devices(monkeypatch):
     """The launcher's runtime-free GPU count (DRM render nodes; torch's query only where there is no /dev/dri) equals what
     torch reports in this process, and *_VISIBLE_DEVICES narrows it."""
