@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCLL_ABI_VERSION 6
+#define DCLL_ABI_VERSION 7
 
 enum {
     DCLL_OK = 0,
@@ -258,6 +258,24 @@ int dcll_dense_lif_step(const dcll_dense_desc *d, const float *x, const float *W
                         const float *alpha, const float *tau_m, const float *alphas, const float *tau_s,
                         float *eps0, float *eps1, float *arp, const float *i2o_W, const float *i2o_b,
                         float *out_s, float *out_p, float *out_pv, float *out_v, int32_t B, void *stream);
+
+/*
+ * Backward of one DenseDCLLlayer step for local learning (ABI 7) — DCLLBase.train_dcll (:690-718) is layer-agnostic: it builds
+ * the optimizer from dclllayer.i2h.parameters() (:634-635) and DenseDCLLlayer.forward keeps pvoutput in the graph (:250-255).
+ *   dv = (g_p . i2o_W + g_pv) * pv * (1 - pv) + g_v ;  dW (out,in) = dv^T . eps1 ;  db (out) = sum_b dv
+ * eps1 (B,in): the layer's eps1 state AFTER the step; pv (B,out) = sigmoid(v) as the step returned it; g_p (B,target), g_pv,
+ * g_v (B,out): gradients of the loss w.r.t. pvoutput / pv / pvmem, each may be NULL (g_p needs i2o_W (target,out)).
+ * scratch: scratch_floats >= B*out + k*out*(in+1), k >= 1 batch chunks (up to 64 are used).  The _open form leaves the last
+ * reduction to dcll_grad_reduce_adam (rowlen = in + 1, c_out = out): *part / *nchunk as dcll_conv_lif_backward_open.
+ * Sums run in a fixed order (an fp32-MFMA GEMM over sample pairs per chunk, chunks ascending): deterministic, and the closed
+ * form is the open form + dcll_grad_reduce_adam without tensors — the same bits.
+ */
+int dcll_dense_lif_backward(const dcll_dense_desc *d, const float *eps1, const float *pv, const float *g_p,
+                            const float *g_pv, const float *g_v, const float *i2o_W, float *dW, float *db,
+                            float *scratch, int64_t scratch_floats, int32_t B, void *stream);
+int dcll_dense_lif_backward_open(const dcll_dense_desc *d, const float *eps1, const float *pv, const float *g_p,
+                                 const float *g_pv, const float *g_v, const float *i2o_W, float *scratch,
+                                 int64_t scratch_floats, int32_t B, const float **part, int32_t *nchunk, void *stream);
 
 /*
  * All T timesteps of a DenseDCLLlayer in one call — `for t: layer.forward(x[t])` (:250-255) — the dense twin of

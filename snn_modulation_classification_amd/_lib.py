@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("DCLL_HIP_SO") or os.path.join(_PKG, "libdcll_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 DCLL_OK, DCLL_ERR_INVALID, DCLL_ERR_UNSUPPORTED, DCLL_ERR_LAUNCH = 0, -1, -2, -3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class DCLLHipError(RuntimeError):
@@ -118,6 +118,8 @@ SIGNATURES = {
     "dcll_cells_to_planes": (_I32, [_P, _P, _I64, _I32, _P]),
     "dcll_dense_lif_step": (_I32, [_DDP] + [_P] * 16 + [_I32, _P]),
     "dcll_dense_lif_sequence": (_I32, [_DDP] + [_P] * 16 + [_I32, _I32, _P]),
+    "dcll_dense_lif_backward": (_I32, [_DDP] + [_P] * 9 + [_I64, _I32, _P]),
+    "dcll_dense_lif_backward_open": (_I32, [_DDP] + [_P] * 7 + [_I64, _I32, ctypes.POINTER(ctypes.c_void_p), _IP, _P]),
     "dcll_conv_lif_sequence": (_I32, [_DP] + [_P] * 13 + [_I32, _P, _P, _I32, _OP, _I32, _I32, _P]),
     "dcll_permute_readout": (_I32, [_P, _P, _I32, _P]),
     "dcll_conv_lif_sequence_cells": (_I32, [_DP] + [_P] * 10 + [_P, _P, _I32, _OP, _I32, _I32, _P]),

@@ -494,6 +494,148 @@ extern "C" int dcll_grad_reduce_adam(const dcll_grad_parts *layers, int32_t n_la
     return DCLL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Local learning on a DENSE slice (round 6): the backward of one DenseDCLLlayer step (dcll/pytorch_libdcll.py:250-255 under
+// DCLLBase.train_dcll :690-718 — the optimizer is built from dclllayer.i2h.parameters() whatever the layer type, :634-635).
+//   dv[b,o] = (sum_n g_p[b,n] * i2o_W[n,o] + g_pv[b,o]) * pv[b,o] * (1 - pv[b,o]) + g_v[b,o]     pv = sigmoid(v): sigmoid'
+//   dW[o,k] = sum_b dv[b,o] * eps1[b,k]        db[o] = sum_b dv[b,o]
+// (i2o is frozen, the spikes and the neuron state are detached: nothing else carries a gradient.)
+// k_dense_bwd_dv: one thread per (b, o), the readout rows ascending (fmaf).
+// k_dense_bwd_wgrad: an fp32-MFMA GEMM dv^T x [eps1 | 1] over a batch chunk per workgroup: v_mfma_f32_32x32x2_f32 with the
+//   two k lanes on a SAMPLE pair, A = dv (lane = output neuron), B = eps1 (lane = input feature; the column `in` is the
+//   constant 1: the bias gradient is one more column of the same product) — both operands are 32 consecutive floats of a
+//   row per half-wave, straight from global memory (L2-resident: a chunk's dv rows are re-read by every feature tile).
+//   Partial rows part[chunk][o][in + 1] in dcll_grad_parts' layout: dcll_grad_reduce_adam finishes them (fixed chunk order)
+//   together with the optimizer step, like the conv layers' — or alone, for the closed form.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_bwd_dv(int out, int target, const float *__restrict__ pv,
+                                                       const float *__restrict__ g_p, const float *__restrict__ g_pv,
+                                                       const float *__restrict__ g_v, const float *__restrict__ i2o_W,
+                                                       float *__restrict__ dv, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long b = i / out;
+    const int o = (int)(i - b * out);
+    float g = g_pv ? g_pv[i] : 0.0f;
+    if (g_p)
+        for (int r = 0; r < target; ++r) g = __builtin_fmaf(g_p[b * target + r], i2o_W[(long)r * out + o], g);
+    const float s = pv[i];
+    float d = g * (s * (1.0f - s));
+    if (g_v) d += g_v[i];
+    dv[i] = d;
+}
+
+constexpr int DW_NT = 4;        // feature tiles (32 columns each) per wave: one A fragment feeds four MFMAs
+__global__ __launch_bounds__(256) void k_dense_bwd_wgrad(int in, int out, const float *__restrict__ dv,
+                                                          const float *__restrict__ eps1, float *__restrict__ part, int B,
+                                                          int per_chunk)
+{
+    const int lane = threadIdx.x & 63, jj = lane & 31, kk = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rowlen = in + 1;
+    const int o0 = blockIdx.y * 32;
+    const int c0 = (blockIdx.x * 4 + w) * (32 * DW_NT);                 // first column of this wave's tiles
+    if (c0 >= rowlen) return;                                           // (whole waves; the kernel has no barrier)
+    const int chunk = blockIdx.z;
+    const int b0 = chunk * per_chunk, b1 = min(B, b0 + per_chunk);
+    f32x16 acc[DW_NT];
+#pragma unroll
+    for (int t = 0; t < DW_NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const bool ook = o0 + jj < out;
+    int col[DW_NT];
+#pragma unroll
+    for (int t = 0; t < DW_NT; ++t) col[t] = c0 + 32 * t + jj;
+    for (int b = b0; b < b1; b += 2) {
+        const int bb = b + kk;
+        const bool bok = bb < b1;
+        const float a = (bok && ook) ? dv[(long)bb * out + o0 + jj] : 0.0f;
+        float e[DW_NT];
+#pragma unroll
+        for (int t = 0; t < DW_NT; ++t)
+            e[t] = !bok ? 0.0f : col[t] < in ? eps1[(long)bb * in + col[t]] : col[t] == in ? 1.0f : 0.0f;
+#pragma unroll
+        for (int t = 0; t < DW_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, e[t], acc[t], 0, 0, 0);
+    }
+    // accumulator register r of lane l: row (r & 3) + 8 (r >> 2) + 4 (l >> 5) = output neuron, column l & 31 = feature
+    float *prow = part + (long)chunk * out * rowlen;
+#pragma unroll
+    for (int t = 0; t < DW_NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (o < out && col[t] < rowlen) prow[(long)o * rowlen + col[t]] = acc[t][r];
+        }
+}
+
+static int dense_backward_impl(const dcll_dense_desc *d, const float *eps1, const float *pv, const float *g_p,
+                               const float *g_pv, const float *g_v, const float *i2o_W, float *scratch,
+                               int64_t scratch_floats, int32_t B, hipStream_t st, dcll_grad_parts *P, const char *who)
+{
+    if (!d || d->in_features < 1 || d->out_features < 1) return fail(DCLL_ERR_INVALID, "bad descriptor", who);
+    if (!eps1 || !pv || !scratch) return fail(DCLL_ERR_INVALID, "null pointer", who);
+    if (g_p && (!i2o_W || d->target < 1)) return fail(DCLL_ERR_INVALID, "g_p needs i2o_W and target >= 1", who);
+    if (B < 1) return fail(DCLL_ERR_INVALID, "empty batch", who);
+    const int in = d->in_features, out = d->out_features;
+    const long ndv = (long)B * out, per_row = (long)out * (in + 1);
+    long nchunk = (scratch_floats - ndv) / per_row;
+    if (nchunk < 1) return fail(DCLL_ERR_INVALID, "scratch too small (need B*out + k*out*(in+1) floats, k >= 1)", who);
+    // chunks of an even number of samples (an MFMA k-step is a sample pair); enough of them to fill the chip with the tile grid
+    const long tiles = (long)((in + 1 + 4 * 32 * DW_NT - 1) / (4 * 32 * DW_NT)) * ((out + 31) / 32);
+    long want = (1024 + tiles - 1) / tiles;
+    if (want > 64) want = 64;
+    if (nchunk > want) nchunk = want;
+    long per = (B + nchunk - 1) / nchunk;
+    per += per & 1;
+    nchunk = (B + per - 1) / per;
+    hipLaunchKernelGGL(k_dense_bwd_dv, dim3((unsigned)((ndv + 255) / 256)), dim3(256), 0, st, out, g_p ? d->target : 0, pv, g_p, g_pv, g_v, i2o_W,
+                       scratch, ndv);
+    HIP_CHECK_LAUNCH("k_dense_bwd_dv");
+    float *part = scratch + ndv;
+    hipLaunchKernelGGL(k_dense_bwd_wgrad, dim3((unsigned)((in + 1 + 4 * 32 * DW_NT - 1) / (4 * 32 * DW_NT)), (unsigned)((out + 31) / 32),
+                                               (unsigned)nchunk), dim3(256), 0, st, in, out, scratch, eps1, part, B, (int)per);
+    HIP_CHECK_LAUNCH("k_dense_bwd_wgrad");
+    P->part = part;
+    P->rowlen = in + 1;
+    P->nchunk = (int32_t)nchunk;
+    P->c_out = out;
+    return DCLL_OK;
+}
+
+extern "C" int dcll_dense_lif_backward(const dcll_dense_desc *d, const float *eps1, const float *pv, const float *g_p,
+                                       const float *g_pv, const float *g_v, const float *i2o_W, float *dW, float *db,
+                                       float *scratch, int64_t scratch_floats, int32_t B, void *stream)
+{
+    const char *who = "dcll_dense_lif_backward";
+    if (!dW) return fail(DCLL_ERR_INVALID, "null dW", who);
+    dcll_grad_parts P;
+    memset(&P, 0, sizeof(P));
+    int rc = dense_backward_impl(d, eps1, pv, g_p, g_pv, g_v, i2o_W, scratch, scratch_floats, B, (hipStream_t)stream, &P, who);
+    if (rc) return rc;
+    P.dW = dW;
+    P.db = db;
+    P.adam_w = P.adam_b = -1;
+    return dcll_grad_reduce_adam(&P, 1, nullptr, 0, nullptr, stream);          // the closed form: reduce only
+}
+
+extern "C" int dcll_dense_lif_backward_open(const dcll_dense_desc *d, const float *eps1, const float *pv, const float *g_p,
+                                            const float *g_pv, const float *g_v, const float *i2o_W, float *scratch,
+                                            int64_t scratch_floats, int32_t B, const float **part, int32_t *nchunk,
+                                            void *stream)
+{
+    const char *who = "dcll_dense_lif_backward_open";
+    if (!part || !nchunk) return fail(DCLL_ERR_INVALID, "null part / nchunk", who);
+    dcll_grad_parts P;
+    memset(&P, 0, sizeof(P));
+    int rc = dense_backward_impl(d, eps1, pv, g_p, g_pv, g_v, i2o_W, scratch, scratch_floats, B, (hipStream_t)stream, &P, who);
+    if (rc) return rc;
+    *part = P.part;
+    *nchunk = P.nchunk;
+    return DCLL_OK;
+}
+
 // planes[t][b][:] = 0 except planes[t][b][cells[t][b]] = 1      (one thread per output float4; hw % 4 == 0)
 __global__ __launch_bounds__(256) void k_cells_to_planes(const int32_t *__restrict__ cells, float *__restrict__ planes,
                                                           long n_samples, int hw)

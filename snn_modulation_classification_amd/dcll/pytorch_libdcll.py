@@ -656,6 +656,10 @@ class CLLDenseModule(nn.Module):
         dev = self.weight.device
         self._set_tau(torch.Tensor(1 - 1e-3 / taum).to(dev), torch.Tensor(1 - 1e-3 / taus).to(dev))
 
+    def make_desc(self, i2o=None):
+        return DenseDesc(self.in_channels, self.out_channels, 0 if i2o is None else i2o.weight.shape[0],
+                         int(self.alpha.numel() > 1), int(self.wrp > 0), float(self.alpharp), float(self.wrp))
+
     def _step(self, input, i2o=None):
         if not self.spiking:
             raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
@@ -664,8 +668,7 @@ class CLLDenseModule(nn.Module):
             logger.warning("Batch size changed from {} to {} since last iteration. Reallocating states."
                            .format(old, input.shape[0]))
             self.init_state(input.shape[0])
-        desc = DenseDesc(self.in_channels, self.out_channels, 0 if i2o is None else i2o.weight.shape[0],
-                         int(self.alpha.numel() > 1), int(self.wrp > 0), float(self.alpharp), float(self.wrp))
+        desc = self.make_desc(i2o)
         st = self.state
         with torch.no_grad():
             return ops.dense_lif_step(desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas,
@@ -696,6 +699,28 @@ class CLLDenseRRPModule(CLLDenseModule):
         if not self.spiking:
             raise Exception('Refractory not allowed in non-spiking mode')
         return super().forward(input)
+
+
+class _DenseLIFStepFn(torch.autograd.Function):
+    """One DenseDCLLlayer step as an autograd node: forward = dcll_dense_lif_step, backward = dcll_dense_lif_backward.
+    Gradients reach i2h.weight / i2h.bias via pvoutput, pv and pvmem; i2o is frozen, spikes and the neuron state carry no
+    gradient — the graph the reference builds with eager ops (:131-148 / :171-195, :250-255)."""
+
+    @staticmethod
+    def forward(ctx, layer, x, W, b):
+        i2h = layer.i2h
+        s, p, pv, v = i2h._step(x, layer.i2o)
+        ctx.layer = layer
+        ctx.desc = i2h.make_desc(layer.i2o)
+        ctx.eps1 = i2h.state.eps1.clone()          # (the state buffers are updated in place by the next step)
+        ctx.pv = pv
+        ctx.mark_non_differentiable(s)
+        return s, p, pv, v
+
+    @staticmethod
+    def backward(ctx, gs, gp, gpv, gv):
+        dW, db = ops.dense_lif_backward(ctx.desc, ctx.eps1, ctx.pv, gp, gpv, gv, ctx.layer.i2o.weight)
+        return None, None, dW, (db if ctx.layer.i2h.bias is not None else None)
 
 
 class DenseDCLLlayer(nn.Module):
@@ -731,7 +756,12 @@ class DenseDCLLlayer(nn.Module):
 
     def forward(self, input):
         """-> (output spikes, pvoutput, pv, pvmem)  (reference :250-255)."""
-        s, p, pv, v = self.i2h._step(input.reshape(-1, self.in_channels), self.i2o)
+        x = input.reshape(-1, self.in_channels)
+        if getattr(self, 'build_graph', False) and torch.is_grad_enabled():
+            # local-learning step: same kernel, wrapped in an autograd node (see _DenseLIFStepFn)
+            s, p, pv, v = _DenseLIFStepFn.apply(self, x, self.i2h.weight, self.i2h.bias)
+        else:
+            s, p, pv, v = self.i2h._step(x, self.i2o)
         return s, (p if self.dropout is None else self.dropout(p)), pv, v
 
     def forward_sequence(self, x_seq, want_v=False):
@@ -860,19 +890,23 @@ class DCLLBase(nn.Module):
         """The loss kind (ops.LOSS_KINDS) if this slice's learning step runs without torch ops — forward, loss gradient,
         backward and Adam as C-ABI calls — else None (then train_dcll builds the autograd graph around the same HIP
         forward / backward).  Served: Conv2dDCLLlayer; crit = SmoothL1Loss (beta 1) or MSELoss with mean reduction;
-        optimizer(s) = torch.optim.Adam without amsgrad / maximize / capturable / fused; DCLL_NATIVE_LEARNING != 0."""
+        optimizer(s) = torch.optim.Adam without amsgrad / maximize / capturable / fused; DCLL_NATIVE_LEARNING != 0.
+        A DenseDCLLlayer slice (with a bias) is served the same way (_learn_dense)."""
         cached = getattr(self, '_native_kind', _UNSET)      # (0 is a loss kind: SmoothL1Loss)
         if cached is not _UNSET:
             return cached
         kind = None
         crit, opt = getattr(self, 'crit', None), getattr(self, 'optimizer', None)
-        ok = (os.environ.get('DCLL_NATIVE_LEARNING', '1') != '0' and isinstance(self.dclllayer, Conv2dDCLLlayer) and
+        ok = (os.environ.get('DCLL_NATIVE_LEARNING', '1') != '0' and
+              isinstance(self.dclllayer, (Conv2dDCLLlayer, DenseDCLLlayer)) and
               crit is not None and opt is not None and getattr(crit, 'reduction', None) == 'mean' and
               self.dclllayer.dropout is None)               # (lc_dropout: torch's mask and its gradient, autograd path)
         if ok and type(crit) is nn.SmoothL1Loss and getattr(crit, 'beta', 1.0) == 1.0:
             kind = ops.LOSS_KINDS['SmoothL1Loss']
         elif ok and type(crit) is nn.MSELoss:
             kind = ops.LOSS_KINDS['MSELoss']
+        if kind is not None and isinstance(self.dclllayer, DenseDCLLlayer) and self.dclllayer.i2h.bias is None:
+            kind = None
         if kind is not None and self.dclllayer.output_layer:
             if type(self.output_crit) is not type(crit) or getattr(self.output_crit, 'reduction', None) != 'mean':
                 kind = None
@@ -929,6 +963,33 @@ class DCLLBase(nn.Module):
                 self.activity_hist.append((ops.pv_lowhigh(pv, 1, self.iter - 1)[0], pv.numel()))
         return dict(out=((o if L.output_layer else s), p, pv, v), fin=fin, learned=learned, rec=rec, input=input,
                     target=target, want_loss=want_loss, clout_out=clout_out, p=p, o=o, pv=pv, v=v)
+
+    def _learn_dense(self, input, target):
+        """_learn_forward_backward for a DenseDCLLlayer slice: dcll_dense_lif_step -> dcll_local_loss_grad ->
+        dcll_dense_lif_backward into the .grad of i2h.weight / i2h.bias.  No optimizer step.
+        -> (output, pvoutput, pv, pvmem, loss (1,) device tensor or None, learned)"""
+        L = self.dclllayer
+        i2h = L.i2h
+        bufs = self.__dict__.setdefault('_learn_bufs', {})
+        self.iter += 1
+        with torch.no_grad():
+            learned = self.iter >= self.burnin
+            rec = isinstance(self, DCLLClassification)
+            s, p, pv, v = i2h._step(input.reshape(-1, L.in_channels), L.i2o)
+            if self.collect_stats and (self.iter % 20) == 0:
+                self.activity_hist.append((ops.pv_lowhigh(pv, 1, self.iter - 1)[0], pv.numel()))
+            if not learned:
+                return s, p, pv, v, None, False
+            res = ops.local_loss_grad(p, None, target, self._native_learning(), out=bufs, want_loss=True, want_clout=rec)
+            if rec:
+                self._clout.append(res[3])
+            for q in (i2h.weight, i2h.bias):
+                if q.grad is None:
+                    q.grad = torch.zeros_like(q)
+            gb = bufs.setdefault('grads', {})
+            gb.update(dW=i2h.weight.grad, db=i2h.bias.grad)
+            ops.dense_lif_backward(i2h.make_desc(L.i2o), i2h.state.eps1, pv, res[0], None, None, L.i2o.weight, out=gb)
+        return s, p, pv, v, res[2], True
 
     def _backward_from_pv(self):
         """True if this slice's backward can take sigmoid' from pv: no pooling, <= 32 readout rows (k_bwd_dv_nopool)."""
@@ -1005,7 +1066,7 @@ class DCLLBase(nn.Module):
     def _grad_tensors(self):
         L = self.dclllayer
         prm = [L.i2h.weight, L.i2h.bias] + ([L.output_.weight, L.output_.bias] if L.output_layer else [])
-        return [q.grad for q in prm]
+        return [q.grad for q in prm if q is not None]
 
     def _adam_tensors(self, advance=True):
         """This slice's parameters as dcll_adam_step entries, on the state tensors of its torch optimizer objects (created
@@ -1042,11 +1103,12 @@ class DCLLBase(nn.Module):
         valid until the slice's next step, which overwrites them (the reference returns fresh tensors each step).  A caller
         that collects them over timesteps must .clone() them; ConvNetwork.learn / train.py only chain `output` into the
         next slice within the same step."""
-        if not isinstance(self.dclllayer, Conv2dDCLLlayer):
-            raise NotImplementedError('local learning is implemented for Conv2dDCLLlayer slices')
         from .. import parallel
         if not regularize and self._native_learning() is not None:
-            output, pvoutput, pv, pvmem, loss, learned = self._learn_forward_backward(input, target)
+            if isinstance(self.dclllayer, DenseDCLLlayer):
+                output, pvoutput, pv, pvmem, loss, learned = self._learn_dense(input, target)
+            else:
+                output, pvoutput, pv, pvmem, loss, learned = self._learn_forward_backward(input, target)
             if learned:
                 parallel.allreduce_mean_tensors(self._grad_tensors(), local_n=input.shape[0])
                 if do_train:

@@ -311,6 +311,51 @@ def dense_lif_sequence(desc, x_seq, W, b, alpha, tau_m, alphas, tau_s, eps0, eps
     return s, p, pv, v
 
 
+def dense_lif_backward(desc, eps1, pv, g_p, g_pv, g_v, i2o_W, out=None, open_reduce=False):
+    """Gradients of one DenseDCLLlayer step (dcll_dense_lif_backward) -> (dW (out,in), db (out)).  `out`: optional dict with
+    preallocated 'dW', 'db', 'bwd_scratch' (the learning loop writes into the parameters' .grad).  `open_reduce`:
+    dcll_dense_lif_backward_open — dW / db are not written yet, out['parts'] describes the partial rows for grad_reduce_adam
+    (the same record a conv layer's open backward leaves)."""
+    B = eps1.shape[0]
+    dev = eps1.device
+    out = {} if out is None else out
+    nin, nout = desc.in_features, desc.out_features
+    _expect(eps1, "eps1", torch.float32, (B, nin))
+    _expect(pv, "pv", torch.float32, (B, nout))
+    if g_p is not None:
+        _expect(g_p, "g_p", torch.float32, (B, desc.target))
+        _expect(i2o_W, "i2o_W", torch.float32, (desc.target, nout))
+    for name, t in (("g_pv", g_pv), ("g_v", g_v)):
+        if t is not None:
+            _expect(t, name, torch.float32, (B, nout))
+
+    def buf(key, shape):
+        t = out.get(key)
+        if t is None:
+            t = out[key] = torch.empty(shape, device=dev, dtype=torch.float32)
+        _expect(t, key, torch.float32, shape)
+        return t
+    dW, db = buf('dW', (nout, nin)), buf('db', (nout,))
+    n_scratch = B * nout + min(64, (B + 1) // 2) * nout * (nin + 1)
+    scratch = out.get('bwd_scratch')
+    if scratch is None or scratch.numel() != n_scratch:
+        scratch = out['bwd_scratch'] = torch.empty((n_scratch,), device=dev, dtype=torch.float32)
+    c = lambda t: None if t is None else _f32(t, "grad").contiguous()
+    if open_reduce:
+        part, nchunk = ctypes.c_void_p(), ctypes.c_int32()
+        rc = _lib.get().dcll_dense_lif_backward_open(
+            ctypes.byref(desc), ptr(eps1), ptr(pv.contiguous()), ptr(c(g_p)), ptr(c(g_pv)), ptr(c(g_v)), ptr(i2o_W), ptr(scratch),
+            n_scratch, B, ctypes.byref(part), ctypes.byref(nchunk), stream_ptr())
+        check(rc, "dcll_dense_lif_backward_open")
+        out['parts'] = dict(part=part.value, nchunk=nchunk.value, c_out=nout, rowlen=nin + 1, dW=dW, db=db, keep=scratch)
+        return dW, db
+    rc = _lib.get().dcll_dense_lif_backward(
+        ctypes.byref(desc), ptr(eps1), ptr(pv.contiguous()), ptr(c(g_p)), ptr(c(g_pv)), ptr(c(g_v)), ptr(i2o_W), ptr(dW), ptr(db),
+        ptr(scratch), n_scratch, B, stream_ptr())
+    check(rc, "dcll_dense_lif_backward")
+    return dW, db
+
+
 def permute_readout(Wt):
     """(N, 8192) readout matrix -> the fused epilogue's layout (dcll_permute_readout)."""
     Wt = Wt.contiguous()

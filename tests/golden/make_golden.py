@@ -19,6 +19,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-g7b # only the dense sequences (added in round 5)
     python tests/golden/make_golden.py --only-carry # only the two-batch state carry-over run (added in round 5)
     python tests/golden/make_golden.py --only-refyaml-variants # only the arp 0 / scalar-tau runs of radio_ml_conv_ref.yaml (round 5)
+    python tests/golden/make_golden.py --only-g6d # only the dense-slice learning steps (added in round 6)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -683,6 +684,56 @@ def g7b_dense_sequence(lib, x_seeds=(11, 12)):
     np.savez_compressed(os.path.join(OUT, "g7b_dense_sequence.npz"), **out)
 
 
+def g6d_dense_learning(lib):
+    """DCLLBase.train_dcll on a DENSE slice (round-5 verdict, missing #2): DCLLClassification(DenseDCLLlayer(512, 128, target 24)),
+    SmoothL1Loss, Adam(betas (0, .95), weight_decay 10, lr 1e-5), B = 8, burn-in 4, T = 9 -> iter 4..9 learn (six steps, the
+    neuron state and the Adam moments carried along), regularize = False as ConvNetwork.learn passes it
+    (dcll/pytorch_libdcll.py:198-255, :634-635, :690-718).  Variants: rrp (wrp 1, random_tau=True — which the refractory dense
+    module never applies: its init_state :160-169 does not call randomize_tau), plain (wrp 0, scalar tau), plain_rtau (wrp 0,
+    random_tau: per-feature time constants), reg (rrp with train_dcll's default regularize = 0.05: the regularisers reach
+    pvmem and pv directly).  Per variant: initial state dict, packed input / output spikes, pvoutput and loss per step,
+    gradients of i2h.weight / i2h.bias at the first and the last learning step, final state dict and neuron state."""
+    out = {}
+    B, T, target, burnin = 8, 9, 24, 4
+    # (rrp / reg at 512 -> 128, the two non-refractory variants at 256 -> 64 with odd tile counts left to G7b: fixture size)
+    for name, cin, cout, wrp, rtau, reg in (("rrp", 512, 128, 1.0, True, False), ("plain", 256, 64, 0.0, False, False),
+                                            ("plain_rtau", 200, 72, 0.0, True, False), ("reg", 512, 128, 1.0, False, 0.05)):
+        seed(9)
+        layer = lib.DenseDCLLlayer(cin, cout, target_size=target, alpha=.9, alphas=.85, alpharp=.65, wrp=wrp, random_tau=rtau)
+        with torch.no_grad():
+            layer.i2h.weight.mul_(60.0)
+            layer.i2h.bias.mul_(0.02)
+        sl = lib.DCLLClassification(dclllayer=layer, name="dense", batch_size=B, loss=torch.nn.SmoothL1Loss,
+                                    optimizer=torch.optim.Adam,
+                                    kwargs_optimizer={"lr": 1e-5, "betas": [0.0, .95], "weight_decay": 10.0}, burnin=burnin)
+        pre = "g6d/%s/" % name
+        out.update(state_dict_np(layer, pre + "sd0/"))
+        g = torch.Generator().manual_seed(21)
+        labels = torch.randint(0, target, (B,), generator=g)
+        tgt = torch.zeros(B, target)
+        tgt[torch.arange(B), labels] = 1
+        out[pre + "target"] = npy(tgt)
+        xs, ss, ps, losses = [], [], [], []
+        sl.train()
+        for t in range(T):
+            x = (torch.rand(B, cin, generator=g) < 0.2).float()
+            o, p, pv, v, l = sl.train_dcll(x, tgt, regularize=reg)
+            xs.append(pack_bits(npy(x)))
+            ss.append(pack_bits(npy(o)))
+            ps.append(npy(p))
+            losses.append(npy(l).reshape(-1)[0])
+            if sl.iter == sl.burnin or t == T - 1:          # the first and the last learning step
+                out[pre + "grad/%d/w" % t] = npy(layer.i2h.weight.grad)
+                out[pre + "grad/%d/b" % t] = npy(layer.i2h.bias.grad)
+        out[pre + "x"], out[pre + "s"], out[pre + "p"] = np.stack(xs), np.stack(ss), np.stack(ps)
+        out[pre + "loss"] = np.asarray(losses, dtype=np.float32)
+        out[pre + "clout"] = np.stack(sl.clout)
+        out.update(state_dict_np(layer, pre + "sd1/"))
+        for i, nm in enumerate(layer.i2h.state._fields):
+            out[pre + "final_%s" % nm] = npy(layer.i2h.state[i])
+    np.savez_compressed(os.path.join(OUT, "g6d_dense_learning.npz"), **out)
+
+
 def g8_image(du):
     rng = np.random.RandomState(3)
     x = rng.rand(3, 6, 6).astype(np.float32)
@@ -756,6 +807,9 @@ def main():
         return
     if "--only-g7b" in sys.argv:
         g7b_dense_sequence(lib)
+        return
+    if "--only-g6d" in sys.argv:
+        g6d_dense_learning(lib)
         return
     if "--only-variants" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:

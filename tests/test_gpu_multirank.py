@@ -121,7 +121,7 @@ def test_bench_strong_scaling_flag_fixes_the_global_batch():
     for n in (1, 4):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1",
                             "--global-batch", "1027", "--cpu-windows", "0", "--per-step", "0", "--config5", "0",
-                            "--live-traffic", "0", "--batch-sweep", "0", "--trained", "0", "--t1024", "0"],
+                            "--live-traffic", "0", "--batch-sweep", "0", "--plane128", "0", "--trained", "0", "--t1024", "0"],
                            env=env, capture_output=True, text=True, timeout=1000)
         assert r.returncode == 0, r.stderr[-3000:]
         out = [l for l in r.stdout.splitlines() if l.strip()]
@@ -173,7 +173,7 @@ def test_bench_under_the_drivers_torchrun_command():
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     bench = os.path.join(ROOT, "bench.py")
-    quiet = ["--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--live-traffic", "0", "--batch-sweep", "0",
+    quiet = ["--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--live-traffic", "0", "--batch-sweep", "0", "--plane128", "0",
              "--trained", "0", "--t1024", "0"]
 
     def torchrun(n, extra):

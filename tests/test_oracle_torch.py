@@ -111,3 +111,47 @@ def test_g7b_dense_sequence_bit_exact(golden, case, cin, cout, wrp):
         assert np.array_equal(p.numpy(), g[pre + "p"][step])
     for i, nm in enumerate(("eps0", "eps1", "arp")[:3 if wrp > 0 else 2]):
         assert np.array_equal(layer.state[i].numpy(), g[pre + "final_" + nm])
+
+
+G6D = [("rrp", 1.0, False), ("plain", 0.0, False), ("plain_rtau", 0.0, False), ("reg", 1.0, 0.05)]
+
+
+@pytest.mark.parametrize("name,wrp,reg", G6D)
+def test_g6d_dense_learning_steps_bit_exact(golden, name, wrp, reg):
+    """Fixture G6d (DCLLBase.train_dcll on a DenseDCLLlayer slice, generated by importing the reference): the oracle's
+    dense step under torch autograd with the reference's loss / regulariser expressions (:694-703) and torch.optim.Adam
+    reproduces every spike, readout, loss, gradient and the trained weights bit for bit (same torch build)."""
+    g = golden("g6d_dense_learning.npz")
+    pre = "g6d/%s/" % name
+    sd = sd_t(g.sub(pre + "sd0/"))
+    W = sd["i2h.weight"].clone().requires_grad_(True)
+    b = sd["i2h.bias"].clone().requires_grad_(True)
+    opt = torch.optim.Adam([W, b], lr=1e-5, betas=[0.0, .95], weight_decay=10.0)
+    crit = torch.nn.SmoothL1Loss()
+    cin, cout = W.shape[1], W.shape[0]
+    x_all = unpack_bits(g[pre + "x"], cin)
+    tgt = t(g[pre + "target"])
+    T, B = x_all.shape[:2]
+    st = [torch.zeros(B, cin), torch.zeros(B, cin)] + ([torch.zeros(B, cout)] if wrp > 0 else [])
+    burnin = 4
+    for step in range(T):
+        s, pv, v, new = R.dense_lif_step(t(x_all[step]), W, b, sd["i2h.alpha"], sd["i2h.tau_m__dt"], sd["i2h.alphas"],
+                                         sd["i2h.tau_s__dt"], st, .65, wrp)
+        st = [q.detach() for q in new]
+        p = torch.nn.functional.linear(pv, sd["i2o.weight"], sd["i2o.bias"])
+        assert np.array_equal(s.numpy(), unpack_bits(g[pre + "s"][step], cout)), step
+        assert np.array_equal(p.detach().numpy(), g[pre + "p"][step]), step
+        if step + 1 >= burnin:
+            opt.zero_grad()
+            loss = crit(p, tgt)
+            if reg:
+                loss = loss + 20.0 * reg * torch.mean(torch.relu(v + 0.01)) + 0.1 * reg * torch.relu(0.1 - torch.mean(pv))
+            loss.backward()
+            if pre + "grad/%d/w" % step in g.keys():
+                assert np.array_equal(W.grad.numpy(), g[pre + "grad/%d/w" % step])
+                assert np.array_equal(b.grad.numpy(), g[pre + "grad/%d/b" % step])
+            opt.step()
+    assert np.array_equal(W.detach().numpy(), g[pre + "sd1/i2h.weight"])
+    assert np.array_equal(b.detach().numpy(), g[pre + "sd1/i2h.bias"])
+    for i, nm in enumerate(("eps0", "eps1", "arp")[:len(st)]):
+        assert np.array_equal(st[i].numpy(), g[pre + "final_" + nm]), nm
