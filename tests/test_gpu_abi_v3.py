@@ -612,8 +612,12 @@ def test_dense_slice_local_learning_reproduces_the_reference(golden, dev, name, 
                 gw, gb = L.i2h.weight.grad.cpu().numpy(), L.i2h.bias.grad.cpu().numpy()
                 np.testing.assert_allclose(gw, g[key], rtol=2e-3, atol=1e-6 * np.abs(g[key]).max())
                 np.testing.assert_allclose(gb, g[pre + "grad/%d/b" % t_], rtol=2e-3, atol=1e-6 * np.abs(g[pre + "grad/%d/b" % t_]).max())
-    assert launched.count("k_dense_bwd_wgrad") == 6 and launched.count("k_dense_bwd_dv") == 6, launched.names
-    assert (launched.count("k_adam_multi") == 6) == bool(native and not reg), launched.names      # else torch's optimizer
+    if native and not reg:      # (the autograd engine runs a node's backward on its own thread: the per-thread launch log of this
+        #                          thread sees the forward only)
+        assert launched.count("k_dense_bwd_wgrad") == 6 and launched.count("k_dense_bwd_dv") == 6, launched.names
+        assert launched.count("k_adam_multi") == 6, launched.names
+    else:
+        assert launched.count("k_adam_multi") == 0, launched.names                                # torch's optimizer
     assert np.array_equal(np.asarray(sl.clout), g[pre + "clout"])
     for nm in ("weight", "bias"):
         w0, w1 = g[pre + "sd0/i2h." + nm], g[pre + "sd1/i2h." + nm]
