@@ -175,7 +175,7 @@ def per_step_paths(dev, batch=512, steps=48, reps=3):
     return out
 
 
-def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
+def run_ref_network(dev, B, steps, warmup, rank=0, world=1, validate=True):
     """BASELINE config 5 as this build defines it (quant.py; the reference has no quantisation code, so
     parity is unpinned): radio_ml_conv_ref.yaml — 7 x (64 channels, (1,3) kernels, (1,2) pooling) — on a Q=16 x I=128 I/Q
     plane, per-output-channel int8 conv weights handed to the kernels AS INT8 through the C ABI (dcll_layer_opts), 1-bit
@@ -254,7 +254,7 @@ def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
     # 6 % of the samples at this batch: an in-place write-back raced with late waves — tests/test_gpu_kernels.py
     # test_sequence_w3_first_layer_grid_beyond_residency_with_carried_state.)
     validation = None
-    if fused and rank == 0 and "res" in last:
+    if validate and fused and rank == 0 and "res" in last:
         try:
             pick = torch.unique(torch.linspace(0, B - 1, 16).round().long()).to(dev)
             small = make_net(len(pick))
@@ -286,7 +286,7 @@ def run_ref_network(dev, B, steps, warmup, rank=0, world=1):
     if roof:
         # HBM traffic of the six launches: PMC counters cannot be read from inside this process — the summary of the separate
         # `rocprofv3 --pmc` passes of this command (profiles/collect_r05.sh ref) is used when it is for this batch
-        for rnd in (5, 4, 3):
+        for rnd in (6, 5, 4, 3):
             name = "r%02d_pmc_ref_b%d.json" % (rnd, B)
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)) as f:
@@ -336,7 +336,7 @@ def bench_ref_network(a):
     assert world == a.gpus, "torchrun --nproc-per-node must equal --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, a.gpus)
     dev = torch.device("cuda", parallel.local_device(local_rank))
     torch.cuda.set_device(dev)
-    rec = run_ref_network(dev, a.batch or 1024, a.steps, a.warmup, rank, world)
+    rec = run_ref_network(dev, a.batch or 1024, a.steps, a.warmup, rank, world, validate=bool(a.validate))
     if parallel.is_distributed():
         parallel.barrier()
     if rank == 0:
@@ -475,7 +475,7 @@ def live_hbm_traffic(extra_args, kernel_prefix, timeout=300):
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__)] + list(extra_args) + [
                    "--steps", "1", "--warmup", "0", "--cpu-windows", "0", "--per-step", "0", "--config5", "0", "--batch-sweep", "0",
-                   "--trained", "0", "--live-traffic", "0", "--t1024", "0", "--plane128", "0"]
+                   "--trained", "0", "--live-traffic", "0", "--t1024", "0", "--plane128", "0", "--validate", "0"]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
                                                                       "MASTER_ADDR", "MASTER_PORT", "DCLL_FORCE_DIST")}
             env["TMPDIR"] = "/tmp"
@@ -618,6 +618,9 @@ def main():
     ap.add_argument("--plane128", type=int, default=1,
                     help="1 (default, N=1 headline run only): also run the reference's argparse-default 128x128 plane at batch 64 "
                          "(2 steps + 4 windows of the CPU path) and report it as the `plane128` sub-record")
+    ap.add_argument("--validate", type=int, default=1,
+                    help="1 (default): config 5 re-runs 16 windows of its timed batch at batch 16 and compares (0: the PMC child "
+                         "passes — their per-launch averages must see the timed launches only)")
     ap.add_argument("--network", default="radio", choices=["radio", "ref"],
                     help="radio = radio_ml_conv.yaml (headline); ref = radio_ml_conv_ref.yaml with int8 weights (config 5)")
     a = ap.parse_args()

@@ -423,6 +423,12 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
 // registers) over the 128 pixel pairs: A[co][pixel pair], B[pixel pair][column] = one ds_read at an immediate offset
 // from the column's lane base.  Partial sums go to part[workgroup][co][1568 + 1] (k_bwd_reduce adds them in order).
 constexpr int WG32_GLD = 257;
+#ifndef STEP_PRIO_HALF
+#define STEP_PRIO_HALF 0
+#endif
+#ifndef WG32_SPLIT2_MAX_BATCH
+#define WG32_SPLIT2_MAX_BATCH 1024
+#endif
 // TILED = false: the 16x16 plane, one sample per job, image rows / channels share their zero padding (RF 19, CF 361).
 // TILED = true: planes with h % 16 == 0 and w % 16 == 0, one 16x16 tile of a sample per job; the tile's 22x22 eps1
 // region with its real halo (zero outside the plane) is staged per channel (RF 22, CF 484).
@@ -2285,6 +2291,12 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         real0 = __builtin_amdgcn_s_memrealtime();           // constant 100 MHz: the shader clock under THIS load
     }
 
+#if STEP_PRIO_HALF
+    // (experiments/build_variant.sh -DSTEP_PRIO_HALF=1, round 6: the two workgroups that share a CU at two samples per CU are
+    //  blockIdx i and i + gridDim / 2 — the first at a raised priority, so that it finishes its chunk loop first and its
+    //  epilogue burst runs under the other's MFMAs.  Measured: HISTORY.md "Round 6"; 0 in the product)
+    if (blockIdx.x < gridDim.x / 2) __builtin_amdgcn_s_setprio(3);
+#endif
     if (tid < 32) sbias[tid] = bias[tid];
     step_wchunk<Q8> wc;
     auto fetch_w = [&](int cp) { wc.fetch(cp); };
@@ -3140,6 +3152,12 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
     if (c32 && d->h == 16 && d->w == 16) {
         if (nchunk > 256) nchunk = 256;
         if (nchunk > B) nchunk = B;
+        // round 6: up to WG32_SPLIT2_MAX_BATCH samples 128 batch chunks x 2 column halves instead of 256 x 1 — half the partial
+        // rows (25.7 instead of 51.4 MB), which every workgroup stores at the END of the launch, all at once, and the reduction
+        // reads back: at B = 512 k_bwd_wgrad_c32 103.4 -> 100.6 us, k_grad_reduce_adam 25.0 -> 18.1 us; B = 384 (1.5 jobs per
+        // chunk before: two against one) 116 -> 93 us for the closed call; neutral at 2048, a loss at 4096 (the per-job staging
+        // doubles against the MFMAs) — experiments/wgrad_split_sweep.py, HISTORY.md "Round 6"
+        if (B > 160 && B <= WG32_SPLIT2_MAX_BATCH && nchunk > 128) nchunk = 128;
         // fewer samples than CUs: a sample's column tiles over 2, 3 or 6 workgroups
         if (nchunk <= 48)
             hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false, 6>), dim3((unsigned)nchunk, 6), dim3(512), 0, st, scratch,
