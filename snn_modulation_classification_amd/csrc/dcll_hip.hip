@@ -2294,7 +2294,8 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
 #if STEP_PRIO_HALF
     // (experiments/build_variant.sh -DSTEP_PRIO_HALF=1, round 6: the two workgroups that share a CU at two samples per CU are
     //  blockIdx i and i + gridDim / 2 — the first at a raised priority, so that it finishes its chunk loop first and its
-    //  epilogue burst runs under the other's MFMAs.  Measured: HISTORY.md "Round 6"; 0 in the product)
+    //  epilogue burst runs under the other's MFMAs.  Measured neutral — learn 0.5418 / 0.5411 vs 0.5415 / 0.5402 ms, test 0.2522 / 0.2525
+    //  vs 0.2520 / 0.2526 per timestep at B = 512, alternating runs — HISTORY.md "Round 6"; 0 in the product)
     if (blockIdx.x < gridDim.x / 2) __builtin_amdgcn_s_setprio(3);
 #endif
     if (tid < 32) sbias[tid] = bias[tid];
