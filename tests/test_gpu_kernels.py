@@ -619,7 +619,7 @@ def test_backward_vs_torch_autograd(golden, golden_meta, dev, case):
                                                      (32, 32, False, (32, 48), 2), (32, 32, True, (128, 128), 2),
                                                      (1, 32, False, (16, 16), 300), (32, 32, True, (16, 16), 5),
                                                      (32, 32, False, (16, 16), 70), (32, 32, False, (16, 16), 130),
-                                                     (32, 32, True, (16, 16), 300),
+                                                     (32, 32, True, (16, 16), 300), (32, 32, False, (16, 16), 1030),
                                                      # K = 3 * 60 = 180, not a multiple of 32: the output_ gradient over batch
                                                      # chunks (k_bwd_outgrad_part) — open and closed form must split alike
                                                      (2, 3, True, (6, 10), 20)])
@@ -633,7 +633,9 @@ def test_backward_on_large_planes(dev, cin, cout, out_layer, hw, B):
     rng = np.random.RandomState(17)
     # 32 -> 32 layers: the MFMA weight-gradient kernel over 16x16 tiles with their real halo; the two 16x16 cases: the
     # first layer's two-tile MFMA kernel k_bwd_wgrad_c1 (300 samples over 256 workgroups) and k_bwd_wgrad_c32 with a
-    # sample's column tiles over 6 / 3 / 2 / 1 workgroups (B = 5 / 70 / 130 / 300)
+    # sample's column tiles over 6 / 3 / 2 / 2 / 1 workgroups (B = 5 / 70 / 130 / 300 / 1030: since round 6 every batch from
+    # 161 to 1024 samples runs 128 chunks x 2 column halves — 300 samples = ragged chunks of two and three jobs —, larger
+    # ones 256 chunks x 1)
     Wn, bn, alpha, tau_m, alphas, tau_s = _rand_layer(rng, cin, cout, gain=3.0)
     sdn = _sd_from(Wn, bn, alpha, tau_m, alphas, tau_s, hw, rng=rng)
     K = cout * hw[0] * hw[1]
