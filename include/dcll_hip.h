@@ -50,7 +50,11 @@ typedef struct dcll_conv_desc {
     int32_t h, w;               /* input plane = im_dims                                                 */
     int32_t kh, kw;             /* kernel_size                                                           */
     int32_t pad_h, pad_w;       /* padding                                                               */
-    int32_t stride, dilation, groups; /* must be 1,1,1 (what ConvNetwork builds, networks/__init__.py:132-145) */
+    int32_t stride, dilation, groups; /* F.conv2d's (:417, :495); ConvNetwork builds 1,1,1 (networks/__init__.py:132-145).
+                                       * Other values (>= 1, groups dividing c_in and c_out; W is then (c_out, c_in/groups,
+                                       * kh, kw), the chain runs over the group's channel pairs) are served by the per-step
+                                       * calls dcll_conv_lif_step / dcll_conv_lif_backward[_open] on their generic kernels;
+                                       * the sequence calls return DCLL_ERR_UNSUPPORTED for them                          */
     int32_t pool_h, pool_w;     /* MaxPool2d(kernel=stride=pool, padding=(pool-1)/2)   :542-549          */
     int32_t target;             /* target_size: rows of i2o.weight (and output_.weight)                  */
     int32_t output_layer;       /* !=0: also o = output_(flatten(pv))  :605-606                          */
@@ -131,7 +135,7 @@ int dcll_conv_out_shape(const dcll_conv_desc *d, int32_t *conv_h, int32_t *conv_
 /*
  * One timestep of Conv2dDCLLlayer.forward — exact drop-in for dcll/pytorch_libdcll.py:599-608.
  *   x        (B,c_in,h,w)   input spikes (any fp32 values are accepted, the reference does not check)
- *   W,b      i2h.weight (c_out,c_in,kh,kw), i2h.bias (c_out)
+ *   W,b      i2h.weight (c_out,c_in/groups,kh,kw), i2h.bias (c_out) — b may be NULL (bias=False, :323-326: the chains start at 0)
  *   alpha,tau_m,alphas,tau_s   i2h.alpha, i2h.tau_m__dt, i2h.alphas, i2h.tau_s__dt
  *   eps0,eps1 (B,c_in,h,w)  neuron state, updated IN PLACE          arp (B,c_out,ch,cw) idem (may be NULL if !refractory)
  *   i2o_W (target, c_out*ph*pw), i2o_b (target)        out_W,out_b: output_ layer, NULL unless output_layer

@@ -52,9 +52,10 @@ def _pair(v):
     return tuple(v) if hasattr(v, "__len__") else (v, v)
 
 
-def conv_desc(c_in, c_out, hw, kernel, padding, pooling, target, output_layer, tau_is_tensor, wrp, alpharp=.65):
+def conv_desc(c_in, c_out, hw, kernel, padding, pooling, target, output_layer, tau_is_tensor, wrp, alpharp=.65,
+              stride=1, dilation=1, groups=1):
     (kh, kw), (pah, paw), (poh, pow_) = _pair(kernel), _pair(padding), _pair(pooling)
-    return ConvDesc(c_in, c_out, hw[0], hw[1], kh, kw, pah, paw, 1, 1, 1, poh, pow_, target, int(output_layer),
+    return ConvDesc(c_in, c_out, hw[0], hw[1], kh, kw, pah, paw, stride, dilation, groups, poh, pow_, target, int(output_layer),
                     int(tau_is_tensor), int(wrp > 0), alpharp, wrp)
 
 
@@ -67,16 +68,16 @@ def conv_out_shape(d):
 class OracleConvLayer:
     """Stateful wrapper: numpy float32 in/out, neuron state updated in place like the C ABI does."""
 
-    def __init__(self, sd, hw, padding, pooling, wrp, alpharp=.65, output_layer=False):
+    def __init__(self, sd, hw, padding, pooling, wrp, alpharp=.65, output_layer=False, stride=1, dilation=1, groups=1):
         f = lambda k: np.ascontiguousarray(np.asarray(sd[k], dtype=np.float32))
-        self.W, self.b = f("i2h.weight"), f("i2h.bias")
+        self.W, self.b = f("i2h.weight"), (f("i2h.bias") if "i2h.bias" in sd else None)      # (bias=False: chains start at 0)
         self.tau = [f("i2h.alpha"), f("i2h.tau_m__dt"), f("i2h.alphas"), f("i2h.tau_s__dt")]
         self.i2o_W, self.i2o_b = f("i2o.weight"), f("i2o.bias")
         self.out_W = f("output_.weight") if output_layer else None
         self.out_b = f("output_.bias") if output_layer else None
-        c_out, c_in, kh, kw = self.W.shape
-        self.d = conv_desc(c_in, c_out, hw, (kh, kw), padding, pooling, self.i2o_W.shape[0], output_layer,
-                           self.tau[0].size > 1, wrp, alpharp)
+        c_out, cig, kh, kw = self.W.shape
+        self.d = conv_desc(cig * groups, c_out, hw, (kh, kw), padding, pooling, self.i2o_W.shape[0], output_layer,
+                           self.tau[0].size > 1, wrp, alpharp, stride, dilation, groups)
         self.ch, self.cw, self.ph, self.pw = conv_out_shape(self.d)
         self.state = None
 

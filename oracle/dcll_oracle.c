@@ -27,8 +27,9 @@
 
 static void out_shape(const dcll_conv_desc *d, int *ch, int *cw, int *ph, int *pw)
 {
-    *ch = d->h + 2 * d->pad_h - d->kh + 1;
-    *cw = d->w + 2 * d->pad_w - d->kw + 1;
+    /* get_output_shape, pytorch_libdcll.py:368-375 (stride = dilation = 1: h + 2 pad - kh + 1) */
+    *ch = (d->h + 2 * d->pad_h - d->dilation * (d->kh - 1) - 1) / d->stride + 1;
+    *cw = (d->w + 2 * d->pad_w - d->dilation * (d->kw - 1) - 1) / d->stride + 1;
     /* MaxPool2d(kernel=stride=pool, padding=(pool-1)/2), floor mode */
     *ph = (*ch + 2 * ((d->pool_h - 1) / 2) - d->pool_h) / d->pool_h + 1;
     *pw = (*cw + 2 * ((d->pool_w - 1) / 2) - d->pool_w) / d->pool_w + 1;
@@ -62,7 +63,7 @@ int dcll_oracle_conv_lif_step(const dcll_conv_desc *d, const float *x, const flo
                               const float *i2o_W, const float *i2o_b, const float *out_W, const float *out_b,
                               float *out_s, float *out_p, float *out_o, float *out_pv, float *out_v, int32_t B)
 {
-    if (d->stride != 1 || d->dilation != 1 || d->groups != 1) return DCLL_ERR_UNSUPPORTED;
+    if (d->stride < 1 || d->dilation < 1 || d->groups < 1 || d->c_in % d->groups || d->c_out % d->groups) return DCLL_ERR_INVALID;
     int ch, cw, ph, pw;
     out_shape(d, &ch, &cw, &ph, &pw);
     const int C = d->c_in, O = d->c_out, H = d->h, Wd = d->w, KH = d->kh, KW = d->kw;
@@ -95,16 +96,20 @@ int dcll_oracle_conv_lif_step(const dcll_conv_desc *d, const float *x, const flo
             const float *padb = pad + (size_t)bi * C * HP * WP;
             for (int y = 0; y < ch; ++y) {
                 for (int xx = 0; xx < cw; ++xx) accrow[xx] = b ? b[co] : 0.0f;
-                for (int cp = 0; cp < (C + 1) / 2; ++cp)
+                /* F.conv2d's groups / stride / dilation (:417, :495): co sees the cig channels of its group; tap (ky, kx) of
+                 * output (y, x) reads padded input (y stride + ky dilation, x stride + kx dilation); the chain runs over the
+                 * group's channel pairs.  All three at 1: the plain convolution. */
+                const int cig = C / d->groups, grp = co / (O / d->groups), st = d->stride, dl = d->dilation;
+                for (int cp = 0; cp < (cig + 1) / 2; ++cp)
                     for (int ky = 0; ky < KH; ++ky)
                         for (int kx = 0; kx < KW; ++kx)
                             for (int hh = 0; hh < 2; ++hh) {
                                 int ci = 2 * cp + hh;
-                                if (ci >= C) continue;
-                                const float *row = padb + ((size_t)ci * HP + (y + ky)) * WP + kx;
-                                const float w = W[(((size_t)co * C + ci) * KH + ky) * KW + kx];
+                                if (ci >= cig) continue;
+                                const float *row = padb + ((size_t)(grp * cig + ci) * HP + (y * st + ky * dl)) * WP + kx * dl;
+                                const float w = W[(((size_t)co * cig + ci) * KH + ky) * KW + kx];
 #pragma omp simd
-                                for (int xx = 0; xx < cw; ++xx) accrow[xx] = fmaf(row[xx], w, accrow[xx]);
+                                for (int xx = 0; xx < cw; ++xx) accrow[xx] = fmaf(row[(size_t)xx * st], w, accrow[xx]);
                             }
                 for (int xx = 0; xx < cw; ++xx) {
                     const float acc = accrow[xx];

@@ -25,12 +25,15 @@ def _pair(v):
 
 
 def conv_lif_step(x, weight, bias, alpha, tau_m, alphas, tau_s, state, alpharp=.65, wrp=0.0,
-                  stride=1, padding=0, dilation=1, groups=1):
+                  stride=1, padding=0, dilation=1, groups=1, act=None, spiking=True):
     """One timestep of ContinuousConv2D / ContinuousRelativeRefractoryConv2D.
 
     state = (eps0, eps1) or (eps0, eps1, arp).  Returns (spikes, pv, v, new_state).
     Each line is one separately rounded fp32 op, exactly as pytorch_libdcll.py:493-503 / :415-420.
+    act: the layer's activation (:419 / :500; None = nn.Sigmoid(), the default); spiking=False (plain variant only, :336-339):
+    the output is pvmem itself instead of (pvmem > 0).
     """
+    act = torch.sigmoid if act is None else act
     eps0 = x * tau_s + alphas * state[0]                       # :493 / :415
     eps1 = alpha * state[1] + eps0 * tau_m                     # :494 / :416
     pvmem = F.conv2d(eps1, weight, bias, stride, padding, dilation, groups)   # :495 / :417
@@ -38,16 +41,17 @@ def conv_lif_step(x, weight, bias, alpha, tau_m, alphas, tau_s, state, alpharp=.
         arp = alpharp * state[2]                               # :497
         v = pvmem + arp                                        # :498
         s = (v > 0).float()                                    # :499
-        pv = torch.sigmoid(v)                                  # :500
+        pv = act(v)                                            # :500
         arp = arp - s * wrp                                    # :503 (in-place there)
         return s, pv, v, (eps0, eps1, arp)
-    pv = torch.sigmoid(pvmem)                                  # :419
-    s = (pvmem > 0).float()                                    # :420
+    pv = act(pvmem)                                            # :419
+    s = (pvmem > 0).float() if spiking else pvmem              # :420 (output_act :336-339)
     return s, pv, pvmem, (eps0, eps1)
 
 
-def dense_lif_step(x, weight, bias, alpha, tau_m, alphas, tau_s, state, alpharp=.65, wrp=0.0):
+def dense_lif_step(x, weight, bias, alpha, tau_m, alphas, tau_s, state, alpharp=.65, wrp=0.0, act=None, spiking=True):
     """One timestep of CLLDenseModule / CLLDenseRRPModule (pytorch_libdcll.py:139-148, :179-195)."""
+    act = torch.sigmoid if act is None else act
     eps0 = x * tau_s + alphas * state[0]
     eps1 = alpha * state[1] + eps0 * tau_m
     pvmem = F.linear(eps1, weight, bias)
@@ -55,10 +59,10 @@ def dense_lif_step(x, weight, bias, alpha, tau_m, alphas, tau_s, state, alpharp=
         arp = alpharp * state[2]
         v = pvmem + arp
         s = (v > 0).float()
-        pv = torch.sigmoid(v)
+        pv = act(v)
         arp = arp - s * wrp
         return s, pv, v, (eps0, eps1, arp)
-    return (pvmem > 0).float(), torch.sigmoid(pvmem), pvmem, (eps0, eps1)
+    return ((pvmem > 0).float() if spiking else pvmem), act(pvmem), pvmem, (eps0, eps1)
 
 
 def max_pool(x, pooling):
@@ -70,9 +74,11 @@ def max_pool(x, pooling):
 class RefConvLayer:
     """Functional twin of Conv2dDCLLlayer built from a state-dict-like mapping of tensors."""
 
-    def __init__(self, sd, padding, pooling, wrp, alpharp=.65, output_layer=False):
+    def __init__(self, sd, padding, pooling, wrp, alpharp=.65, output_layer=False, stride=1, dilation=1, groups=1, act=None,
+                 spiking=True):
         self.w = sd["i2h.weight"]
-        self.b = sd["i2h.bias"]
+        self.b = sd.get("i2h.bias")         # (bias=False: no such entry)
+        self.stride, self.dilation, self.groups, self.act, self.spiking = stride, dilation, groups, act, spiking
         self.alpha, self.tau_m = sd["i2h.alpha"], sd["i2h.tau_m__dt"]
         self.alphas, self.tau_s = sd["i2h.alphas"], sd["i2h.tau_s__dt"]
         self.i2o_w, self.i2o_b = sd["i2o.weight"], sd["i2o.bias"]
@@ -87,10 +93,11 @@ class RefConvLayer:
 
     def out_hw(self, hw):
         kh, kw = self.w.shape[2:]
-        return hw[0] + 2 * self.padding[0] - kh + 1, hw[1] + 2 * self.padding[1] - kw + 1
+        return ((hw[0] + 2 * self.padding[0] - self.dilation * (kh - 1) - 1) // self.stride + 1,
+                (hw[1] + 2 * self.padding[1] - self.dilation * (kw - 1) - 1) // self.stride + 1)
 
     def init_state(self, batch, hw):
-        cin, cout = self.w.shape[1], self.w.shape[0]
+        cin, cout = self.w.shape[1] * self.groups, self.w.shape[0]
         z = torch.zeros(batch, cin, *hw)
         st = [z, z.clone()]
         if self.wrp > 0:
@@ -102,7 +109,8 @@ class RefConvLayer:
         if self.state is None or self.state[0].shape[0] != x.shape[0]:
             self.init_state(x.shape[0], x.shape[2:4])
         s, pv, v, self.state = conv_lif_step(x, self.w, self.b, self.alpha, self.tau_m, self.alphas, self.tau_s,
-                                             self.state, self.alpharp, self.wrp, 1, self.padding)
+                                             self.state, self.alpharp, self.wrp, self.stride, self.padding, self.dilation,
+                                             self.groups, self.act, self.spiking)
         s, pv = max_pool(s, self.pooling), max_pool(pv, self.pooling)
         flat = pv.reshape(pv.shape[0], -1)
         p = F.linear(flat, self.i2o_w, self.i2o_b)
@@ -113,12 +121,12 @@ class RefConvLayer:
 class RefDenseLayer:
     """Functional twin of DenseDCLLlayer (pytorch_libdcll.py:198-255)."""
 
-    def __init__(self, sd, wrp, alpharp=.65):
-        self.w, self.b = sd["i2h.weight"], sd["i2h.bias"]
+    def __init__(self, sd, wrp, alpharp=.65, act=None, spiking=True):
+        self.w, self.b = sd["i2h.weight"], sd.get("i2h.bias")
         self.alpha, self.tau_m = sd["i2h.alpha"], sd["i2h.tau_m__dt"]
         self.alphas, self.tau_s = sd["i2h.alphas"], sd["i2h.tau_s__dt"]
-        self.i2o_w, self.i2o_b = sd["i2o.weight"], sd["i2o.bias"]
-        self.wrp, self.alpharp = float(wrp), float(alpharp)
+        self.i2o_w, self.i2o_b = sd["i2o.weight"], sd.get("i2o.bias")     # (bias=False strips both, :229)
+        self.wrp, self.alpharp, self.act, self.spiking = float(wrp), float(alpharp), act, spiking
         self.state = None
 
     def forward(self, x):
@@ -130,7 +138,7 @@ class RefDenseLayer:
                 st.append(torch.zeros(x.shape[0], self.w.shape[0]))
             self.state = tuple(st)
         s, pv, v, self.state = dense_lif_step(x, self.w, self.b, self.alpha, self.tau_m, self.alphas, self.tau_s,
-                                              self.state, self.alpharp, self.wrp)
+                                              self.state, self.alpharp, self.wrp, self.act, self.spiking)
         return s, F.linear(pv, self.i2o_w, self.i2o_b), pv, v
 
 

@@ -94,11 +94,15 @@ static inline int split16_max_batch(void)
 
 static inline void conv_shape(const dcll_conv_desc *d, int *ch, int *cw, int *ph, int *pw)
 {
-    *ch = d->h + 2 * d->pad_h - d->kh + 1;
-    *cw = d->w + 2 * d->pad_w - d->kw + 1;
+    // (reference get_output_shape, dcll/pytorch_libdcll.py:368-375; stride = dilation = 1: h + 2 pad - kh + 1)
+    *ch = (d->h + 2 * d->pad_h - d->dilation * (d->kh - 1) - 1) / d->stride + 1;
+    *cw = (d->w + 2 * d->pad_w - d->dilation * (d->kw - 1) - 1) / d->stride + 1;
     *ph = (*ch + 2 * ((d->pool_h - 1) / 2) - d->pool_h) / d->pool_h + 1;
     *pw = (*cw + 2 * ((d->pool_w - 1) / 2) - d->pool_w) / d->pool_w + 1;
 }
+
+// the specialised kernels (MFMA step / sequence / weight-gradient kernels, the tiled VALU kernel) are plain convolutions
+static inline bool plain_conv(const dcll_conv_desc *d) { return d->stride == 1 && d->dilation == 1 && d->groups == 1; }
 
 static int check_desc(const dcll_conv_desc *d)
 {
@@ -106,8 +110,12 @@ static int check_desc(const dcll_conv_desc *d)
     if (d->c_in < 1 || d->c_out < 1 || d->h < 1 || d->w < 1 || d->kh < 1 || d->kw < 1 || d->pad_h < 0 ||
         d->pad_w < 0 || d->pool_h < 1 || d->pool_w < 1 || d->target < 0)
         return fail(DCLL_ERR_INVALID, "descriptor has a non-positive dimension");
-    if (d->stride != 1 || d->dilation != 1 || d->groups != 1)
-        return fail(DCLL_ERR_UNSUPPORTED, "stride/dilation/groups other than 1 are not implemented");
+    // stride / dilation / groups other than 1 (F.conv2d's, reference :417 / :495): served by the generic per-step kernels
+    // (k_conv_lif, k_bwd_wgrad) only — ConvNetwork never builds such a layer
+    if (d->stride < 1 || d->dilation < 1 || d->groups < 1 || d->c_in % d->groups != 0 || d->c_out % d->groups != 0)
+        return fail(DCLL_ERR_INVALID, "stride / dilation / groups must be >= 1 and groups must divide c_in and c_out");
+    if (d->h + 2 * d->pad_h < d->dilation * (d->kh - 1) + 1 || d->w + 2 * d->pad_w < d->dilation * (d->kw - 1) + 1)
+        return fail(DCLL_ERR_INVALID, "empty conv/pool output");
     int ch, cw, ph, pw;
     conv_shape(d, &ch, &cw, &ph, &pw);
     if (ch < 1 || cw < 1 || ph < 1 || pw < 1) return fail(DCLL_ERR_INVALID, "empty conv/pool output");
@@ -158,21 +166,25 @@ __global__ void k_conv_lif(dcll_conv_desc d, int ch, int cw, const float *__rest
     r /= ch;
     int co = (int)(r % d.c_out);
     long b = r / d.c_out;
-    const float *e = eps1 + b * d.c_in * d.h * d.w;
-    const long wbase = (long)co * d.c_in * d.kh * d.kw;
+    // groups (F.conv2d): output channel co belongs to group co / (c_out / groups) and sees that group's cig = c_in / groups
+    // input channels; the pinned chain runs over the group's channel pairs.  stride / dilation: tap (ky, kx) of output (y, x)
+    // reads input (y * stride + ky * dilation - pad, ...).  With all three at 1 this is the plain convolution, bit for bit.
+    const int cig = d.c_in / d.groups, grp = co / (d.c_out / d.groups);
+    const float *e = eps1 + (b * d.c_in + (long)grp * cig) * d.h * d.w;
+    const long wbase = (long)co * cig * d.kh * d.kw;
     float acc = bias ? bias[co] : 0.0f;
-    const int npair = (d.c_in + 1) >> 1;
+    const int npair = (cig + 1) >> 1;
     for (int cp = 0; cp < npair; ++cp)
         for (int ky = 0; ky < d.kh; ++ky) {
-            int yy = y + ky - d.pad_h;
+            int yy = y * d.stride + ky * d.dilation - d.pad_h;
             bool yin = yy >= 0 && yy < d.h;
             for (int kx = 0; kx < d.kw; ++kx) {
-                int xq = xx + kx - d.pad_w;
+                int xq = xx * d.stride + kx * d.dilation - d.pad_w;
                 bool in = yin && xq >= 0 && xq < d.w;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     int ci = 2 * cp + hh;
-                    if (ci < d.c_in) {
+                    if (ci < cig) {
                         float ev = in ? e[((long)ci * d.h + yy) * d.w + xq] : 0.0f;
                         acc = __builtin_fmaf(ev, W.at(wbase + ((long)ci * d.kh + ky) * d.kw + kx, co), acc);
                     }
@@ -360,15 +372,19 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
                                                     int RB)
 {
     extern __shared__ float sm[];
-    const int co = blockIdx.x / d.c_in, ci = blockIdx.x % d.c_in;
+    // (groups: output channel co sees the cig = c_in / groups input channels of its group; row length cig * ntap + 1)
+    const int cig = d.c_in / d.groups;
+    const int co = blockIdx.x / cig, cil = blockIdx.x % cig, ci = (co / (d.c_out / d.groups)) * cig + cil;
     const int WP = d.w + 2 * d.pad_w, ntap = d.kh * d.kw;
-    float *e = sm;                                // zero-padded band of the eps1 plane of (b, ci): RB + kh - 1 rows
-    float *red = sm + (RB + d.kh - 1) * WP;       // 4 x (WG_MAXTAPS + 1) wave totals
+    // zero-padded band of the eps1 plane of (b, ci): the input rows RB output rows read = (RB - 1) stride + (kh - 1) dilation + 1
+    const int band = (RB - 1) * d.stride + (d.kh - 1) * d.dilation + 1;
+    float *e = sm;
+    float *red = sm + band * WP;                  // 4 x (WG_MAXTAPS + 1) wave totals
     float acc[WG_MAXTAPS];
 #pragma unroll
     for (int t = 0; t < WG_MAXTAPS; ++t) acc[t] = 0.0f;
     float accb = 0.0f;
-    const long rowlen = (long)d.c_in * ntap + 1;
+    const long rowlen = (long)cig * ntap + 1;
     float *prow = part + ((long)blockIdx.y * d.c_out + co) * rowlen;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         const float *ep = eps1 + ((long)b * d.c_in + ci) * d.h * d.w;
@@ -376,8 +392,8 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
         for (int y0 = 0; y0 < ch; y0 += RB) {         // bands of RB output rows (the whole plane when it fits LDS)
             const int rows = min(RB, ch - y0);
             __syncthreads();
-            for (int i = threadIdx.x; i < (rows + d.kh - 1) * WP; i += 256) {
-                const int iy = y0 + i / WP - d.pad_h, ix = i % WP - d.pad_w;
+            for (int i = threadIdx.x; i < ((rows - 1) * d.stride + (d.kh - 1) * d.dilation + 1) * WP; i += 256) {
+                const int iy = y0 * d.stride + i / WP - d.pad_h, ix = i % WP - d.pad_w;
                 e[i] = ((unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w) ? ep[iy * d.w + ix] : 0.0f;
             }
             __syncthreads();
@@ -385,10 +401,10 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
                 const int yy = pos / cw, xx = pos % cw;
                 const float g = gp[(y0 + yy) * cw + xx];
                 accb += g;
-                const float *eb = e + yy * WP + xx;
+                const float *eb = e + yy * d.stride * WP + xx * d.stride;
 #pragma unroll
                 for (int t = 0; t < WG_MAXTAPS; ++t)
-                    if (t < ntap) acc[t] = __builtin_fmaf(g, eb[(t / d.kw) * WP + (t % d.kw)], acc[t]);
+                    if (t < ntap) acc[t] = __builtin_fmaf(g, eb[(t / d.kw) * d.dilation * WP + (t % d.kw) * d.dilation], acc[t]);
             }
         }
     }
@@ -411,8 +427,8 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
     if (threadIdx.x <= ntap) {
         const int t = threadIdx.x < ntap ? threadIdx.x : WG_MAXTAPS;
         const float tot = ((red[t] + red[(WG_MAXTAPS + 1) + t]) + red[2 * (WG_MAXTAPS + 1) + t]) + red[3 * (WG_MAXTAPS + 1) + t];
-        if (threadIdx.x < ntap) prow[(long)ci * ntap + threadIdx.x] = tot;
-        else if (ci == 0) prow[rowlen - 1] = tot;
+        if (threadIdx.x < ntap) prow[(long)cil * ntap + threadIdx.x] = tot;
+        else if (cil == 0) prow[rowlen - 1] = tot;
     }
 }
 
@@ -2787,7 +2803,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     const long per = (long)d->c_in * d->h * d->w, nin = per * B;
     const long nconv = (long)B * d->c_out * ch * cw, npool = (long)B * d->c_out * ph * pw;
     const int K = d->c_out * ph * pw;
-    const bool k7 = d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b;
+    const bool k7 = d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->pool_h == 1 && d->pool_w == 1 && b && plain_conv(d);
     const bool plane16 = d->h == 16 && d->w == 16 && k7;
     // (16x16 plane: two workgroups per sample — 8-row tiles — when the batch alone would leave half the CUs idle)
     const bool split16 = plane16 && B <= split16_max_batch();
@@ -2878,7 +2894,7 @@ extern "C" int dcll_conv_lif_step(const dcll_conv_desc *d, const float *x, const
     {
         constexpr int COG = 8;
         const dim3 tg(((cw + 15) / 16) * ((ch + 15) / 16), (d->c_out + COG - 1) / COG, B);
-        const bool tile_ok = ch >= 8 && cw >= 8 && B <= 65535;
+        const bool tile_ok = ch >= 8 && cw >= 8 && B <= 65535 && plain_conv(d);
 #define DCLL_TILED(KH_, KW_)                                                                                          \
     hipLaunchKernelGGL((k_conv_lif_tiled<KH_, KW_, COG>), tg, dim3(256), 0, st, *d, ch, cw, eps1, W, b, arp, s_full,    \
                        pv_full, out_v)
@@ -3144,12 +3160,12 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
     }
     if (!dv_done) HIP_CHECK_LAUNCH("k_bwd_dv");
     // weight gradient: partial sums over batch chunks (after the g_v_full plane in scratch), then a fixed-order reduce
-    const long rowlen = (long)d->c_in * d->kh * d->kw + 1;
+    const long rowlen = (long)(d->c_in / d->groups) * d->kh * d->kw + 1;      // (a weight row: the c_in / groups channels of co's group)
     const long per_chunk = (long)d->c_out * rowlen;
     float *part = scratch + nconv;
     long nchunk = (scratch_floats - nconv) / per_chunk;
     if (nchunk < 1) return fail(DCLL_ERR_INVALID, "dcll_conv_lif_backward: scratch too small (need B*c_out*ch*cw + k*(c_out*(c_in*kh*kw+1)), k >= 1)");
-    const bool c32 = d->c_in == 32 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3;
+    const bool c32 = d->c_in == 32 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && plain_conv(d);
     if (c32 && d->h == 16 && d->w == 16) {
         if (nchunk > 256) nchunk = 256;
         if (nchunk > B) nchunk = B;
@@ -3173,14 +3189,14 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
             hipLaunchKernelGGL((k_bwd_wgrad_c32<ROWF, CHF, false>), dim3((unsigned)nchunk), dim3(512), 0, st, scratch, eps1,
                                part, B, 16, 16);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c32");
-    } else if (d->c_in == 1 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->h == 16 &&
+    } else if (plain_conv(d) && d->c_in == 1 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 && d->h == 16 &&
                d->w == 16) {                                   // first layer of radio_ml_conv.yaml: MFMA, two column tiles
         if (nchunk > 512) nchunk = 512;
         if (nchunk > B) nchunk = B;
         hipLaunchKernelGGL((k_bwd_wgrad_c1<ROWF, false>), dim3((unsigned)nchunk), dim3(128), 0, st, scratch, eps1, part, B,
                            16, 16);
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c1");
-    } else if (d->c_in == 1 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 &&
+    } else if (plain_conv(d) && d->c_in == 1 && d->c_out == 32 && d->kh == 7 && d->kw == 7 && d->pad_h == 3 && d->pad_w == 3 &&
                d->h % 16 == 0 && d->w % 16 == 0) {             // first layer on large planes: one 16x16 tile per job
         const long njob = (long)B * (d->h / 16) * (d->w / 16);
         if (nchunk > 1024) nchunk = 1024;
@@ -3197,15 +3213,17 @@ static int conv_lif_backward_impl(const dcll_conv_desc *d, const float *eps1, co
         HIP_CHECK_LAUNCH("k_bwd_wgrad_c32 (tiled)");
     } else {
         // the eps1 plane is staged in LDS in bands of RB output rows (+ kh - 1 halo rows), at most 48 KB
+        // (RB output rows read (RB - 1) stride + (kh - 1) dilation + 1 input rows)
         const int WP = d->w + 2 * d->pad_w;
-        int RB = (48 * 1024 / 4 - 4 * (WG_MAXTAPS + 1)) / WP - (d->kh - 1);
+        const int rows_fit = (48 * 1024 / 4 - 4 * (WG_MAXTAPS + 1)) / WP;
+        int RB = rows_fit < (d->kh - 1) * d->dilation + 1 ? 0 : (rows_fit - (d->kh - 1) * d->dilation - 1) / d->stride + 1;
         if (RB < 1) return fail(DCLL_ERR_UNSUPPORTED, "dcll_conv_lif_backward: input rows too wide for the LDS-staged weight-gradient kernel");
         if (RB > ch) RB = ch;
-        const size_t lds = ((size_t)(RB + d->kh - 1) * WP + 4 * (WG_MAXTAPS + 1)) * sizeof(float);
+        const size_t lds = ((size_t)((RB - 1) * d->stride + (d->kh - 1) * d->dilation + 1) * WP + 4 * (WG_MAXTAPS + 1)) * sizeof(float);
         if (nchunk > 64) nchunk = 64;
         if (nchunk > B) nchunk = B;
-        hipLaunchKernelGGL(k_bwd_wgrad, dim3(d->c_out * d->c_in, (unsigned)nchunk), dim3(256), lds, st, *d, ch, cw, scratch,
-                           eps1, part, B, RB);
+        hipLaunchKernelGGL(k_bwd_wgrad, dim3(d->c_out * (d->c_in / d->groups), (unsigned)nchunk), dim3(256), lds, st, *d, ch, cw,
+                           scratch, eps1, part, B, RB);
         HIP_CHECK_LAUNCH("k_bwd_wgrad");
     }
     if (open_part) {
@@ -3441,7 +3459,7 @@ static int check_seq_geometry(const dcll_conv_desc *d, int c_in, const char *who
     if (rc) return rc;
     const bool small = d->h == 16 && d->w == 16;
     const bool tiled = d->h >= 8 && d->h % 8 == 0 && d->w >= 32 && d->w % 32 == 0;   // k_lif_seq_c1t / k_lif_seq_c32t
-    if (d->c_in != c_in || d->c_out > 32 || (c_in == 32 && d->c_out != 32) || !(small || tiled) || d->kh != 7 ||
+    if (!plain_conv(d) || d->c_in != c_in || d->c_out > 32 || (c_in == 32 && d->c_out != 32) || !(small || tiled) || d->kh != 7 ||
         d->kw != 7 || d->pad_h != 3 || d->pad_w != 3 || d->pool_h != 1 || d->pool_w != 1)
         return fail(DCLL_ERR_UNSUPPORTED,
                     "sequence kernel supports 7x7 pad 3, pool 1, c_out<=32 (==32 for c_in 32) on a 16x16 plane or a plane "

@@ -623,7 +623,8 @@ __global__ __launch_bounds__(256) void k_w3f_traces_advance(const int32_t *__res
 bool dcll_seq_w3_geometry(const dcll_conv_desc *d)
 {
     const bool pow2 = d->w >= 2 && d->w <= 256 && (d->w & (d->w - 1)) == 0;
-    return (d->c_in == 1 || d->c_in == 64) && d->c_out == 64 && d->kh == 1 && d->kw == 3 && d->pad_h == 0 && d->pad_w == 1 &&
+    return d->stride == 1 && d->dilation == 1 && d->groups == 1 &&
+           (d->c_in == 1 || d->c_in == 64) && d->c_out == 64 && d->kh == 1 && d->kw == 3 && d->pad_h == 0 && d->pad_w == 1 &&
            d->pool_h == 1 && d->pool_w == 2 && pow2 && ((long)d->h * d->w) % 32 == 0 && (256 % d->w == 0 || d->w == 256);
 }
 

@@ -99,12 +99,22 @@ def _as_pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
-def _check_act(act):
-    """Every kernel computes pv = sigmoid(v) (and the backward its derivative): any other activation would silently
-    give wrong pv and gradients, so it is refused here (the reference's callers only ever pass nn.Sigmoid())."""
-    if not isinstance(act, nn.Sigmoid):
-        raise NotImplementedError('the HIP kernels implement act = nn.Sigmoid() only, got %r' % (act,))
-    return act
+def _is_sigmoid(act):
+    """The fused kernels compute pv = sigmoid(v) (and the backward its derivative).  A layer built with another activation —
+    or with spiking=False, bias=False, stride / dilation / groups other than 1: the constructor options of the reference
+    (:299-313, :75-104) that ConvNetwork never uses — takes the GENERAL step (`_general()`): the HIP step for the traces, the
+    convolution in the pinned order (the generic kernels take stride / dilation / groups and a NULL bias), the refractory trace
+    and the threshold; the activation, the pooling and the readouts as torch ops on the device; gradients through an autograd
+    node whose backward is the HIP weight-gradient kernel (`_ConvLIFVFn` / `_DenseLIFVFn`).  Pinned by fixture G1x."""
+    return isinstance(act, nn.Sigmoid)
+
+
+def _max_pool(x, pooling):
+    """nn.MaxPool2d(kernel_size=pooling, stride=pooling, padding=(pooling - 1) // 2) (reference :542-549)."""
+    ph, pw = pooling
+    if (ph, pw) == (1, 1):
+        return x
+    return torch.nn.functional.max_pool2d(x, (ph, pw), (ph, pw), ((ph - 1) // 2, (pw - 1) // 2))
 
 
 class ContinuousConv2D(nn.Module):
@@ -123,7 +133,7 @@ class ContinuousConv2D(nn.Module):
         self.padding = _as_pair(padding)
         self.stride, self.dilation, self.groups = stride, dilation, groups
         self.random_tau = random_tau
-        self.act = _check_act(act)
+        self.act = act
         self.spiking = spiking
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
         if bias:
@@ -276,8 +286,6 @@ class ContinuousConv2D(nn.Module):
               defer_ro=False):
         """Run one step through dcll_conv_lif_step; returns (s_pooled, p, o, pv_pooled, v).  `out`: optional dict of
         reusable output buffers; `stacked` / `finish` / `defer_ro`: the fused readout tail of the step (ops.conv_lif_step)."""
-        if not self.spiking:
-            raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
         self._check_batch(input)
         desc = self.make_desc(input.shape[2:4], pooling, 0 if i2o is None else i2o.weight.shape[0],
                               output_ is not None)
@@ -285,16 +293,37 @@ class ContinuousConv2D(nn.Module):
         arp = st.arp if len(st) > 2 else None
         with torch.no_grad():
             return ops.conv_lif_step(
-                desc, input, self.weight, self.bias, self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt,
+                desc, input, self.weight, self._bias_or_zero(), self.alpha, self.tau_m__dt, self.alphas, self.tau_s__dt,
                 st.eps0, st.eps1, arp,
                 None if i2o is None else i2o.weight, None if i2o is None else i2o.bias,
                 None if output_ is None else output_.weight, None if output_ is None else output_.bias, out=out,
                 q8=self.int8_weights(), stacked=stacked, finish=finish, want_v=want_v, defer_ro=defer_ro)
 
+    def _general(self):
+        """True when the layer was built with an option outside the fused step (see _is_sigmoid)."""
+        return not (_is_sigmoid(self.act) and self.spiking and self.bias is not None and self.stride == 1 and
+                    self.dilation == 1 and self.groups == 1)
+
+    def _bias_or_zero(self):
+        """bias=False: a zero vector — the pinned chain then starts at +0.0, which IS the bias-free convolution (and lets the
+        specialised kernels serve the layer)."""
+        if self.bias is not None:
+            return self.bias
+        z = self.__dict__.get('_zero_bias')
+        if z is None or z.device != self.weight.device:
+            z = self.__dict__['_zero_bias'] = torch.zeros(self.out_channels, device=self.weight.device)
+        return z
+
+    def _outputs(self, s, pv, v):
+        """(output, pv) of the reference's forward from the HIP step's (spikes, sigmoid(v), v): output_act (:336-339) and
+        act (:419 / :500) as the layer was built."""
+        return (s if self.spiking else v), (pv if _is_sigmoid(self.act) else self.act(v))
+
     def forward(self, input):
-        """-> (output spikes, pv, pvmem), un-pooled (reference :407-426)."""
+        """-> (output, pv, pvmem), un-pooled (reference :407-426)."""
         s, _, _, pv, v = self._step(input)
-        return s, pv, v
+        o, pv = self._outputs(s, pv, v)
+        return o, pv, v
 
 
 class ContinuousRelativeRefractoryConv2D(ContinuousConv2D):
@@ -326,7 +355,8 @@ class ContinuousRelativeRefractoryConv2D(ContinuousConv2D):
         if not self.spiking:
             raise Exception('Refractory not allowed in non-spiking mode')
         s, _, _, pv, v = self._step(input)
-        return s, pv, v
+        o, pv = self._outputs(s, pv, v)
+        return o, pv, v
 
 
 class _ConvLIFStepFn(torch.autograd.Function):
@@ -355,6 +385,28 @@ class _ConvLIFStepFn(torch.autograd.Function):
         dW, db, d_outW, d_outb = ops.conv_lif_backward(ctx.desc, ctx.eps1, ctx.v, ctx.pv, gp, go, gpv, gv,
                                                        layer.i2o.weight, want_out=layer.output_layer and go is not None)
         return None, None, dW, db, d_outW, d_outb
+
+
+class _ConvLIFVFn(torch.autograd.Function):
+    """The conv + neuron part of a GENERAL layer step (_is_sigmoid) as an autograd node: forward = dcll_conv_lif_step without
+    readouts -> (spikes, v), un-pooled; backward = dcll_conv_lif_backward fed with dL/dv alone (dW = dv (*) eps1, db = sum dv).
+    Activation, pooling and readouts are torch ops on top of v, so whatever the layer's `act` is, torch differentiates it."""
+
+    @staticmethod
+    def forward(ctx, i2h, x, W, b):
+        s, _, _, _, v = i2h._step(x)
+        ctx.i2h = i2h
+        ctx.desc = i2h.make_desc(x.shape[2:4])
+        ctx.eps1 = i2h.state.eps1.clone()       # (the state buffers are updated in place by the next step)
+        ctx.v = v
+        ctx.mark_non_differentiable(s)
+        return s, v
+
+    @staticmethod
+    def backward(ctx, gs, gv):
+        dW, db, _, _ = ops.conv_lif_backward(ctx.desc, ctx.eps1, ctx.v, None, None, None, None, gv.contiguous(), None,
+                                             want_out=False)
+        return None, None, dW, (db if ctx.i2h.bias is not None else None)
 
 
 class Conv2dDCLLlayer(nn.Module):
@@ -436,6 +488,8 @@ class Conv2dDCLLlayer(nn.Module):
     def forward(self, input):
         """-> (output, pvoutput, pv, pvmem): next-layer spikes (or output_ logits on the last layer), local
         readout logits, pooled sigmoid, un-pooled membrane (reference :599-608) — one C-ABI call."""
+        if self.i2h._general():
+            return self._forward_general(input)
         if getattr(self, 'build_graph', False) and torch.is_grad_enabled():
             # local-learning step: same kernels, wrapped in an autograd node (see _ConvLIFStepFn)
             out = _ConvLIFStepFn.apply(self, input, self.i2h.weight, self.i2h.bias,
@@ -459,6 +513,24 @@ class Conv2dDCLLlayer(nn.Module):
                                         out=self.__dict__.get('_step_bufs'))
         return (o if self.output_layer else s), self._drop(p), pv, v
 
+    def _forward_general(self, input):
+        """forward() of a layer built with an option outside the fused step (_is_sigmoid): the HIP step yields spikes and v
+        (reference :407-426 / :485-509 up to the threshold), the rest of :599-608 — act, the two poolings, i2o, output_ — are
+        torch ops on the device; under train_dcll's graph v is differentiable through _ConvLIFVFn."""
+        i2h = self.i2h
+        if getattr(self, 'build_graph', False) and torch.is_grad_enabled():
+            s, v = _ConvLIFVFn.apply(i2h, input, i2h.weight, i2h.bias)
+        else:
+            s, _, _, _, v = i2h._step(input)
+        pv = i2h.act(v)
+        output = _max_pool(s if i2h.spiking else v, self.pooling)
+        pv = _max_pool(pv, self.pooling)
+        flat = pv.reshape(pv.shape[0], -1)
+        pvoutput = self._drop(torch.nn.functional.linear(flat, self.i2o.weight, self.i2o.bias))
+        if self.output_layer:
+            output = torch.nn.functional.linear(flat.detach(), self.output_.weight, self.output_.bias)
+        return output, pvoutput, pv, v
+
     def _drop(self, p):
         return p if self.dropout is None else self.dropout(p)
 
@@ -478,8 +550,7 @@ class Conv2dDCLLlayer(nn.Module):
         channels; W a power of two <= 256; k_lif_seq_w3)."""
         i = self.i2h
         H, W = self.im_dims
-        if not (i.stride == 1 and i.dilation == 1 and i.groups == 1 and i.bias is not None and i.spiking) or \
-                i.tau_per_channel() is None or self.dropout_active():     # (a masked readout is drawn per step: per-step path)
+        if i._general() or i.tau_per_channel() is None or self.dropout_active():   # (a masked readout is drawn per step)
             return None
         if i.kernel_size == (7, 7) and i.padding == (3, 3) and self.pooling == (1, 1) and i.out_channels <= 32 and \
                 ((H, W) == (16, 16) or (H % 8 == 0 and W % 32 == 0)):         # k_lif_seq_c1/c32 or the tiled c1t/c32t
@@ -624,7 +695,7 @@ class CLLDenseModule(nn.Module):
         else:
             self.register_parameter('bias', None)
         self.reset_parameters()
-        self.act = _check_act(act)
+        self.act = act
         self.random_tau = random_tau
         self._set_tau(torch.Tensor([alpha]), torch.Tensor([alphas]))
         self.spiking = spiking
@@ -632,6 +703,12 @@ class CLLDenseModule(nn.Module):
         self.state = None
 
     _set_tau = ContinuousConv2D._set_tau
+    _outputs = ContinuousConv2D._outputs
+
+    def _general(self):
+        """True when the layer was built with an option outside the fused step (see _is_sigmoid; the dense kernels take a
+        NULL bias as they are)."""
+        return not (_is_sigmoid(self.act) and self.spiking and self.bias is not None)
 
     def reset_parameters(self):
         stdv = 1. / math.sqrt(self.weight.size(1))
@@ -661,8 +738,6 @@ class CLLDenseModule(nn.Module):
                          int(self.alpha.numel() > 1), int(self.wrp > 0), float(self.alpharp), float(self.wrp))
 
     def _step(self, input, i2o=None):
-        if not self.spiking:
-            raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
         if self.state is None or not (input.shape[0] == self.state.eps0.shape[0] == self.state.eps1.shape[0]):
             old = -1 if self.state is None else self.state.eps0.shape[0]
             logger.warning("Batch size changed from {} to {} since last iteration. Reallocating states."
@@ -677,7 +752,8 @@ class CLLDenseModule(nn.Module):
 
     def forward(self, input):
         s, _, pv, v = self._step(input)
-        return s, pv, v
+        o, pv = self._outputs(s, pv, v)
+        return o, pv, v
 
 
 class CLLDenseRRPModule(CLLDenseModule):
@@ -723,6 +799,26 @@ class _DenseLIFStepFn(torch.autograd.Function):
         return None, None, dW, (db if ctx.layer.i2h.bias is not None else None)
 
 
+class _DenseLIFVFn(torch.autograd.Function):
+    """The neuron part of a GENERAL dense layer step (_is_sigmoid) as an autograd node: forward = dcll_dense_lif_step without a
+    readout -> (spikes, v); backward = dcll_dense_lif_backward fed with dL/dv alone (dW = dv^T . eps1, db = sum dv)."""
+
+    @staticmethod
+    def forward(ctx, i2h, x, W, b):
+        s, _, pv, v = i2h._step(x)
+        ctx.i2h = i2h
+        ctx.desc = i2h.make_desc()
+        ctx.eps1 = i2h.state.eps1.clone()
+        ctx.pv = pv
+        ctx.mark_non_differentiable(s)
+        return s, v
+
+    @staticmethod
+    def backward(ctx, gs, gv):
+        dW, db = ops.dense_lif_backward(ctx.desc, ctx.eps1, ctx.pv, None, None, gv.contiguous(), None)
+        return None, None, dW, (db if ctx.i2h.bias is not None else None)
+
+
 class DenseDCLLlayer(nn.Module):
     def __init__(self, in_channels, out_channels, target_size=None, bias=True, alpha=.9, alphas=.85, alpharp=.65,
                  wrp=0., act=nn.Sigmoid(), lc_dropout=False, lc_ampl=.5, spiking=True, random_tau=False,
@@ -757,6 +853,17 @@ class DenseDCLLlayer(nn.Module):
     def forward(self, input):
         """-> (output spikes, pvoutput, pv, pvmem)  (reference :250-255)."""
         x = input.reshape(-1, self.in_channels)
+        i2h = self.i2h
+        if i2h._general():
+            # an option outside the fused step (_is_sigmoid): spikes and v from the HIP step, act and i2o as torch ops; under
+            # train_dcll's graph v is differentiable through _DenseLIFVFn (reference :131-148 / :171-195, :250-255)
+            if getattr(self, 'build_graph', False) and torch.is_grad_enabled():
+                s, v = _DenseLIFVFn.apply(i2h, x, i2h.weight, i2h.bias)
+            else:
+                s, _, _, v = i2h._step(x)
+            pv = i2h.act(v)
+            p = torch.nn.functional.linear(pv, self.i2o.weight, self.i2o.bias)
+            return ((s if i2h.spiking else v).detach(), (p if self.dropout is None else self.dropout(p)), pv, v)
         if getattr(self, 'build_graph', False) and torch.is_grad_enabled():
             # local-learning step: same kernel, wrapped in an autograd node (see _DenseLIFStepFn)
             s, p, pv, v = _DenseLIFStepFn.apply(self, x, self.i2h.weight, self.i2h.bias)
@@ -771,8 +878,9 @@ class DenseDCLLlayer(nn.Module):
         i2h = self.i2h
         T, B = x_seq.shape[0], x_seq.shape[1]
         x_seq = x_seq.reshape(T, B, self.in_channels)
-        if not i2h.spiking:
-            raise NotImplementedError('non-spiking (analog output) layers are not implemented by the HIP path')
+        if i2h._general():        # (an option outside the fused kernels: step by step, stacked)
+            outs = [self.forward(x_seq[t]) for t in range(T)]
+            return tuple(torch.stack([o_[k] for o_ in outs]) if (k < 3 or want_v) else None for k in range(4))
         if i2h.state is None or i2h.state.eps0.shape[0] != B:
             i2h.init_state(B)
         desc = DenseDesc(i2h.in_channels, i2h.out_channels, self.i2o.weight.shape[0], int(i2h.alpha.numel() > 1),
@@ -862,7 +970,8 @@ class DCLLBase(nn.Module):
 
     def write_stats(self, writer, label, epoch):
         writer.add_histogram(self.name + '/weight', self.dclllayer.i2h.weight.flatten(), epoch)
-        writer.add_histogram(self.name + '/bias', self.dclllayer.i2h.bias.flatten(), epoch)
+        if self.dclllayer.i2h.bias is not None:
+            writer.add_histogram(self.name + '/bias', self.dclllayer.i2h.bias.flatten(), epoch)
         if self.collect_stats and len(self.activity_hist):
             pd = np.mean(self._activity_rows(), axis=0)
             pd = pd / pd.sum()
@@ -899,6 +1008,7 @@ class DCLLBase(nn.Module):
         crit, opt = getattr(self, 'crit', None), getattr(self, 'optimizer', None)
         ok = (os.environ.get('DCLL_NATIVE_LEARNING', '1') != '0' and
               isinstance(self.dclllayer, (Conv2dDCLLlayer, DenseDCLLlayer)) and
+              not self.dclllayer.i2h._general() and            # (act / spiking / bias / stride ...: the autograd path)
               crit is not None and opt is not None and getattr(crit, 'reduction', None) == 'mean' and
               self.dclllayer.dropout is None)               # (lc_dropout: torch's mask and its gradient, autograd path)
         if ok and type(crit) is nn.SmoothL1Loss and getattr(crit, 'beta', 1.0) == 1.0:
@@ -1149,7 +1259,8 @@ class DCLLClassification(DCLLBase):
     def forward(self, input, ignore_burnin=False):
         L = self.dclllayer
         record = ignore_burnin or (self.iter + 1) >= self.burnin
-        fused = (record and isinstance(L, Conv2dDCLLlayer) and not L.dropout_active() and    # (a masked p: argmax after the mask)
+        fused = (record and isinstance(L, Conv2dDCLLlayer) and not L.i2h._general() and       # (torch readouts there)
+                 not L.dropout_active() and                                                    # (a masked p: argmax after the mask)
                  not (getattr(L, 'build_graph', False) and torch.is_grad_enabled()))      # (not the autograd node)
         if fused:
             L.__dict__['_finish'] = {'clout': True}     # the step's finishing launch also writes the argmax recorded below

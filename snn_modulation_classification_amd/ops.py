@@ -86,7 +86,7 @@ def layer_opts(desc, q8=None, presigmoid=False):
     o = LayerOpts()
     if q8 is not None:
         q, scale = q8
-        _expect(q, "w_q8", torch.int8, (desc.c_out, desc.c_in, desc.kh, desc.kw))
+        _expect(q, "w_q8", torch.int8, (desc.c_out, desc.c_in // desc.groups, desc.kh, desc.kw))
         _expect(scale, "w_scale", torch.float32, (desc.c_out,))
         o.w_q8, o.w_scale = ptr(q).value, ptr(scale).value
     o.pv_presigmoid = int(bool(presigmoid))
@@ -95,8 +95,8 @@ def layer_opts(desc, q8=None, presigmoid=False):
 
 def _check_layer_operands(desc, W, b, eps0, eps1, arp, B, tau=None, tau4=None):
     ch, cw, _, _ = conv_out_shape(desc)
-    _expect(W, "W", torch.float32, (desc.c_out, desc.c_in, desc.kh, desc.kw))
-    _expect(b, "b", torch.float32, (desc.c_out,))
+    _expect(W, "W", torch.float32, (desc.c_out, desc.c_in // desc.groups, desc.kh, desc.kw))
+    _expect(b, "b", torch.float32, (desc.c_out,))       # (None = bias=False: the generic kernels start their chains at 0)
     _expect(eps0, "eps0", torch.float32, (B, desc.c_in, desc.h, desc.w))
     _expect(eps1, "eps1", torch.float32, (B, desc.c_in, desc.h, desc.w))
     _expect(arp, "arp", torch.float32, (B, desc.c_out, ch, cw))
@@ -225,14 +225,14 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
             t = out[key] = torch.empty(shape, device=dev, dtype=torch.float32)
         _expect(t, key, torch.float32, shape)
         return t
-    dW = buf('dW', (desc.c_out, desc.c_in, desc.kh, desc.kw))
+    dW = buf('dW', (desc.c_out, desc.c_in // desc.groups, desc.kh, desc.kw))
     db = buf('db', (desc.c_out,))
     d_outW = buf('d_outW', (desc.target, K), want_out)
     d_outb = buf('d_outb', (desc.target,), want_out)
     # partial-sum rows for the weight gradient: one per workgroup, up to 256 (a sample of a large plane is many 16x16
     # tile jobs, so small batches still fill the chip); the same area then holds the batch chunks of the output_ gradient
     jobs = B * max(1, (desc.h // 16) * (desc.w // 16))
-    per_chunk = desc.c_out * (desc.c_in * desc.kh * desc.kw + 1)
+    per_chunk = desc.c_out * ((desc.c_in // desc.groups) * desc.kh * desc.kw + 1)
     nchunk = min(jobs, 1024 if desc.c_in == 1 else 256)      # (first layer: 128-thread workgroups, 6 KB partial rows)
     part = nchunk * per_chunk
     if want_out and desc.target <= 32 and K % 32 != 0:
@@ -259,7 +259,7 @@ def conv_lif_backward(desc, eps1, v, pv_pooled, g_p, g_o, g_pv, g_v, i2o_W, want
             ctypes.byref(part), ctypes.byref(nchunk), stream_ptr())
         check(rc, "dcll_conv_lif_backward_open")
         out['parts'] = dict(part=part.value, nchunk=nchunk.value, c_out=desc.c_out,
-                            rowlen=desc.c_in * desc.kh * desc.kw + 1, dW=dW, db=db, keep=scratch)
+                            rowlen=(desc.c_in // desc.groups) * desc.kh * desc.kw + 1, dW=dW, db=db, keep=scratch)
         return dW, db, d_outW, d_outb
     rc = _lib.get().dcll_conv_lif_backward(
         ctypes.byref(desc), ptr(eps1), ptr(v), ptr(pv_pooled), ptr(c(g_p)), ptr(c(g_o) if want_out else None),

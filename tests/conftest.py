@@ -60,3 +60,22 @@ def trained_checkpoint(tmp_path_factory):
     512 synthetic modulation windows (oracle/trained_parity.py) — the trained-weights parity tests share it."""
     from oracle import trained_parity
     return trained_parity.train_checkpoint(str(tmp_path_factory.mktemp("trained")), steps=40)
+
+
+# -- fixture G1x (round 6): layers built with the options ConvNetwork never uses -----------------------------------------------
+G1X_FIELDS = ("kind", "cin", "cout", "kh", "kw", "pad_h", "pad_w", "pool_h", "pool_w", "H", "W", "stride", "dilation", "groups",
+              "bias", "spiking", "act", "wrp100", "random_tau", "output_layer", "B", "learn")
+G1X_CASES = ["stride2_rrp", "dil2_pool2", "stride2_dil2_out", "stride3_k5", "tanh_plain", "tanh_rrp_out", "relu_stride2",
+             "nonspiking", "nonspiking_out", "i2h_groups2", "i2h_groups3_s2_rrp", "i2h_nobias", "i2h_nobias_groups2_dil2_tanh",
+             "i2h_depthwise", "dense_nobias", "dense_tanh_rrp", "dense_nonspiking"]
+G1X_LEARN_CASES = ["learn_stride2_tanh", "learn_dil2_nonspiking", "learn_dense_nobias_tanh"]
+
+
+def g1x_cfg(g, case):
+    """The cfg row of a G1x case (tests/golden/make_golden.py: G1X_CASES) as a namespace; .act_module() builds the activation."""
+    import types
+    import torch
+    c = types.SimpleNamespace(**{k: int(v) for k, v in zip(G1X_FIELDS, g["g1x/%s/cfg" % case])})
+    c.wrp = c.wrp100 / 100.0
+    c.act_module = lambda: {0: torch.nn.Sigmoid, 1: torch.nn.Tanh, 2: torch.nn.ReLU}[c.act]()
+    return c

@@ -20,6 +20,7 @@ modules; `yaml.load` given SafeLoader (PyYAML >= 6).
     python tests/golden/make_golden.py --only-carry # only the two-batch state carry-over run (added in round 5)
     python tests/golden/make_golden.py --only-refyaml-variants # only the arp 0 / scalar-tau runs of radio_ml_conv_ref.yaml (round 5)
     python tests/golden/make_golden.py --only-g6d # only the dense-slice learning steps (added in round 6)
+    python tests/golden/make_golden.py --only-g1x # only the layer-option cases: stride / dilation / groups / bias / act / spiking (round 6)
 
 Fixture list: G1 single layer-steps, G2 three-layer rollouts, G3 iq2spiketrain,
 G4 vote helpers, G5 load_network_spec, G6 train_dcll steps (reduced net), G6b train_dcll steps at the production geometry, G7 dense layer steps,
@@ -734,6 +735,106 @@ def g6d_dense_learning(lib):
     np.savez_compressed(os.path.join(OUT, "g6d_dense_learning.npz"), **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G1x (round 6): the constructor options ConvNetwork never uses — stride / dilation / groups other than 1, bias=False, an
+# activation other than nn.Sigmoid(), spiking=False (dcll/pytorch_libdcll.py:299-313, :407-426, :485-509, :75-148, :599-608).
+G1X_ACTS = {0: torch.nn.Sigmoid, 1: torch.nn.Tanh, 2: torch.nn.ReLU}
+# cfg row (int32): kind (0 Conv2dDCLLlayer, 1 ContinuousConv2D / ...RefractoryConv2D alone, 2 DenseDCLLlayer), cin, cout, kh, kw,
+#                  pad_h, pad_w, pool_h, pool_w, H, W, stride, dilation, groups, bias, spiking, act id, wrp * 100, random_tau,
+#                  output_layer, B, learn (1: two train_dcll steps instead of three forward steps)
+G1X_CASES = {
+    "stride2_rrp":      (0, 4, 6, 3, 3, 1, 1, 1, 1, 11, 12, 2, 1, 1, 1, 1, 0, 100, 1, 0, 3, 0),
+    "dil2_pool2":       (0, 3, 5, 3, 3, 2, 2, 2, 2, 10, 12, 1, 2, 1, 1, 1, 0, 0, 0, 0, 2, 0),
+    "stride2_dil2_out": (0, 4, 8, 3, 3, 2, 2, 1, 1, 13, 13, 2, 2, 1, 1, 1, 0, 50, 1, 1, 2, 0),
+    "stride3_k5":       (0, 2, 4, 5, 5, 2, 2, 1, 1, 17, 16, 3, 1, 1, 1, 1, 0, 0, 1, 0, 2, 0),
+    "tanh_plain":       (0, 4, 6, 3, 3, 1, 1, 2, 2, 12, 12, 1, 1, 1, 1, 1, 1, 0, 1, 0, 3, 0),
+    "tanh_rrp_out":     (0, 4, 6, 3, 3, 1, 1, 1, 1, 8, 8, 1, 1, 1, 1, 1, 1, 100, 0, 1, 2, 0),
+    "relu_stride2":     (0, 3, 6, 3, 3, 1, 1, 1, 1, 12, 10, 2, 1, 1, 1, 1, 2, 0, 0, 0, 2, 0),
+    "nonspiking":       (0, 4, 6, 3, 3, 1, 1, 2, 2, 12, 12, 1, 1, 1, 1, 0, 0, 0, 1, 0, 3, 0),
+    "nonspiking_out":   (0, 4, 6, 5, 5, 2, 2, 1, 1, 9, 9, 1, 1, 1, 1, 0, 0, 0, 0, 1, 2, 0),
+    "i2h_groups2":      (1, 4, 6, 3, 3, 1, 1, 1, 1, 10, 10, 1, 1, 2, 1, 1, 0, 0, 1, 0, 3, 0),
+    "i2h_groups3_s2_rrp": (1, 6, 9, 3, 3, 1, 1, 1, 1, 11, 9, 2, 1, 3, 1, 1, 0, 100, 1, 0, 2, 0),
+    "i2h_nobias":       (1, 4, 6, 3, 3, 1, 1, 1, 1, 10, 10, 1, 1, 1, 0, 1, 0, 0, 0, 0, 3, 0),
+    "i2h_nobias_groups2_dil2_tanh": (1, 4, 4, 3, 3, 2, 2, 1, 1, 10, 10, 1, 2, 2, 0, 1, 1, 100, 1, 0, 2, 0),
+    "i2h_depthwise":    (1, 5, 5, 3, 3, 1, 1, 1, 1, 9, 9, 1, 1, 5, 1, 1, 0, 0, 0, 0, 2, 0),
+    "dense_nobias":     (2, 40, 24, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0, 5, 0),
+    "dense_tanh_rrp":   (2, 40, 24, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 100, 0, 0, 5, 0),
+    "dense_nonspiking": (2, 40, 24, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0, 5, 0),
+    "learn_stride2_tanh": (0, 4, 6, 3, 3, 1, 1, 1, 1, 11, 12, 2, 1, 1, 1, 1, 1, 100, 1, 1, 4, 1),
+    "learn_dil2_nonspiking": (0, 3, 5, 3, 3, 2, 2, 2, 2, 10, 12, 1, 2, 1, 1, 0, 0, 0, 0, 0, 4, 1),
+    "learn_dense_nobias_tanh": (2, 40, 24, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0, 1, 1, 0, 0, 0, 5, 1),
+}
+
+
+def g1x_layer_options(lib):
+    """Three consecutive steps from zero state (or, `learn` cases, two train_dcll steps with burn-in 1: the second one learns)
+    of layers built with the options above; per case: cfg, the initial state dict, inputs, (output, pvoutput, pv, pvmem) and the
+    neuron state per step; learn cases: target, gradients of i2h.weight (/ i2h.bias, output_.*) of the learning step, loss."""
+    out = {}
+    for name, cfg in G1X_CASES.items():
+        (kind, cin, cout, kh, kw, pah, paw, poh, pow_, H, W, stride, dil, groups, bias, spiking, act_id, wrp100, rtau, outl, B,
+         learn) = cfg
+        seed(11)
+        act, wrp = G1X_ACTS[act_id](), wrp100 / 100.0
+        pre = "g1x/%s/" % name
+        out[pre + "cfg"] = np.asarray(cfg, dtype=np.int32)
+        if kind == 0:
+            layer = lib.Conv2dDCLLlayer(cin, cout, kernel_size=(kh, kw), padding=(pah, paw), pooling=(poh, pow_), im_dims=(H, W),
+                                        target_size=7, stride=stride, dilation=dil, alpha=.92, alphas=.85, alpharp=.65, wrp=wrp,
+                                        act=act, lc_ampl=.5, random_tau=bool(rtau), spiking=bool(spiking), lc_dropout=False,
+                                        output_layer=bool(outl)).init_hiddens(B)
+            mod, i2h, shape = layer, layer.i2h, (cin, H, W)
+        elif kind == 1:
+            kw_ = dict(stride=stride, padding=(pah, paw), dilation=dil, groups=groups, bias=bool(bias), alpha=.92, alphas=.85,
+                       act=act, random_tau=bool(rtau))
+            i2h = (lib.ContinuousRelativeRefractoryConv2D(cin, cout, (kh, kw), alpharp=.65, wrp=wrp, **kw_) if wrp > 0 else
+                   lib.ContinuousConv2D(cin, cout, (kh, kw), spiking=bool(spiking), **kw_))
+            i2h.init_state(B, (H, W))
+            mod, shape = i2h, (cin, H, W)
+        else:
+            layer = lib.DenseDCLLlayer(cin, cout, target_size=7, bias=bool(bias), alpha=.9, alphas=.85, alpharp=.65, wrp=wrp, act=act,
+                                       spiking=bool(spiking), random_tau=bool(rtau)).init_hiddens(B)
+            mod, i2h, shape = layer, layer.i2h, (cin,)
+        with torch.no_grad():               # a drive strong enough that both spike values occur
+            i2h.weight.mul_(200.0 if kind == 2 else 40.0)
+            if i2h.bias is not None:
+                i2h.bias.mul_(0.02 if kind == 2 else 0.05)
+        out.update(state_dict_np(mod, pre + "sd/"))
+        g = torch.Generator().manual_seed(5)
+        if learn:
+            sl = lib.DCLLClassification(dclllayer=layer, name="g1x", batch_size=B, loss=torch.nn.SmoothL1Loss,
+                                        optimizer=torch.optim.Adam,
+                                        kwargs_optimizer={"lr": 1e-6, "betas": [0.0, .95], "weight_decay": 10.0}, burnin=2)
+            out.update(state_dict_np(mod, pre + "sd/"))     # (DCLLBase.init re-ran init_hiddens: random_tau draws again)
+            labels = torch.randint(0, 7, (B,), generator=g)
+            tgt = torch.zeros(B, 7)
+            tgt[torch.arange(B), labels] = 1
+            out[pre + "target"] = npy(tgt)
+            sl.train()
+        for t in range(2 if learn else 3):
+            x = (torch.rand(B, *shape, generator=g) < 0.2).float()
+            out[pre + "x%d" % t] = npy(x)
+            if learn:
+                o, p, pv, v, l = sl.train_dcll(x, tgt, regularize=False)
+                out[pre + "loss%d" % t] = npy(l).reshape(-1)[:1]
+            elif kind == 1:
+                o, pv, v = mod.forward(x)
+                p = None
+            else:
+                o, p, pv, v = mod.forward(x)
+            for nm, val in (("o", o), ("p", p), ("pv", pv), ("v", v)):
+                if val is not None:
+                    out[pre + "%s%d" % (nm, t)] = npy(val)
+            for i, nm in enumerate(i2h.state._fields):
+                out[pre + "out_%s%d" % (nm, t)] = npy(i2h.state[i])
+        if learn:
+            for pn, prm in mod.named_parameters():
+                if prm.grad is not None:
+                    out[pre + "grad/" + pn] = npy(prm.grad)
+            out.update(state_dict_np(mod, pre + "sd1/"))
+    np.savez_compressed(os.path.join(OUT, "g1x_layer_options.npz"), **out)
+
+
 def g8_image(du):
     rng = np.random.RandomState(3)
     x = rng.rand(3, 6, 6).astype(np.float32)
@@ -811,6 +912,9 @@ def main():
     if "--only-g6d" in sys.argv:
         g6d_dense_learning(lib)
         return
+    if "--only-g1x" in sys.argv:
+        g1x_layer_options(lib)
+        return
     if "--only-variants" in sys.argv:
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -887,6 +991,8 @@ def main():
     meta["g6b"] = g6b_train_production(lib, nets, du)
     g7_dense(lib)
     g7b_dense_sequence(lib)
+    g6d_dense_learning(lib)
+    g1x_layer_options(lib)
     g2_carry(lib, nets, du)
     g8_image(du)
     meta["g9"] = g9_checkpoint(lib, nets, du)

@@ -469,8 +469,15 @@ def test_error_conventions(dev):
                               torch.zeros((32, 32, 7, 7), device=dev), torch.zeros(32, device=dev),
                               torch.ones((4, 32), device=dev), st(), st(), st(), 1, 1)
     d2 = ops.make_conv_desc(1, 4, (8, 8), 3, 1, 1, 10, False, False, 0.0, stride=2)
-    with pytest.raises(NotImplementedError):
-        ops.conv_out_shape(d2)
+    assert ops.conv_out_shape(d2) == (4, 4, 4, 4)               # (round 6: stride / dilation / groups run on the generic kernels)
+    with pytest.raises(ValueError):                             # groups must divide both channel counts
+        ops.conv_out_shape(ops.make_conv_desc(3, 4, (8, 8), 3, 1, 1, 10, False, False, 0.0, groups=2))
+    with pytest.raises(NotImplementedError):                    # ... but no fused sequence kernel takes them
+        d3 = ops.make_conv_desc(32, 32, (16, 16), 7, 3, 1, 24, False, True, 1.0, stride=2)
+        ops.conv_lif_sequence(d3, torch.zeros((1, 1, 32, 8), device=dev, dtype=torch.int32),
+                              torch.zeros((32, 32, 7, 7), device=dev), torch.zeros(32, device=dev),
+                              torch.ones((4, 32), device=dev), torch.zeros((1, 32, 16, 16), device=dev),
+                              torch.zeros((1, 32, 16, 16), device=dev), torch.zeros((1, 32, 8, 8), device=dev), 1, 1)
     with pytest.raises(_lib.DCLLHipError):
         ops.readout(torch.zeros(2, 4), torch.zeros(3, 4), None)      # CPU tensors: no CPU fallback
 

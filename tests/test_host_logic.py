@@ -598,14 +598,29 @@ def test_classification_slice_bookkeeping(cpu_device):
     assert L.get_predictions_by_vote(s.clout, y)[0].shape == (3,)
 
 
-def test_non_sigmoid_activation_is_refused(cpu_device):
-    """Every kernel hard-codes sigmoid: another `act` must fail loudly instead of giving wrong pv / gradients."""
+def test_layer_options_select_the_general_step(cpu_device):
+    """Round 6: an activation other than nn.Sigmoid(), spiking=False, bias=False, stride / dilation / groups other than 1 are
+    ACCEPTED (reference :299-313, :75-104) and route the layer to its general step — the fused kernels hard-code sigmoid, spikes
+    and a plain convolution, so such a layer must never reach them (the fused sequence path, the native learning step and the
+    fused readout tail are off for it); the default construction stays on the fused path.  (The arithmetic: tests/test_gpu_options.py.)"""
     L = cpu_device
-    with pytest.raises(NotImplementedError):
-        L.Conv2dDCLLlayer(1, 4, kernel_size=3, padding=1, pooling=1, im_dims=(8, 8), target_size=5, act=torch.nn.ReLU())
-    with pytest.raises(NotImplementedError):
-        L.DenseDCLLlayer(8, 4, target_size=5, act=torch.nn.Tanh())
-    L.Conv2dDCLLlayer(1, 4, kernel_size=3, padding=1, pooling=1, im_dims=(8, 8), target_size=5, act=torch.nn.Sigmoid())
+    mk = lambda **kw: L.Conv2dDCLLlayer(2, 4, kernel_size=3, padding=1, pooling=1, im_dims=(8, 8), target_size=5, **kw)
+    plain = mk(act=torch.nn.Sigmoid())
+    assert not plain.i2h._general()
+    for kw in (dict(act=torch.nn.ReLU()), dict(spiking=False), dict(stride=2), dict(dilation=2), dict(act=torch.nn.Tanh(), wrp=1.0)):
+        layer = mk(**kw)
+        assert layer.i2h._general() and layer.sequence_kind() is None, kw
+        sl = L.DCLLClassification(dclllayer=layer, batch_size=2, loss=torch.nn.SmoothL1Loss, optimizer=torch.optim.Adam,
+                                  kwargs_optimizer={"lr": 1e-6}, burnin=1)
+        assert sl._native_learning() is None, kw
+    assert L.ContinuousConv2D(4, 4, 3, groups=2)._general() and L.ContinuousConv2D(4, 4, 3, bias=False)._general()
+    assert L.ContinuousConv2D(4, 4, 3, groups=2).weight.shape == (4, 2, 3, 3)
+    for kw in (dict(act=torch.nn.Tanh()), dict(spiking=False), dict(bias=False)):
+        d = L.DenseDCLLlayer(8, 4, target_size=5, **kw)
+        assert d.i2h._general(), kw
+    assert not L.DenseDCLLlayer(8, 4, target_size=5).i2h._general()
+    with pytest.raises(Exception):          # (reference :556-558)
+        mk(spiking=False, wrp=1.0)
 
 
 # ---------------------------------------------------------------------------------------------- entry points

@@ -227,3 +227,45 @@ def test_g7b_dense_sequence_free_running(golden, case, cin, cout, wrp):
     assert np.array_equal(layer.state[0], g[pre + "final_eps0"]) and np.array_equal(layer.state[1], g[pre + "final_eps1"])
     if wrp > 0:
         assert np.array_equal(layer.state[2], g[pre + "final_arp"])
+
+
+@pytest.mark.parametrize("case", [c for c in __import__("conftest").G1X_CASES if not c.startswith("dense")])
+def test_g1x_layer_options_pinned_order_oracle(golden, case):
+    """Fixture G1x (round 6): conv layers with stride / dilation / groups other than 1 and bias=False through the pinned-order C
+    oracle, teacher-forced on the reference's state: traces bit-exact, v inside the rounding band, NO spike flip on these
+    fixtures (what lets the GPU test demand the reference's spikes).  (Activation / non-spiking output only change what is done
+    with v: checked on the GPU path and in test_oracle_torch.)"""
+    from conftest import g1x_cfg
+    g = golden("g1x_layer_options.npz")
+    c = g1x_cfg(g, case)
+    pre = "g1x/%s/" % case
+    sd = g.sub(pre + "sd/")
+    if c.kind == 1:                     # the bare i2h module: its state dict has no "i2h." prefix and no readout
+        sd = {"i2h." + k: v for k, v in sd.items()}
+    ch = (c.H + 2 * c.pad_h - c.dilation * (c.kh - 1) - 1) // c.stride + 1
+    cw = (c.W + 2 * c.pad_w - c.dilation * (c.kw - 1) - 1) // c.stride + 1
+    # (the oracle's readouts are not checked here: a one-row dummy over the un-pooled map, pooling (1, 1))
+    sd = dict(sd, **{"i2o.weight": np.zeros((1, c.cout * ch * cw), np.float32), "i2o.bias": np.zeros((1,), np.float32)})
+    W = sd["i2h.weight"]
+    bias = sd["i2h.bias"] if "i2h.bias" in sd else np.zeros(c.cout, np.float32)
+    layer = C.OracleConvLayer(sd, (c.H, c.W), (c.pad_h, c.pad_w), (1, 1), c.wrp, .65, False, c.stride, c.dilation, c.groups)
+    assert (layer.ch, layer.cw) == (ch, cw)
+    layer.init_state(c.B)
+    flips = 0
+    for t in range(3):
+        if t > 0:
+            layer.state[0][...] = g[pre + "out_eps0%d" % (t - 1)]
+            layer.state[1][...] = g[pre + "out_eps1%d" % (t - 1)]
+            if c.wrp > 0:
+                layer.state[2][...] = g[pre + "out_arp%d" % (t - 1)]
+        o, p, pv, v, s = layer.forward(g[pre + "x%d" % t])
+        assert np.array_equal(layer.state[0], g[pre + "out_eps0%d" % t]) and np.array_equal(layer.state[1], g[pre + "out_eps1%d" % t])
+        vr = g[pre + "v%d" % t]
+        bnd = 8 * EPS * F.conv2d(torch.from_numpy(np.abs(g[pre + "out_eps1%d" % t])), torch.from_numpy(np.abs(W)),
+                                 torch.from_numpy(np.abs(bias)), c.stride, (c.pad_h, c.pad_w), c.dilation, c.groups).numpy()
+        bnd = bnd + EPS * np.abs(vr)
+        assert v.shape == vr.shape and np.all(np.abs(v - vr) <= bnd), (case, t, np.abs(v - vr).max())
+        flips += int(((v > 0) != (vr > 0)).sum())
+        if c.wrp > 0 and flips == 0:
+            np.testing.assert_allclose(layer.state[2], g[pre + "out_arp%d" % t], atol=1e-6, rtol=0)
+    assert flips == 0, "choose another seed for %s: %d band-internal flips" % (case, flips)

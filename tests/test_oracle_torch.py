@@ -155,3 +155,38 @@ def test_g6d_dense_learning_steps_bit_exact(golden, name, wrp, reg):
     assert np.array_equal(b.detach().numpy(), g[pre + "sd1/i2h.bias"])
     for i, nm in enumerate(("eps0", "eps1", "arp")[:len(st)]):
         assert np.array_equal(st[i].numpy(), g[pre + "final_" + nm]), nm
+
+
+@pytest.mark.parametrize("case", __import__("conftest").G1X_CASES)
+def test_g1x_layer_options_torch_port_is_bit_identical(golden, case):
+    """Fixture G1x (round 6; make_golden.py --only-g1x): layers built with stride / dilation / groups other than 1, bias=False,
+    an activation other than nn.Sigmoid(), spiking=False (dcll/pytorch_libdcll.py:299-313, :75-104) — the torch restatement
+    with the same options reproduces the reference's three steps bit for bit (output, pvoutput, pv, pvmem, neuron state)."""
+    from conftest import g1x_cfg
+    g = golden("g1x_layer_options.npz")
+    c = g1x_cfg(g, case)
+    pre = "g1x/%s/" % case
+    sd = {k: torch.from_numpy(v) for k, v in g.sub(pre + "sd/").items()}
+    if c.kind == 2:
+        layer = R.RefDenseLayer(sd, c.wrp, .65, act=c.act_module(), spiking=bool(c.spiking))
+    else:
+        if c.kind == 1:         # (the bare i2h module: no readout tensors in its state dict)
+            sd = dict({"i2h." + k: v for k, v in sd.items()}, **{"i2o.weight": torch.zeros(1, 1), "i2o.bias": torch.zeros(1)})
+        layer = R.RefConvLayer(sd, (c.pad_h, c.pad_w), (c.pool_h, c.pool_w), c.wrp, .65, bool(c.output_layer), c.stride, c.dilation,
+                               c.groups, c.act_module(), bool(c.spiking))
+    for t in range(3):
+        x = torch.from_numpy(g[pre + "x%d" % t])
+        if c.kind == 1:
+            if layer.state is None:
+                layer.init_state(c.B, (c.H, c.W))
+            o, pv, v, layer.state = R.conv_lif_step(x, layer.w, layer.b, layer.alpha, layer.tau_m, layer.alphas, layer.tau_s,
+                                                    layer.state, .65, c.wrp, c.stride, layer.padding, c.dilation, c.groups,
+                                                    layer.act, layer.spiking)
+            got = {"o": o, "pv": pv, "v": v}
+        else:
+            o, p, pv, v = layer.forward(x)
+            got = {"o": o, "p": p, "pv": pv, "v": v}
+        for nm, val in got.items():
+            assert np.array_equal(val.numpy(), g[pre + "%s%d" % (nm, t)]), (case, t, nm)
+        for i, nm in enumerate(("eps0", "eps1", "arp")[:len(layer.state)]):
+            assert np.array_equal(layer.state[i].numpy(), g[pre + "out_%s%d" % (nm, t)]), (case, t, nm)
