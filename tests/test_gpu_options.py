@@ -212,3 +212,54 @@ def test_options_through_the_c_abi_vs_oracle(dev):
         dW, db, _, _ = ops.conv_lif_backward(d, eps1, v, None, None, None, None, t_(r), None, want_out=False)
         np.testing.assert_allclose(dW.cpu().numpy(), Wt.grad.numpy(), rtol=1e-4, atol=1e-5 * float(Wt.grad.abs().max()))
         np.testing.assert_allclose(db.cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=1e-5 * float(bt.grad.abs().max()))
+
+
+def test_int8_weights_with_groups_and_stride_equal_the_dequantised_run(dev):
+    """dcll_layer_opts.w_q8 (int8 conv weights + per-output-channel scale) on a grouped, strided, dilated layer — the generic kernel
+    converts a weight once, (float)q * scale[co]: v, spikes and state bit-identical to the call on the dequantised fp32 tensor."""
+    from snn_modulation_classification_amd import ops, quant
+    rng = np.random.RandomState(8)
+    cin, cout, groups, hw, B = 6, 9, 3, (12, 10), 3
+    W = torch.from_numpy((rng.randn(cout, cin // groups, 3, 3) * 0.3).astype(np.float32)).to(dev)
+    q, scale = quant.quantize_int8_per_channel(W)
+    Wd = quant.dequantize(q, scale).contiguous()
+    b = torch.from_numpy((rng.randn(cout) * 0.1).astype(np.float32)).to(dev)
+    tau = [torch.full((1,), v, device=dev) for v in (.92, 1. / (1 - .92), .85, 1. / (1 - .85))]
+    d = ops.make_conv_desc(cin, cout, hw, 3, 1, 1, 0, False, False, 1.0, .65, 2, 2, groups)
+    ch, cw, _, _ = ops.conv_out_shape(d)
+    runs = []
+    for q8 in (None, (q, scale)):
+        eps0 = torch.zeros((B, cin) + hw, device=dev)
+        eps1, arp = torch.zeros_like(eps0), torch.zeros((B, cout, ch, cw), device=dev)
+        outs = []
+        r2 = np.random.RandomState(9)
+        for _ in range(3):
+            x = torch.from_numpy((r2.uniform(size=(B, cin) + hw) < 0.3).astype(np.float32)).to(dev)
+            s, _, _, pv, v = ops.conv_lif_step(d, x, Wd, b, *tau, eps0, eps1, arp, q8=q8)
+            outs.append((s.clone(), v.clone()))
+        runs.append((outs, eps1.clone(), arp.clone()))
+    for (s0, v0), (s1, v1) in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(s0, s1) and bits_equal(v0.cpu().numpy(), v1.cpu().numpy())
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert float(runs[0][0][-1][0].mean()) not in (0.0, 1.0)       # (both spike values occur: not vacuous)
+
+
+def test_dense_forward_sequence_of_a_general_layer_equals_the_step_loop(dev):
+    """DenseDCLLlayer.forward_sequence on a layer outside the fused kernels (act = Tanh, bias=False): the step loop, stacked."""
+    from snn_modulation_classification_amd.dcll import pytorch_libdcll as L
+    torch.manual_seed(3)
+    mk = lambda: L.DenseDCLLlayer(40, 24, target_size=7, bias=False, alpha=.9, alphas=.85, wrp=1.0, act=torch.nn.Tanh()).to(dev)
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    with torch.no_grad():
+        a.i2h.weight.mul_(200.0)
+        b.i2h.weight.mul_(200.0)
+    x = (torch.rand(6, 5, 40, device=dev) < 0.2).float()
+    a.init_hiddens(5)
+    b.init_hiddens(5)
+    with torch.no_grad():
+        seq = a.forward_sequence(x, want_v=True)
+        steps = [b.forward(x[t]) for t in range(6)]
+    for k in range(4):
+        assert torch.equal(seq[k], torch.stack([s_[k] for s_ in steps])), k
+    assert 0.0 < float(seq[0].mean()) < 1.0
