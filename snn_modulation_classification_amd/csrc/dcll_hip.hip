@@ -439,9 +439,6 @@ __global__ __launch_bounds__(256) void k_bwd_wgrad(dcll_conv_desc d, int ch, int
 // registers) over the 128 pixel pairs: A[co][pixel pair], B[pixel pair][column] = one ds_read at an immediate offset
 // from the column's lane base.  Partial sums go to part[workgroup][co][1568 + 1] (k_bwd_reduce adds them in order).
 constexpr int WG32_GLD = 257;
-#ifndef STEP_PRIO_HALF
-#define STEP_PRIO_HALF 0
-#endif
 #ifndef WG32_SPLIT2_MAX_BATCH
 #define WG32_SPLIT2_MAX_BATCH 1024
 #endif
@@ -2307,13 +2304,6 @@ __global__ __launch_bounds__(256) void k_lif_step_c32(const float *__restrict__ 
         real0 = __builtin_amdgcn_s_memrealtime();           // constant 100 MHz: the shader clock under THIS load
     }
 
-#if STEP_PRIO_HALF
-    // (experiments/build_variant.sh -DSTEP_PRIO_HALF=1, round 6: the two workgroups that share a CU at two samples per CU are
-    //  blockIdx i and i + gridDim / 2 — the first at a raised priority, so that it finishes its chunk loop first and its
-    //  epilogue burst runs under the other's MFMAs.  Measured neutral — learn 0.5418 / 0.5411 vs 0.5415 / 0.5402 ms, test 0.2522 / 0.2525
-    //  vs 0.2520 / 0.2526 per timestep at B = 512, alternating runs — HISTORY.md "Round 6"; 0 in the product)
-    if (blockIdx.x < gridDim.x / 2) __builtin_amdgcn_s_setprio(3);
-#endif
     if (tid < 32) sbias[tid] = bias[tid];
     step_wchunk<Q8> wc;
     auto fetch_w = [&](int cp) { wc.fetch(cp); };
