@@ -1321,3 +1321,20 @@ def test_vote_tallies_equal_the_torch_construction(dev, B, L, n):
     cm, acc = parallel.split_tallies(got, n)
     assert int(cm.sum()) == L * B and all(int(got[l, -1]) == B for l in range(L))
     assert torch.equal(ops.vote_tallies(votes, labels, n), got)
+
+
+@pytest.mark.parametrize("B", [161, 255, 257, 511, 513, 1023, 1024, 1025])
+def test_weight_gradient_chunking_on_ragged_batches(dev, B):
+    """k_bwd_wgrad_c32 around the batch sizes where its chunking changes (round 6: 161 .. 1024 samples run 128 batch chunks x 2
+    column halves, ragged when 128 does not divide B; above, 256 chunks x 1): dW / db of a 32 -> 32 layer step from a given dL/dv
+    against a float64 reference on the device (unfold + matmul) — a mis-indexed or dropped job would be an error of order 1/B."""
+    from snn_modulation_classification_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B)
+    eps1 = torch.rand(B, 32, 16, 16, generator=g).to(dev)
+    gv = (torch.randn(B, 32, 16, 16, generator=g) / B).to(dev)
+    d = ops.make_conv_desc(32, 32, (16, 16), 7, 3, 1, 0, False, True, 1.0)
+    dW, db, _, _ = ops.conv_lif_backward(d, eps1, torch.zeros_like(gv), None, None, None, None, gv, None, want_out=False)
+    cols = torch.nn.functional.unfold(eps1.double(), 7, padding=3)                       # (B, 32*49, 256)
+    ref = torch.einsum("bop,bkp->ok", gv.double().reshape(B, 32, 256), cols).reshape(32, 32, 7, 7)
+    np.testing.assert_allclose(dW.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(ref.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), gv.double().sum((0, 2, 3)).cpu().numpy(), rtol=2e-4, atol=1e-6)
